@@ -1,0 +1,249 @@
+/*
+ * koaf.h -- C ABI of libkoaf.so: the hand-written gfx950 (MI355X / CDNA4) kernels under the
+ * koafusion train-step hot path.
+ *
+ * The reference (imedslab/OAProgressionMMF) has no FFI: its hot path is stock torch.nn called from
+ *   koafusion/models/_torchvision.py:118-138,141-246   (conv / BatchNorm2d / ReLU / MaxPool / GAP)
+ *   koafusion/models/_core_trf.py:118-205               (Linear / LayerNorm / GELU / attention)
+ *   koafusion/various/_losses.py:89-108                 (focal softmax-CE)
+ *   koafusion/preproc/_pt.py:175-200                    (F.interpolate x0.5 downscale)
+ *   torch.optim.Adam via koafusion/various/_optimizers.py:47-52
+ * Each entry point below names the reference call site it replaces.  All pointers are DEVICE
+ * pointers to fp32 (unless stated), all tensors are dense; activations are NHWC ("(n,h,w,c)",
+ * c fastest).  Nothing allocates; every call is asynchronous on `stream` (a hipStream_t passed as
+ * void*).  Return value: 0 = ok, negative = error (text via koaf_last_error()).
+ *
+ * Not thread-safe on one stream; re-entrant across devices/streams.
+ */
+#ifndef KOAF_H
+#define KOAF_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KOAF_OK 0
+#define KOAF_EINVAL (-1)
+#define KOAF_ELAUNCH (-2)
+
+int koaf_version(void);
+const char* koaf_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generic MFMA GEMM  C[M,N] = alpha * sum_k A(m,k) B(n,k)  (+bias[n]) (+residual[m,n])
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain).
+ * Each operand is either K-contiguous ("KC": element (r,k) at ptr + r*ld + k) or K-major
+ * ("KM": element (r,k) at ptr + k*ld + r).  Operands can be gathered on the fly from an NHWC
+ * tensor (implicit-GEMM convolution) and transformed on load with relu(sc[c]*x+sh[c]) -- the
+ * previous layer's BatchNorm+ReLU, so normalised activations never touch HBM.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct KoafOperand {
+    const float* ptr;
+    int64_t ld;       /* KC: stride between rows; KM: stride between k-rows */
+    int64_t bs0, bs1; /* batch strides (elements) for batch index z = z0*nb1 + z1 */
+    int64_t tap_stride; /* gather 3 (K-major weights [C][taps][rows]): offset between filter taps */
+    int32_t kind;     /* 0 = KC, 1 = KM */
+    int32_t gather;   /* 0 none; 1 conv forward gather; 2 transposed-conv (dgrad) gather;
+                         3 (KM only) tapped weights: k = (tap, c), element at c*ld + tap*tap_stride + r */
+    int32_t H, W, C;  /* source NHWC tensor dims for a gathered operand (C = channels per tap) */
+    int32_t CS;       /* channels per source pixel (0 = C); > C when the GEMM sees a channel slab */
+    int32_t PH, PW;   /* pixel grid the GEMM rows (KC) or the k index (KM) enumerate: (n,py,px) */
+    int32_t KH, KW, stride, pad;
+    int32_t tf;       /* 0 none; 1 relu(sc[c]*x + sh[c]) on load (c = source channel) */
+    const float* sc;
+    const float* sh;
+} KoafOperand;
+
+typedef struct KoafGemm {
+    KoafOperand A, B;
+    int32_t M, N, K;
+    int32_t nb0, nb1; /* batch = nb0*nb1 (>=1 each) */
+    int32_t splitk;   /* >=1; >1: C is a slab buffer [splitk][M][N] (ldc == N), no epilogue */
+    int32_t bm, bn;   /* block tile (64|128); 0 = pick */
+    float* C;
+    int64_t ldc, cbs0, cbs1;
+    float alpha;
+    int32_t _pad0;
+    const float* bias;     /* [N] or NULL */
+    const float* residual; /* [M][ldr] (+batch strides) or NULL */
+    int64_t ldr, rbs0, rbs1;
+    float* stats;          /* [ceil(M/bm)][2][stats_ld] per-M-tile column sum / sum of squares, or NULL */
+    int64_t stats_ld;      /* 0 = N */
+    int64_t stats_bs;      /* column offset per batch index (grouped conv slabs) */
+} KoafGemm;
+
+int koaf_gemm(const KoafGemm* g, void* stream);
+/* rows of `stats` koaf_gemm will write for (M, bm) -- callers size the buffer with this */
+int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn);
+/* out[i] = sum_s slabs[s][i], i < n  (deterministic split-K combine) */
+int koaf_slab_reduce(const float* slabs, int32_t nslab, int64_t n, float* out, void* stream);
+
+/* ---- Convolution (nn.Conv2d, bias-free; _torchvision.py:23-31) as implicit GEMM on NHWC -------
+ * x [N,H,W,Cin], w packed [Cout,KH,KW,Cin] (the memory of a channels_last (Cout,Cin,KH,KW)
+ * parameter), y [N,OH,OW,Cout].  in_sc/in_sh (nullable): fused BatchNorm+ReLU of the producer
+ * applied to x on load.  stats (nullable): per-M-tile column sums / sums of squares of y for the
+ * following BatchNorm (train mode), *stats_rows rows of [2][Cout].  */
+int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W,
+                    int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                    const float* in_sc, const float* in_sh, float* stats, int32_t* stats_rows,
+                    void* stream);
+/* rows of the stats buffer koaf_conv2d_fwd writes for M output pixels */
+int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout);
+/* dx [N,H,W,Cin] = conv_transpose(dy [N,OH,OW,Cout], w) (+residual: the other branch's gradient);
+ * w is read K-major in place (no re-packed copy).  */
+int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
+                      int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride,
+                      int32_t pad, const float* residual, void* stream);
+/* dw packed [Cout,KH,KW,Cin] = sum_pixels dy^T x, x optionally transformed on load.  Deterministic
+ * split-K: slabs = workspace of koaf_conv2d_wgrad_ws() floats (0 = none needed).  */
+int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                             int32_t KH, int32_t KW, int32_t stride, int32_t pad);
+int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int32_t N, int32_t H, int32_t W,
+                      int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride,
+                      int32_t pad, const float* in_sc, const float* in_sh, float* slabs,
+                      void* stream);
+
+/* ---- Grouped 3x3 convolution (ResNeXt 32x4d; _torchvision.py:110,327-330) -------------------
+ * Runs on the same MFMA GEMM as 64-channel block-diagonal slabs: packed weights [C][3][3][C/groups]
+ * are expanded to wexp [C/64][64][9][64] (zeros off the group blocks), gradients compressed back. */
+int koaf_gconv_expand_w(const float* w, float* wexp, int32_t C, int32_t groups, void* stream);
+int koaf_gconv_compress_dw(const float* dwexp, float* dw, int32_t C, int32_t groups, void* stream);
+int koaf_gconv3x3_fwd(const float* x, const float* wexp, float* y, int32_t N, int32_t H, int32_t W,
+                      int32_t C, int32_t stride, const float* in_sc, const float* in_sh,
+                      float* stats, int32_t* stats_rows, void* stream);
+int koaf_gconv3x3_dgrad(const float* dy, const float* wexp, float* dx, int32_t N, int32_t H,
+                        int32_t W, int32_t C, int32_t stride, void* stream);
+int64_t koaf_gconv3x3_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride);
+int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp, int32_t N, int32_t H,
+                        int32_t W, int32_t C, int32_t stride, const float* in_sc,
+                        const float* in_sh, float* slabs, void* stream);
+
+/* ---- Stem: 7x7 s2 p3 conv on the 1->3 channel-repeated image (_torchvision.py:170; the
+ * `repeat "b ch r c -> b (k ch) r c", k=3` of _xrNmrMcP.py:211-213 is folded: w1t = sum_c w[:,c]).
+ * x [N,H,W] (single channel), w1t [49][64], y [N,OH,OW,64].  */
+int koaf_stem_fwd(const float* x, const float* w1t, float* y, int32_t N, int32_t H, int32_t W,
+                  void* stream);
+int64_t koaf_stem_wgrad_ws(int32_t N, int32_t H, int32_t W);
+int koaf_stem_wgrad(const float* dy, const float* x, float* dw1t, int32_t N, int32_t H, int32_t W,
+                    float* slabs, void* stream);
+/* w [64,7,7,3] packed -> w1t [49][64] (sum over the 3 channels); gradient un-fold (copy x3) */
+int koaf_stem_fold_w(const float* w, float* w1t, void* stream);
+int koaf_stem_unfold_dw(const float* dw1t, float* dw, void* stream);
+
+/* ---- BatchNorm2d (nn.BatchNorm2d; _torchvision.py:172,121-131) ------------------------------- */
+/* per-block column sums / sums of squares of x [rows][C] -> part [*part_rows][2][C]
+ * (koaf_colpart_rows(rows, C) rows); for producers without a GEMM epilogue (stem). */
+int koaf_colstats(const float* x, int64_t rows, int32_t C, float* part, int32_t* part_rows,
+                  void* stream);
+int32_t koaf_colpart_rows(int64_t rows, int32_t C);
+/* stats [rows][2][C] -> mean, invstd, sc = gamma*invstd, sh = beta - mean*sc; train: updates
+ * running_mean/var (momentum, unbiased var) and ++num_batches_tracked (int64).  eval (train==0):
+ * stats ignored, uses running stats.  */
+int koaf_bn_finalize(const float* stats, int32_t rows, int32_t C, int64_t count,
+                     const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                     int32_t train, float* mean, float* invstd, float* sc, float* sh,
+                     void* stream);
+/* y = relu(sc*c + sh + identity-term); identity-term = idt (materialised) or idsc*idt+idsh
+ * (downsample branch BN folded).  Bottleneck tail, _torchvision.py:132-136.  */
+int koaf_bn_add_relu(const float* c, const float* sc, const float* sh, const float* idt,
+                     const float* idsc, const float* idsh, float* y, int64_t rows, int32_t C,
+                     void* stream);
+/* y = relu(sc*c+sh) materialised */
+int koaf_bn_relu(const float* c, const float* sc, const float* sh, float* y, int64_t rows,
+                 int32_t C, void* stream);
+/* backward reduce: dz = g * mask, partial sums of dz and dz*(c-mean)*invstd.
+ * mask_mode 0: none; 1: y>0 from tensor `ymask`; 2: sc*c+sh>0 recomputed.  If dz_out != NULL
+ * writes the masked gradient.  part [*part_rows][2][C] (koaf_colpart_rows rows). */
+int koaf_bn_bwd_reduce(const float* g, const float* c, const float* ymask, const float* sc,
+                       const float* sh, const float* mean, const float* invstd, int32_t mask_mode,
+                       float* dz_out, float* part, int32_t* part_rows, int64_t rows, int32_t C,
+                       void* stream);
+/* part -> dgamma, dbeta, and apply coefficients coef [3][C] = {sc, dbeta/M, sc*invstd*dgamma/M} */
+int koaf_bn_bwd_finalize(const float* part, int32_t part_rows, int32_t C, int64_t count,
+                         const float* sc, const float* invstd, float* dgamma, float* dbeta,
+                         float* coef, void* stream);
+/* dc = coef0*(dz - coef1) - coef2*(c - mean) */
+int koaf_bn_bwd_apply(const float* dz, const float* c, const float* mean, const float* coef,
+                      float* dc, int64_t rows, int32_t C, void* stream);
+
+/* ---- MaxPool2d 3x3 s2 p1 over relu(sc*c+sh) (_torchvision.py:173-174), GAP (:182) ------------ */
+int koaf_maxpool_fwd(const float* c, const float* sc, const float* sh, float* y, uint8_t* argmax,
+                     int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* da [N,H,W,C] (gradient wrt relu(bn(c))) gathered from dy via argmax (every element written) */
+int koaf_maxpool_bwd(const float* dy, const uint8_t* argmax, float* da, int32_t N, int32_t H,
+                     int32_t W, int32_t C, void* stream);
+int koaf_gap_fwd(const float* y, float* out, int32_t N, int32_t HW, int32_t C, void* stream);
+int koaf_gap_bwd(const float* dout, float* dy, int32_t N, int32_t HW, int32_t C, void* stream);
+
+/* ---- Input plumbing -------------------------------------------------------------------------- */
+/* "b ch r c s -> (b s) ch r c" (_xrNmrMcP.py:209-210): x [B,R,C,S] -> out [B*S,R,C] */
+int koaf_slice_fold(const float* x, float* out, int32_t B, int32_t R, int32_t Cc, int32_t S,
+                    void* stream);
+/* F.interpolate(scale 0.5, align_corners=False, (bi|tri)linear) == 2x average pooling
+ * (preproc/_pt.py:189-192).  x [B,R,C,S] -> out [B,R/2,C/2,S/fs], fs in {1,2}; S==1 for XR. */
+int koaf_downscale2(const float* x, float* out, int32_t B, int32_t R, int32_t Cc, int32_t S,
+                    int32_t fs, void* stream);
+
+/* ---- Transformer pieces (_core_trf.py) ------------------------------------------------------- */
+/* nn.Linear: y[M,N] = x[M,K] w[N,K]^T + b (+residual) */
+int koaf_linear_fwd(const float* x, const float* w, const float* b, const float* residual,
+                    float* y, int32_t M, int32_t N, int32_t K, void* stream);
+/* dx[M,K] = dy[M,N] w[N,K]  (w read K-major, no re-pack) (+residual) */
+int koaf_linear_dgrad(const float* dy, const float* w, const float* residual, float* dx,
+                      int32_t M, int32_t N, int32_t K, void* stream);
+/* dw[N,K] = dy^T x ; db[N] = column sums of dy (db nullable; ws: koaf_colsum_ws(M,N) floats) */
+int koaf_linear_wgrad(const float* dy, const float* x, float* dw, float* db, float* ws, int32_t M,
+                      int32_t N, int32_t K, void* stream);
+/* nn.LayerNorm(D) rows: y, save mean/rstd (_core_trf.py:190-192,198,202) */
+int koaf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                       float* mean, float* rstd, int32_t rows, int32_t D, float eps, void* stream);
+/* dx; dgamma/dbeta written (part: workspace of koaf_layernorm_bwd_ws floats) */
+int64_t koaf_layernorm_bwd_ws(int32_t rows, int32_t D);
+int koaf_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                       const float* rstd, float* dx, float* dgamma, float* dbeta, float* part,
+                       int32_t rows, int32_t D, void* stream);
+/* Attention core (_core_trf.py:170-180): qkv [B,n,3*h*d] with '(qkv h d)' split; scale applied to
+ * QK^T; attn [B,h,n,n] emitted (it is returned by the reference, :182); out [B,n,h*d].  */
+int koaf_attention_fwd(const float* qkv, float* attn, float* out, int32_t B, int32_t n, int32_t h,
+                       int32_t d, float scale, void* stream);
+/* dqkv (every element written) from dout; ws: workspace of B*h*n*n floats (dS).  */
+int koaf_attention_bwd(const float* dout, const float* qkv, const float* attn, float* dqkv,
+                       float* ws, int32_t B, int32_t n, int32_t h, int32_t d, float scale,
+                       void* stream);
+int koaf_softmax_rows(float* x, int64_t rows, int32_t n, void* stream);
+int koaf_softmax_bwd_rows(float* dp, const float* p, int64_t rows, int32_t n, float scale,
+                          void* stream);
+/* exact (erf) GELU, nn.GELU default (_core_trf.py:146) */
+int koaf_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+int koaf_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+int koaf_relu_fwd(const float* x, float* y, int64_t n, void* stream);
+int koaf_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+/* inverted dropout with a counter-based generator: y = x * keep(seed, i) / (1-p).  The same call
+ * with x := dy is the backward.  (nn.Dropout / nn.Dropout2d on (N,C,1,1); streams differ from
+ * torch's by construction -- SURVEY a10.)  */
+int koaf_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* out = a + b */
+int koaf_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* column sums of x [rows][C] -> out [C] (bias gradients); part: koaf_colsum_ws floats or NULL */
+int64_t koaf_colsum_ws(int32_t rows, int32_t C);
+int koaf_colsum(const float* x, float* out, int32_t rows, int32_t C, float* part, void* stream);
+
+/* ---- FocalLoss (_losses.py:89-108): loss = mean|sum( -(1-pt)^gamma * logpt ) ------------------
+ * logits [B,C], target int64 [B]; writes scalar loss and dlogits (= d loss / d logits).  */
+int koaf_focal_loss(const float* logits, const int64_t* target, float* loss, float* dlogits,
+                    int32_t B, int32_t C, float gamma, int32_t reduction_mean, void* stream);
+/* plain softmax-CE (CrossEntropyLoss wrapper, _losses.py:13-49), mean reduction */
+int koaf_ce_loss(const float* logits, const int64_t* target, float* loss, float* dlogits,
+                 int32_t B, int32_t C, void* stream);
+
+/* ---- torch.optim.Adam (coupled L2) over a flat arena (_optimizers.py:47-52) ------------------ */
+int koaf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int32_t step, int32_t adamw,
+                   void* stream);
+int koaf_fill(float* p, float value, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOAF_H */

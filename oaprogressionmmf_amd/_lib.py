@@ -1,0 +1,143 @@
+"""ctypes binding of libkoaf.so (the C ABI declared in include/koaf.h).
+
+The prototypes are parsed from the header itself, so the Python side cannot drift from the C side.
+There is no CPU fallback: if the library is missing, `lib()` raises -- the product path must fail
+loudly rather than silently run something else.
+"""
+import ctypes
+import os
+import re
+from pathlib import Path
+
+_ROOT = Path(__file__).resolve().parent
+HEADER = _ROOT.parent / "include" / "koaf.h"
+LIB_PATH = _ROOT / "csrc" / "libkoaf.so"
+
+
+class KoafOperand(ctypes.Structure):
+    _fields_ = [
+        ("ptr", ctypes.c_void_p),
+        ("ld", ctypes.c_int64),
+        ("bs0", ctypes.c_int64),
+        ("bs1", ctypes.c_int64),
+        ("tap_stride", ctypes.c_int64),
+        ("kind", ctypes.c_int32),
+        ("gather", ctypes.c_int32),
+        ("H", ctypes.c_int32),
+        ("W", ctypes.c_int32),
+        ("C", ctypes.c_int32),
+        ("CS", ctypes.c_int32),
+        ("PH", ctypes.c_int32),
+        ("PW", ctypes.c_int32),
+        ("KH", ctypes.c_int32),
+        ("KW", ctypes.c_int32),
+        ("stride", ctypes.c_int32),
+        ("pad", ctypes.c_int32),
+        ("tf", ctypes.c_int32),
+        ("sc", ctypes.c_void_p),
+        ("sh", ctypes.c_void_p),
+    ]
+
+
+class KoafGemm(ctypes.Structure):
+    _fields_ = [
+        ("A", KoafOperand),
+        ("B", KoafOperand),
+        ("M", ctypes.c_int32),
+        ("N", ctypes.c_int32),
+        ("K", ctypes.c_int32),
+        ("nb0", ctypes.c_int32),
+        ("nb1", ctypes.c_int32),
+        ("splitk", ctypes.c_int32),
+        ("bm", ctypes.c_int32),
+        ("bn", ctypes.c_int32),
+        ("C", ctypes.c_void_p),
+        ("ldc", ctypes.c_int64),
+        ("cbs0", ctypes.c_int64),
+        ("cbs1", ctypes.c_int64),
+        ("alpha", ctypes.c_float),
+        ("_pad0", ctypes.c_int32),
+        ("bias", ctypes.c_void_p),
+        ("residual", ctypes.c_void_p),
+        ("ldr", ctypes.c_int64),
+        ("rbs0", ctypes.c_int64),
+        ("rbs1", ctypes.c_int64),
+        ("stats", ctypes.c_void_p),
+        ("stats_ld", ctypes.c_int64),
+        ("stats_bs", ctypes.c_int64),
+    ]
+
+
+_SCALARS = {
+    "int": ctypes.c_int,
+    "int32_t": ctypes.c_int32,
+    "int64_t": ctypes.c_int64,
+    "uint64_t": ctypes.c_uint64,
+    "float": ctypes.c_float,
+}
+
+
+def _ctype(decl: str):
+    decl = decl.strip()
+    if "*" in decl:
+        base = decl.replace("const", "").replace("*", "").split()[0]
+        if base == "KoafGemm":
+            return ctypes.POINTER(KoafGemm)
+        if base == "char":
+            return ctypes.c_char_p
+        return ctypes.c_void_p
+    toks = decl.replace("const", "").split()
+    return _SCALARS[toks[0]]
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes])} for every function prototype in koaf.h"""
+    text = Path(path).read_text()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"typedef struct.*?\}\s*\w+;", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([\w\s\*]+?)\b(koaf_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if args in ("void", ""):
+            argtypes = []
+        else:
+            argtypes = []
+            for a in args.split(","):
+                a = a.strip()
+                # drop the parameter name (last identifier) unless it is part of the type
+                mm = re.match(r"(.*?)(\w+)$", a)
+                argtypes.append(_ctype(mm.group(1) if mm.group(1).strip() else a))
+        protos[name] = (_ctype(ret) if ret != "void" else None, argtypes)
+    return protos
+
+
+_LIB = None
+
+
+class KoafError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libkoaf.so (once).  Raises if the HIP extension has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = Path(os.environ.get("KOAF_LIB", LIB_PATH))
+    if not path.exists():
+        raise KoafError(
+            f"libkoaf.so not found at {path}: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C oaprogressionmmf_amd/csrc` -- there is no CPU fallback")
+    handle = ctypes.CDLL(str(path))
+    for name, (restype, argtypes) in parse_header().items():
+        fn = getattr(handle, name)  # AttributeError if a declared symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _LIB = handle
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().koaf_last_error()
+        raise KoafError(f"{what}: rc={rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,592 @@
+// koaf_conv.hip -- convolution / linear / attention entry points built on koaf_gemm, plus the two
+// pieces that are not GEMM-shaped: the 1-channel 7x7 stem and the grouped-conv weight expansion.
+#include <string.h>
+#include "koaf_common.h"
+
+namespace {
+
+inline void zero_gemm(KoafGemm* g) { *g = KoafGemm{}; g->alpha = 1.f; g->nb0 = g->nb1 = 1; g->splitk = 1; }
+
+inline int conv_out(int H, int K, int s, int p) { return (H + 2 * p - K) / s + 1; }
+
+// split-K plan for weight gradients: M x N output, K = pixels.  ~1024 blocks, >= 512 k-rows per split.
+struct WgradPlan { int bm, bn, splitk; };
+inline WgradPlan wgrad_plan(int M, int N, int64_t K, int ctap, int batch) {
+    WgradPlan p;
+    p.bn = (N >= 128 && (ctap % 128) == 0) ? 128 : 64;
+    p.bm = (M >= 128) ? 128 : 64;
+    int64_t tiles = cdiv64(M, p.bm) * cdiv64(N, p.bn) * batch;
+    int64_t sk = 1024 / tiles;
+    int64_t kmax = cdiv64(K, 512);
+    if (sk > kmax) sk = kmax;
+    if (sk < 1) sk = 1;
+    if (sk > 4096) sk = 4096;
+    p.splitk = (int)sk;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// slab reduce with batch: slabs [nb][ns][n] -> out [nb][n]
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) slab_reduce_b_kernel(const float* __restrict__ slabs, int ns, int64_t n,
+                                                            float* __restrict__ out) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float* sb = slabs + (int64_t)blockIdx.y * ns * n;
+    v4f a = *(const v4f*)(sb + i);
+    for (int s = 1; s < ns; ++s) a += *(const v4f*)(sb + (int64_t)s * n + i);
+    *(v4f*)(out + (int64_t)blockIdx.y * n + i) = a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stem: 7x7 s2 p3, one input channel (the 3 repeated channels folded into the weights)
+// block = 4 output rows x 16 output cols x 64 channels; thread = (channel, row)
+// ---------------------------------------------------------------------------------------------
+constexpr int ST_TH = 4, ST_TW = 16, ST_PH = 2 * ST_TH + 5, ST_PW = 2 * ST_TW + 5 + 3;  // patch 13 x 40
+
+__device__ __forceinline__ void stem_load_patch(float (*patch)[ST_PW], const float* __restrict__ x, int n, int H,
+                                                int W, int oy0, int ox0) {
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    for (int i = threadIdx.x; i < ST_PH * ST_PW; i += 256) {
+        const int py = i / ST_PW, px = i - py * ST_PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[((int64_t)n * H + iy) * W + ix];
+        patch[py][px] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1t,
+                                                       float* __restrict__ y, int N, int H, int W, int OH, int OW) {
+    __shared__ __attribute__((aligned(16))) float patch[ST_PH][ST_PW];
+    const int co = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int tx = (OW + ST_TW - 1) / ST_TW, ty = (OH + ST_TH - 1) / ST_TH;
+    int b = blockIdx.x;
+    const int bx = b % tx; b /= tx;
+    const int by = b % ty;
+    const int n = b / ty;
+    const int oy0 = by * ST_TH, ox0 = bx * ST_TW;
+    float wr[49];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) wr[k] = w1t[k * 64 + co];
+    stem_load_patch(patch, x, n, H, W, oy0, ox0);
+    __syncthreads();
+    const int oy = oy0 + pg;
+#pragma unroll 1
+    for (int q = 0; q < ST_TW / 2; ++q) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            const float* pr = &patch[2 * pg + kh][4 * q];
+            const v4f p0 = *(const v4f*)pr, p1 = *(const v4f*)(pr + 4);
+            const float p8 = pr[8];
+            const float pv[9] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3], p8};
+#pragma unroll
+            for (int kw = 0; kw < 7; ++kw) {
+                a0 += pv[kw] * wr[kh * 7 + kw];
+                a1 += pv[kw + 2] * wr[kh * 7 + kw];
+            }
+        }
+        const int ox = ox0 + 2 * q;
+        if (oy < OH) {
+            if (ox < OW) y[(((int64_t)n * OH + oy) * OW + ox) * 64 + co] = a0;
+            if (ox + 1 < OW) y[(((int64_t)n * OH + oy) * OW + ox + 1) * 64 + co] = a1;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         float* __restrict__ slabs, int N, int H, int W, int OH,
+                                                         int OW) {
+    __shared__ __attribute__((aligned(16))) float patch[ST_PH][ST_PW];
+    __shared__ float red[3][64][49 + 1];
+    const int co = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int tx = (OW + ST_TW - 1) / ST_TW, ty = (OH + ST_TH - 1) / ST_TH;
+    const int ntile = N * ty * tx;
+    float acc[49];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) acc[k] = 0.f;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        int b = tile;
+        const int bx = b % tx; b /= tx;
+        const int by = b % ty;
+        const int n = b / ty;
+        const int oy0 = by * ST_TH, ox0 = bx * ST_TW;
+        __syncthreads();
+        stem_load_patch(patch, x, n, H, W, oy0, ox0);
+        __syncthreads();
+        const int oy = oy0 + pg;
+#pragma unroll 1
+        for (int q = 0; q < ST_TW / 2; ++q) {
+            const int ox = ox0 + 2 * q;
+            float g0 = 0.f, g1 = 0.f;
+            if (oy < OH) {
+                if (ox < OW) g0 = dy[(((int64_t)n * OH + oy) * OW + ox) * 64 + co];
+                if (ox + 1 < OW) g1 = dy[(((int64_t)n * OH + oy) * OW + ox + 1) * 64 + co];
+            }
+#pragma unroll
+            for (int kh = 0; kh < 7; ++kh) {
+                const float* pr = &patch[2 * pg + kh][4 * q];
+                const v4f p0 = *(const v4f*)pr, p1 = *(const v4f*)(pr + 4);
+                const float p8 = pr[8];
+                const float pv[9] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3], p8};
+#pragma unroll
+                for (int kw = 0; kw < 7; ++kw) acc[kh * 7 + kw] += g0 * pv[kw] + g1 * pv[kw + 2];
+            }
+        }
+    }
+    // reduce the 4 row groups, write this block's slab [49][64]
+    __syncthreads();
+    if (pg > 0) {
+#pragma unroll
+        for (int k = 0; k < 49; ++k) red[pg - 1][co][k] = acc[k];
+    }
+    __syncthreads();
+    if (pg == 0) {
+        float* sl = slabs + (int64_t)blockIdx.x * 49 * 64;
+#pragma unroll
+        for (int k = 0; k < 49; ++k) sl[k * 64 + co] = acc[k] + red[0][co][k] + red[1][co][k] + red[2][co][k];
+    }
+}
+
+// w [64][49][3] -> w1t [49][64] (sum over the 3 identical input channels)
+__global__ void stem_fold_kernel(const float* __restrict__ w, float* __restrict__ w1t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 64 * 49) return;
+    const int co = i / 49, k = i - co * 49;
+    const float* s = w + (int64_t)i * 3;
+    w1t[k * 64 + co] = s[0] + s[1] + s[2];
+}
+__global__ void stem_unfold_kernel(const float* __restrict__ dw1t, float* __restrict__ dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 64 * 49) return;
+    const int co = i / 49, k = i - co * 49;
+    const float v = dw1t[k * 64 + co];
+    dw[(int64_t)i * 3 + 0] = v;
+    dw[(int64_t)i * 3 + 1] = v;
+    dw[(int64_t)i * 3 + 2] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// grouped 3x3: weights [C][9][Cg] <-> block-diagonal 64-channel slabs [C/64][64][9][64]
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gconv_expand_kernel(const float* __restrict__ w, float* __restrict__ wexp,
+                                                           int C, int Cg) {
+    const int64_t total = (int64_t)C * 9 * 64;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(i & 63);
+        int64_t r = i >> 6;
+        const int tap = (int)(r % 9);
+        const int co = (int)(r / 9);  // global output channel; slab = co/64
+        const int col = co & 63;
+        const int g0 = (col / Cg) * Cg;  // first slab-local input channel of co's group
+        float v = 0.f;
+        if (ci >= g0 && ci < g0 + Cg) v = w[((int64_t)co * 9 + tap) * Cg + (ci - g0)];
+        wexp[i] = v;
+    }
+}
+__global__ void __launch_bounds__(256) gconv_compress_kernel(const float* __restrict__ dwexp, float* __restrict__ dw,
+                                                             int C, int Cg) {
+    const int64_t total = (int64_t)C * 9 * Cg;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cg = (int)(i % Cg);
+        int64_t r = i / Cg;
+        const int tap = (int)(r % 9);
+        const int co = (int)(r / 9);
+        const int g0 = ((co & 63) / Cg) * Cg;
+        dw[i] = dwexp[((int64_t)co * 9 + tap) * 64 + g0 + cg];
+    }
+}
+
+}  // namespace
+
+#define STREAM ((hipStream_t)stream)
+
+// ================================================================================================
+// dense convolution
+// ================================================================================================
+extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W, int32_t Cin,
+                               int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, const float* in_sc,
+                               const float* in_sh, float* stats, int32_t* stats_rows, void* stream) {
+    KOAF_REQUIRE(x && w && y && N > 0 && Cin % 32 == 0 && Cout % 4 == 0, "koaf_conv2d_fwd: bad args (Cin=%d Cout=%d)",
+                 Cin, Cout);
+    KOAF_REQUIRE((in_sc == nullptr) == (in_sh == nullptr), "koaf_conv2d_fwd: in_sc/in_sh come together");
+    const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
+    const int64_t M = (int64_t)N * OH * OW;
+    KOAF_REQUIRE(M < (1ll << 31), "koaf_conv2d_fwd: too many output pixels");
+    KoafGemm g;
+    zero_gemm(&g);
+    g.A.ptr = x;
+    g.A.kind = 0;
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {
+        g.A.gather = 0;
+        g.A.ld = Cin;
+    } else {
+        g.A.gather = 1;
+        g.A.H = H; g.A.W = W; g.A.C = Cin; g.A.CS = Cin;
+        g.A.PH = OH; g.A.PW = OW;
+        g.A.KH = KH; g.A.KW = KW; g.A.stride = stride; g.A.pad = pad;
+    }
+    if (in_sc) { g.A.tf = 1; g.A.sc = in_sc; g.A.sh = in_sh; }
+    g.B.ptr = w;
+    g.B.kind = 0;
+    g.B.ld = (int64_t)KH * KW * Cin;
+    g.M = (int)M; g.N = Cout; g.K = KH * KW * Cin;
+    g.C = y; g.ldc = Cout;
+    g.stats = stats;
+    koaf_gemm_pick_tile(&g, &g.bm, &g.bn);
+    if (stats_rows) *stats_rows = (int)cdiv64(M, g.bm);
+    return koaf_gemm(&g, stream);
+}
+
+extern "C" int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout) {
+    KoafGemm g;
+    zero_gemm(&g);
+    g.M = (int)M; g.N = Cout; g.K = 32;
+    koaf_gemm_pick_tile(&g, &g.bm, &g.bn);
+    return (int32_t)cdiv64(M, g.bm);
+}
+
+extern "C" int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
+                                 int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                                 const float* residual, void* stream) {
+    KOAF_REQUIRE(dy && w && dx && N > 0 && Cout % 32 == 0 && Cin % 4 == 0, "koaf_conv2d_dgrad: bad args");
+    const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
+    const int64_t M = (int64_t)N * H * W;
+    KOAF_REQUIRE(M < (1ll << 31), "koaf_conv2d_dgrad: too many pixels");
+    KoafGemm g;
+    zero_gemm(&g);
+    g.A.ptr = dy;
+    g.A.kind = 0;
+    g.B.ptr = w;
+    g.B.kind = 1;
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {
+        g.A.gather = 0;
+        g.A.ld = Cout;
+        g.B.gather = 0;
+        g.B.ld = Cin;  // element (cin, k=cout) at w + cout*Cin + cin
+    } else {
+        g.A.gather = 2;
+        g.A.H = OH; g.A.W = OW; g.A.C = Cout; g.A.CS = Cout;
+        g.A.PH = H; g.A.PW = W;
+        g.A.KH = KH; g.A.KW = KW; g.A.stride = stride; g.A.pad = pad;
+        g.B.gather = 3;
+        g.B.C = Cout;
+        g.B.ld = (int64_t)KH * KW * Cin;
+        g.B.tap_stride = Cin;
+    }
+    g.M = (int)M; g.N = Cin; g.K = KH * KW * Cout;
+    g.C = dx; g.ldc = Cin;
+    g.residual = residual; g.ldr = Cin;
+    return koaf_gemm(&g, stream);
+}
+
+extern "C" int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH,
+                                        int32_t KW, int32_t stride, int32_t pad) {
+    const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
+    WgradPlan p = wgrad_plan(Cout, KH * KW * Cin, (int64_t)N * OH * OW, Cin, 1);
+    return p.splitk > 1 ? (int64_t)p.splitk * Cout * KH * KW * Cin : 0;
+}
+
+extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int32_t N, int32_t H, int32_t W,
+                                 int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                                 const float* in_sc, const float* in_sh, float* slabs, void* stream) {
+    KOAF_REQUIRE(dy && x && dw && N > 0 && Cin % 64 == 0 && Cout % 4 == 0, "koaf_conv2d_wgrad: bad args");
+    KOAF_REQUIRE((in_sc == nullptr) == (in_sh == nullptr), "koaf_conv2d_wgrad: in_sc/in_sh come together");
+    const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
+    const int64_t P = (int64_t)N * OH * OW;
+    KOAF_REQUIRE(P < (1ll << 31), "koaf_conv2d_wgrad: too many pixels");
+    const int Ntot = KH * KW * Cin;
+    WgradPlan p = wgrad_plan(Cout, Ntot, P, Cin, 1);
+    KOAF_REQUIRE(p.splitk == 1 || slabs, "koaf_conv2d_wgrad: workspace required");
+    KoafGemm g;
+    zero_gemm(&g);
+    g.A.ptr = dy; g.A.kind = 1; g.A.ld = Cout;
+    g.B.ptr = x; g.B.kind = 1;
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {
+        g.B.gather = 0;
+        g.B.ld = Cin;
+    } else {
+        g.B.gather = 1;
+        g.B.H = H; g.B.W = W; g.B.C = Cin; g.B.CS = Cin;
+        g.B.PH = OH; g.B.PW = OW;
+        g.B.KH = KH; g.B.KW = KW; g.B.stride = stride; g.B.pad = pad;
+    }
+    if (in_sc) { g.B.tf = 1; g.B.sc = in_sc; g.B.sh = in_sh; }
+    g.M = Cout; g.N = Ntot; g.K = (int)P;
+    g.bm = p.bm; g.bn = p.bn; g.splitk = p.splitk;
+    g.C = p.splitk > 1 ? slabs : dw;
+    g.ldc = Ntot;
+    int rc = koaf_gemm(&g, stream);
+    if (rc != KOAF_OK || p.splitk == 1) return rc;
+    return koaf_slab_reduce(slabs, p.splitk, (int64_t)Cout * Ntot, dw, stream);
+}
+
+// ================================================================================================
+// grouped 3x3 (ResNeXt) as 64-channel block-diagonal slabs through the same GEMM
+// ================================================================================================
+extern "C" int koaf_gconv_expand_w(const float* w, float* wexp, int32_t C, int32_t groups, void* stream) {
+    KOAF_REQUIRE(w && wexp && C % 64 == 0 && groups > 0 && C % groups == 0 && 64 % (C / groups) == 0,
+                 "koaf_gconv_expand_w: C=%d groups=%d unsupported", C, groups);
+    hipLaunchKernelGGL(gconv_expand_kernel, dim3(1024), dim3(256), 0, STREAM, w, wexp, C, C / groups);
+    return koaf_check_launch("koaf_gconv_expand_w");
+}
+extern "C" int koaf_gconv_compress_dw(const float* dwexp, float* dw, int32_t C, int32_t groups, void* stream) {
+    KOAF_REQUIRE(dwexp && dw && C % 64 == 0 && groups > 0 && C % groups == 0 && 64 % (C / groups) == 0,
+                 "koaf_gconv_compress_dw: C=%d groups=%d unsupported", C, groups);
+    hipLaunchKernelGGL(gconv_compress_kernel, dim3(512), dim3(256), 0, STREAM, dwexp, dw, C, C / groups);
+    return koaf_check_launch("koaf_gconv_compress_dw");
+}
+
+extern "C" int koaf_gconv3x3_fwd(const float* x, const float* wexp, float* y, int32_t N, int32_t H, int32_t W,
+                                 int32_t C, int32_t stride, const float* in_sc, const float* in_sh, float* stats,
+                                 int32_t* stats_rows, void* stream) {
+    KOAF_REQUIRE(x && wexp && y && N > 0 && C % 64 == 0, "koaf_gconv3x3_fwd: bad args");
+    const int OH = conv_out(H, 3, stride, 1), OW = conv_out(W, 3, stride, 1);
+    const int64_t M = (int64_t)N * OH * OW;
+    KOAF_REQUIRE(M < (1ll << 31), "koaf_gconv3x3_fwd: too many pixels");
+    KoafGemm g;
+    zero_gemm(&g);
+    g.nb1 = C / 64;
+    g.A.ptr = x; g.A.kind = 0; g.A.gather = 1; g.A.bs1 = 64;
+    g.A.H = H; g.A.W = W; g.A.C = 64; g.A.CS = C; g.A.PH = OH; g.A.PW = OW;
+    g.A.KH = 3; g.A.KW = 3; g.A.stride = stride; g.A.pad = 1;
+    if (in_sc) { g.A.tf = 1; g.A.sc = in_sc; g.A.sh = in_sh; }
+    g.B.ptr = wexp; g.B.kind = 0; g.B.ld = 576; g.B.bs1 = 64 * 576;
+    g.M = (int)M; g.N = 64; g.K = 576;
+    g.C = y; g.ldc = C; g.cbs1 = 64;
+    g.stats = stats; g.stats_ld = C; g.stats_bs = 64;
+    g.bn = 64; g.bm = 128;
+    if (stats_rows) *stats_rows = (int)cdiv64(M, g.bm);
+    // per-slab transform pointers: the kernel indexes sc/sh by the slab-local channel, so shift via batch
+    // is not available -> handled by passing absolute channel pointers through A.sc + 64*z (see below)
+    if (in_sc) {
+        // launch one slab at a time (few slabs; keeps the operand descriptor simple)
+        for (int z = 0; z < C / 64; ++z) {
+            KoafGemm s = g;
+            s.nb1 = 1;
+            s.A.ptr = x + 64 * z; s.A.sc = in_sc + 64 * z; s.A.sh = in_sh + 64 * z;
+            s.B.ptr = wexp + (int64_t)z * 64 * 576;
+            s.C = y + 64 * z;
+            s.stats = stats ? stats + 64 * z : nullptr; s.stats_bs = 0;
+            int rc = koaf_gemm(&s, stream);
+            if (rc != KOAF_OK) return rc;
+        }
+        return KOAF_OK;
+    }
+    return koaf_gemm(&g, stream);
+}
+
+extern "C" int koaf_gconv3x3_dgrad(const float* dy, const float* wexp, float* dx, int32_t N, int32_t H, int32_t W,
+                                   int32_t C, int32_t stride, void* stream) {
+    KOAF_REQUIRE(dy && wexp && dx && N > 0 && C % 64 == 0, "koaf_gconv3x3_dgrad: bad args");
+    const int OH = conv_out(H, 3, stride, 1), OW = conv_out(W, 3, stride, 1);
+    const int64_t M = (int64_t)N * H * W;
+    KOAF_REQUIRE(M < (1ll << 31), "koaf_gconv3x3_dgrad: too many pixels");
+    KoafGemm g;
+    zero_gemm(&g);
+    g.nb1 = C / 64;
+    g.A.ptr = dy; g.A.kind = 0; g.A.gather = 2; g.A.bs1 = 64;
+    g.A.H = OH; g.A.W = OW; g.A.C = 64; g.A.CS = C; g.A.PH = H; g.A.PW = W;
+    g.A.KH = 3; g.A.KW = 3; g.A.stride = stride; g.A.pad = 1;
+    g.B.ptr = wexp; g.B.kind = 1; g.B.gather = 3; g.B.C = 64; g.B.ld = 576; g.B.tap_stride = 64;
+    g.B.bs1 = 64 * 576;
+    g.M = (int)M; g.N = 64; g.K = 576;
+    g.C = dx; g.ldc = C; g.cbs1 = 64;
+    g.bn = 64; g.bm = 128;
+    return koaf_gemm(&g, stream);
+}
+
+extern "C" int64_t koaf_gconv3x3_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride) {
+    const int OH = conv_out(H, 3, stride, 1), OW = conv_out(W, 3, stride, 1);
+    WgradPlan p = wgrad_plan(64, 576, (int64_t)N * OH * OW, 64, C / 64);
+    return (int64_t)p.splitk * C * 576;
+}
+
+// dwexp [C/64][64][9][64]
+extern "C" int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp, int32_t N, int32_t H, int32_t W,
+                                   int32_t C, int32_t stride, const float* in_sc, const float* in_sh, float* slabs,
+                                   void* stream) {
+    KOAF_REQUIRE(dy && x && dwexp && slabs && N > 0 && C % 64 == 0, "koaf_gconv3x3_wgrad: bad args");
+    const int OH = conv_out(H, 3, stride, 1), OW = conv_out(W, 3, stride, 1);
+    const int64_t P = (int64_t)N * OH * OW;
+    KOAF_REQUIRE(P < (1ll << 31), "koaf_gconv3x3_wgrad: too many pixels");
+    const int nz = C / 64;
+    WgradPlan p = wgrad_plan(64, 576, P, 64, nz);
+    for (int z = 0; z < nz; ++z) {
+        KoafGemm g;
+        zero_gemm(&g);
+        g.A.ptr = dy + 64 * z; g.A.kind = 1; g.A.ld = C;
+        g.B.ptr = x + 64 * z; g.B.kind = 1; g.B.gather = 1;
+        g.B.H = H; g.B.W = W; g.B.C = 64; g.B.CS = C; g.B.PH = OH; g.B.PW = OW;
+        g.B.KH = 3; g.B.KW = 3; g.B.stride = stride; g.B.pad = 1;
+        if (in_sc) { g.B.tf = 1; g.B.sc = in_sc + 64 * z; g.B.sh = in_sh + 64 * z; }
+        g.M = 64; g.N = 576; g.K = (int)P;
+        g.bm = 64; g.bn = 64; g.splitk = p.splitk;
+        g.C = slabs + (int64_t)z * p.splitk * 64 * 576;
+        g.ldc = 576;
+        int rc = koaf_gemm(&g, stream);
+        if (rc != KOAF_OK) return rc;
+    }
+    const int64_t n = 64 * 576;
+    hipLaunchKernelGGL(slab_reduce_b_kernel, dim3((unsigned)cdiv64(n / 4, 256), nz), dim3(256), 0, STREAM, slabs,
+                       p.splitk, n, dwexp);
+    return koaf_check_launch("koaf_gconv3x3_wgrad");
+}
+
+// ================================================================================================
+// stem
+// ================================================================================================
+extern "C" int koaf_stem_fwd(const float* x, const float* w1t, float* y, int32_t N, int32_t H, int32_t W,
+                             void* stream) {
+    KOAF_REQUIRE(x && w1t && y && N > 0 && H > 0 && W > 0, "koaf_stem_fwd: bad args");
+    const int OH = conv_out(H, 7, 2, 3), OW = conv_out(W, 7, 2, 3);
+    const int64_t blocks = (int64_t)N * cdiv64(OH, ST_TH) * cdiv64(OW, ST_TW);
+    KOAF_REQUIRE(blocks < (1ll << 31), "koaf_stem_fwd: grid too large");
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM, x, w1t, y, N, H, W, OH, OW);
+    return koaf_check_launch("koaf_stem_fwd");
+}
+static inline int stem_wgrad_blocks(int N, int H, int W) {
+    const int OH = conv_out(H, 7, 2, 3), OW = conv_out(W, 7, 2, 3);
+    int64_t tiles = (int64_t)N * cdiv64(OH, ST_TH) * cdiv64(OW, ST_TW);
+    return (int)(tiles < 1024 ? tiles : 1024);
+}
+extern "C" int64_t koaf_stem_wgrad_ws(int32_t N, int32_t H, int32_t W) {
+    return (int64_t)stem_wgrad_blocks(N, H, W) * 49 * 64;
+}
+extern "C" int koaf_stem_wgrad(const float* dy, const float* x, float* dw1t, int32_t N, int32_t H, int32_t W,
+                               float* slabs, void* stream) {
+    KOAF_REQUIRE(dy && x && dw1t && slabs && N > 0, "koaf_stem_wgrad: bad args");
+    const int OH = conv_out(H, 7, 2, 3), OW = conv_out(W, 7, 2, 3);
+    const int nb = stem_wgrad_blocks(N, H, W);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb), dim3(256), 0, STREAM, dy, x, slabs, N, H, W, OH, OW);
+    int rc = koaf_check_launch("koaf_stem_wgrad");
+    if (rc != KOAF_OK) return rc;
+    return koaf_slab_reduce(slabs, nb, 49 * 64, dw1t, stream);
+}
+extern "C" int koaf_stem_fold_w(const float* w, float* w1t, void* stream) {
+    KOAF_REQUIRE(w && w1t, "koaf_stem_fold_w: bad args");
+    hipLaunchKernelGGL(stem_fold_kernel, dim3((64 * 49 + 255) / 256), dim3(256), 0, STREAM, w, w1t);
+    return koaf_check_launch("koaf_stem_fold_w");
+}
+extern "C" int koaf_stem_unfold_dw(const float* dw1t, float* dw, void* stream) {
+    KOAF_REQUIRE(dw1t && dw, "koaf_stem_unfold_dw: bad args");
+    hipLaunchKernelGGL(stem_unfold_kernel, dim3((64 * 49 + 255) / 256), dim3(256), 0, STREAM, dw1t, dw);
+    return koaf_check_launch("koaf_stem_unfold_dw");
+}
+
+// ================================================================================================
+// nn.Linear
+// ================================================================================================
+extern "C" int koaf_linear_fwd(const float* x, const float* w, const float* b, const float* residual, float* y,
+                               int32_t M, int32_t N, int32_t K, void* stream) {
+    KOAF_REQUIRE(x && w && y && M > 0 && N > 0 && K > 0, "koaf_linear_fwd: bad args");
+    KoafGemm g;
+    zero_gemm(&g);
+    g.A.ptr = x; g.A.kind = 0; g.A.ld = K;
+    g.B.ptr = w; g.B.kind = 0; g.B.ld = K;
+    g.M = M; g.N = N; g.K = K;
+    g.C = y; g.ldc = N;
+    g.bias = b;
+    g.residual = residual; g.ldr = N;
+    return koaf_gemm(&g, stream);
+}
+extern "C" int koaf_linear_dgrad(const float* dy, const float* w, const float* residual, float* dx, int32_t M,
+                                 int32_t N, int32_t K, void* stream) {
+    KOAF_REQUIRE(dy && w && dx && M > 0 && N > 0 && K > 0, "koaf_linear_dgrad: bad args");
+    KoafGemm g;
+    zero_gemm(&g);
+    g.A.ptr = dy; g.A.kind = 0; g.A.ld = N;
+    g.B.ptr = w; g.B.kind = 1; g.B.ld = K;  // element (r = k_in, kk = n_out) at w + n_out*K + k_in
+    g.M = M; g.N = K; g.K = N;
+    g.C = dx; g.ldc = K;
+    g.residual = residual; g.ldr = K;
+    return koaf_gemm(&g, stream);
+}
+extern "C" int koaf_linear_wgrad(const float* dy, const float* x, float* dw, float* db, float* ws, int32_t M, int32_t N,
+                                 int32_t K, void* stream) {
+    KOAF_REQUIRE(dy && x && dw && M > 0 && N > 0 && K > 0, "koaf_linear_wgrad: bad args");
+    KoafGemm g;
+    zero_gemm(&g);
+    g.A.ptr = dy; g.A.kind = 1; g.A.ld = N;
+    g.B.ptr = x; g.B.kind = 1; g.B.ld = K;
+    g.M = N; g.N = K; g.K = M;
+    g.C = dw; g.ldc = K;
+    int rc = koaf_gemm(&g, stream);
+    if (rc != KOAF_OK || !db) return rc;
+    return koaf_colsum(dy, db, M, N, ws, stream);
+}
+
+// ================================================================================================
+// attention core: S = scale*Q K^T -> softmax -> P V, and its backward (all on koaf_gemm, batched
+// over (b, head) with strided operands straight out of the fused qkv buffer)
+// ================================================================================================
+extern "C" int koaf_attention_fwd(const float* qkv, float* attn, float* out, int32_t B, int32_t n, int32_t h,
+                                  int32_t d, float scale, void* stream) {
+    KOAF_REQUIRE(qkv && attn && out && B > 0 && n > 0 && h > 0 && d > 0, "koaf_attention_fwd: bad args");
+    const int64_t ld = 3ll * h * d;
+    KoafGemm g;
+    zero_gemm(&g);
+    g.nb0 = B; g.nb1 = h;
+    g.A.ptr = qkv; g.A.kind = 0; g.A.ld = ld; g.A.bs0 = n * ld; g.A.bs1 = d;
+    g.B.ptr = qkv + (int64_t)h * d; g.B.kind = 0; g.B.ld = ld; g.B.bs0 = n * ld; g.B.bs1 = d;
+    g.M = n; g.N = n; g.K = d;
+    g.C = attn; g.ldc = n; g.cbs0 = (int64_t)h * n * n; g.cbs1 = (int64_t)n * n;
+    g.alpha = scale;
+    g.bm = 64; g.bn = 64;
+    int rc = koaf_gemm(&g, stream);
+    if (rc != KOAF_OK) return rc;
+    rc = koaf_softmax_rows(attn, (int64_t)B * h * n, n, stream);
+    if (rc != KOAF_OK) return rc;
+    zero_gemm(&g);
+    g.nb0 = B; g.nb1 = h;
+    g.A.ptr = attn; g.A.kind = 0; g.A.ld = n; g.A.bs0 = (int64_t)h * n * n; g.A.bs1 = (int64_t)n * n;
+    g.B.ptr = qkv + 2ll * h * d; g.B.kind = 1; g.B.ld = ld; g.B.bs0 = n * ld; g.B.bs1 = d;
+    g.M = n; g.N = d; g.K = n;
+    g.C = out; g.ldc = (int64_t)h * d; g.cbs0 = (int64_t)n * h * d; g.cbs1 = d;
+    g.bm = 64; g.bn = 64;
+    return koaf_gemm(&g, stream);
+}
+
+extern "C" int koaf_attention_bwd(const float* dout, const float* qkv, const float* attn, float* dqkv, float* ws,
+                                  int32_t B, int32_t n, int32_t h, int32_t d, float scale, void* stream) {
+    KOAF_REQUIRE(dout && qkv && attn && dqkv && ws && B > 0 && n > 0 && h > 0 && d > 0, "koaf_attention_bwd: bad args");
+    const int64_t ld = 3ll * h * d, hd = (int64_t)h * d;
+    const int64_t pb0 = (int64_t)h * n * n, pb1 = (int64_t)n * n;
+    KoafGemm g;
+    int rc;
+    // dV[j,dd] = sum_i P[i,j] dO[i,dd]
+    zero_gemm(&g);
+    g.nb0 = B; g.nb1 = h; g.bm = 64; g.bn = 64;
+    g.A.ptr = attn; g.A.kind = 1; g.A.ld = n; g.A.bs0 = pb0; g.A.bs1 = pb1;
+    g.B.ptr = dout; g.B.kind = 1; g.B.ld = hd; g.B.bs0 = n * hd; g.B.bs1 = d;
+    g.M = n; g.N = d; g.K = n;
+    g.C = dqkv + 2 * hd; g.ldc = ld; g.cbs0 = n * ld; g.cbs1 = d;
+    if ((rc = koaf_gemm(&g, stream)) != KOAF_OK) return rc;
+    // dP[i,j] = sum_dd dO[i,dd] V[j,dd]
+    zero_gemm(&g);
+    g.nb0 = B; g.nb1 = h; g.bm = 64; g.bn = 64;
+    g.A.ptr = dout; g.A.kind = 0; g.A.ld = hd; g.A.bs0 = n * hd; g.A.bs1 = d;
+    g.B.ptr = qkv + 2 * hd; g.B.kind = 0; g.B.ld = ld; g.B.bs0 = n * ld; g.B.bs1 = d;
+    g.M = n; g.N = n; g.K = d;
+    g.C = ws; g.ldc = n; g.cbs0 = pb0; g.cbs1 = pb1;
+    if ((rc = koaf_gemm(&g, stream)) != KOAF_OK) return rc;
+    // dS = P * (dP - rowsum(dP*P)) * scale
+    if ((rc = koaf_softmax_bwd_rows(ws, attn, (int64_t)B * h * n, n, scale, stream)) != KOAF_OK) return rc;
+    // dQ[i,dd] = sum_j dS[i,j] K[j,dd]
+    zero_gemm(&g);
+    g.nb0 = B; g.nb1 = h; g.bm = 64; g.bn = 64;
+    g.A.ptr = ws; g.A.kind = 0; g.A.ld = n; g.A.bs0 = pb0; g.A.bs1 = pb1;
+    g.B.ptr = qkv + hd; g.B.kind = 1; g.B.ld = ld; g.B.bs0 = n * ld; g.B.bs1 = d;
+    g.M = n; g.N = d; g.K = n;
+    g.C = dqkv; g.ldc = ld; g.cbs0 = n * ld; g.cbs1 = d;
+    if ((rc = koaf_gemm(&g, stream)) != KOAF_OK) return rc;
+    // dK[j,dd] = sum_i dS[i,j] Q[i,dd]
+    zero_gemm(&g);
+    g.nb0 = B; g.nb1 = h; g.bm = 64; g.bn = 64;
+    g.A.ptr = ws; g.A.kind = 1; g.A.ld = n; g.A.bs0 = pb0; g.A.bs1 = pb1;
+    g.B.ptr = qkv; g.B.kind = 1; g.B.ld = ld; g.B.bs0 = n * ld; g.B.bs1 = d;
+    g.M = n; g.N = d; g.K = n;
+    g.C = dqkv + hd; g.ldc = ld; g.cbs0 = n * ld; g.cbs1 = d;
+    return koaf_gemm(&g, stream);
+}

@@ -1,0 +1,927 @@
+// koaf_elem.hip -- HBM-bound kernels of the koafusion train step: BatchNorm statistics / backward,
+// bottleneck tail, max-pool, GAP, LayerNorm, softmax, GELU, dropout, focal loss, Adam, layout moves.
+// All are float4-vectorised along the channel (fastest) axis and sized for >= 8 blocks per CU.
+#include <stdarg.h>
+#include "koaf_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void koaf_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* koaf_last_error(void) { return g_err; }
+extern "C" int koaf_version(void) { return 100; }
+
+namespace {
+
+constexpr int EB = 256;  // elementwise block
+
+inline unsigned ew_grid(int64_t nvec) {
+    int64_t b = cdiv64(nvec, EB);
+    if (b > 256 * 32) b = 256 * 32;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column partial sums over a [rows][C] tensor.  Block (256 thr) owns a chunk of <= 1024 columns and
+// `rpb` rows; thread (cvx, ry) walks rows ry, ry+RP, ...; LDS tree over ry; writes part[blk][k][C].
+// ------------------------------------------------------------------------------------------------
+struct ColGeom {
+    int CW;      // columns per chunk
+    int nchunk;  // column chunks
+    int CV;      // column vectors per chunk (CW/4)
+    int RP;      // rows per pass (256/CV)
+    int rpb;     // rows per block
+    int nblk;    // row blocks
+};
+inline bool col_geom(int64_t rows, int C, int max_blk, ColGeom* g) {
+    if (C % 4) return false;
+    int CW = C > 1024 ? 1024 : C;
+    if (C % CW) return false;
+    int CV = CW / 4;
+    if (256 % CV) return false;
+    g->CW = CW;
+    g->nchunk = C / CW;
+    g->CV = CV;
+    g->RP = 256 / CV;
+    int64_t rpb = cdiv64(rows, max_blk);
+    rpb = cdiv64(rpb, g->RP) * g->RP;
+    if (rpb < g->RP * 4) rpb = g->RP * 4;
+    g->rpb = (int)rpb;
+    g->nblk = (int)cdiv64(rows, rpb);
+    return true;
+}
+
+template <int NS>
+__device__ __forceinline__ void col_block_reduce(v4f (&s)[NS], float* part, int blk, int C, int c0, int CV,
+                                                 int RP) {
+    __shared__ v4f red[256];
+    const int t = threadIdx.x;
+    const int cvx = t % CV, ry = t / CV;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        __syncthreads();
+        red[t] = s[k];
+        __syncthreads();
+        if (ry == 0) {
+            v4f a = red[cvx];
+            for (int j = 1; j < RP; ++j) a += red[j * CV + cvx];
+            *(v4f*)&part[((int64_t)blk * NS + k) * C + c0 + 4 * cvx] = a;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) colstats_kernel(const float* __restrict__ x, int64_t rows, int C,
+                                                       ColGeom g, float* __restrict__ part, int sq) {
+    const int t = threadIdx.x, cvx = t % g.CV, ry = t / g.CV;
+    const int c0 = blockIdx.y * g.CW;
+    const int64_t rbeg = (int64_t)blockIdx.x * g.rpb;
+    const int64_t rend = min(rows, rbeg + (int64_t)g.rpb);
+    v4f s[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int64_t r = rbeg + ry; r < rend; r += g.RP) {
+        v4f v = *(const v4f*)&x[r * C + c0 + 4 * cvx];
+        s[0] += v;
+        s[1] += v * v;
+    }
+    if (sq) col_block_reduce<2>(s, part, blockIdx.x, C, c0, g.CV, g.RP);
+    else {
+        v4f s1[1] = {s[0]};
+        col_block_reduce<1>(s1, part, blockIdx.x, C, c0, g.CV, g.RP);
+    }
+}
+
+// generic tiny-C column sum (C not a multiple of 4, e.g. the 2-class head bias)
+__global__ void colsum_small_kernel(const float* __restrict__ x, int rows, int C, float* __restrict__ out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int r = 0; r < rows; ++r) a += x[(int64_t)r * C + c];
+    out[c] = a;
+}
+
+// partial [rows][NS][C] -> out [NS][C]; block = 64 columns x 16 row groups
+template <int NS>
+__global__ void __launch_bounds__(1024) colfinal_kernel(const float* __restrict__ part, int rows, int C,
+                                                        float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ double red[NS][16][64];
+    const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double a[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) a[k] = 0.0;
+    if (c < C)
+        for (int r = gy; r < rows; r += 16)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) a[k] += (double)part[((int64_t)r * NS + k) * C + c];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) red[k][gy][cx] = a[k];
+    __syncthreads();
+    if (gy == 0 && c < C) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            double s = 0.0;
+            for (int j = 0; j < 16; ++j) s += red[k][j][cx];
+            (k == 0 ? out0 : out1)[c] = (float)s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm finalize (train: from partial column sums; eval: running stats)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(const float* __restrict__ stats, int rows, int C,
+                                                           double inv_count, double unbias,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* running_mean,
+                                                           float* running_var, int64_t* nbt, float momentum,
+                                                           float eps, int train, float* mean, float* invstd,
+                                                           float* sc, float* sh) {
+    __shared__ double red[2][16][64];
+    const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    if (train) {
+        double a = 0.0, b = 0.0;
+        if (c < C)
+            for (int r = gy; r < rows; r += 16) {
+                a += (double)stats[((int64_t)r * 2 + 0) * C + c];
+                b += (double)stats[((int64_t)r * 2 + 1) * C + c];
+            }
+        red[0][gy][cx] = a;
+        red[1][gy][cx] = b;
+        __syncthreads();
+    }
+    if (gy == 0 && c < C) {
+        float m, var;
+        if (train) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int j = 0; j < 16; ++j) { s1 += red[0][j][cx]; s2 += red[1][j][cx]; }
+            double dm = s1 * inv_count;
+            double dv = s2 * inv_count - dm * dm;
+            if (dv < 0.0) dv = 0.0;
+            m = (float)dm;
+            var = (float)dv;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(dv * unbias);
+        } else {
+            m = running_mean[c];
+            var = running_var[c];
+        }
+        float is = 1.0f / sqrtf(var + eps);
+        float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        mean[c] = m;
+        invstd[c] = is;
+        sc[c] = g * is;
+        sh[c] = b - m * g * is;
+    }
+    if (train && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+// y = relu(sc*c+sh [+ identity])
+__global__ void __launch_bounds__(256) bn_add_relu_kernel(const float* __restrict__ c, const float* __restrict__ sc,
+                                                          const float* __restrict__ sh, const float* __restrict__ idt,
+                                                          const float* __restrict__ idsc,
+                                                          const float* __restrict__ idsh, float* __restrict__ y,
+                                                          int64_t nvec, int C4) {
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * EB) {
+        const int cv = (int)(i % C4) * 4;
+        v4f v = *(const v4f*)&c[i * 4];
+        v = v * *(const v4f*)&sc[cv] + *(const v4f*)&sh[cv];
+        if (idt) {
+            v4f d = *(const v4f*)&idt[i * 4];
+            if (idsc) d = d * *(const v4f*)&idsc[cv] + *(const v4f*)&idsh[cv];
+            v += d;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        *(v4f*)&y[i * 4] = v;
+    }
+}
+
+// BN backward pass 1: masked gradient + column partials of dz and dz*xhat
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ c,
+                                                            const float* __restrict__ ymask,
+                                                            const float* __restrict__ sc, const float* __restrict__ sh,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int mask_mode,
+                                                            float* __restrict__ dz_out, int64_t rows, int C,
+                                                            ColGeom geo, float* __restrict__ part) {
+    const int t = threadIdx.x, cvx = t % geo.CV, ry = t / geo.CV;
+    const int c0 = blockIdx.y * geo.CW + 4 * cvx;
+    const int64_t rbeg = (int64_t)blockIdx.x * geo.rpb;
+    const int64_t rend = min(rows, rbeg + (int64_t)geo.rpb);
+    const v4f mu = *(const v4f*)&mean[c0], is = *(const v4f*)&invstd[c0];
+    v4f s4 = {0, 0, 0, 0}, h4 = {0, 0, 0, 0};
+    if (mask_mode == 2) { s4 = *(const v4f*)&sc[c0]; h4 = *(const v4f*)&sh[c0]; }
+    v4f s[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int64_t r = rbeg + ry; r < rend; r += geo.RP) {
+        const int64_t o = r * C + c0;
+        v4f gv = *(const v4f*)&g[o];
+        v4f cvv = *(const v4f*)&c[o];
+        if (mask_mode == 1) {
+            v4f yv = *(const v4f*)&ymask[o];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
+        } else if (mask_mode == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] = (cvv[j] * s4[j] + h4[j]) > 0.f ? gv[j] : 0.f;
+        }
+        if (dz_out) *(v4f*)&dz_out[o] = gv;
+        s[0] += gv;
+        s[1] += gv * ((cvv - mu) * is);
+    }
+    col_block_reduce<2>(s, part, blockIdx.x, C, blockIdx.y * geo.CW, geo.CV, geo.RP);
+}
+
+__global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C,
+                                                               double inv_count, const float* __restrict__ sc,
+                                                               const float* __restrict__ invstd, float* dgamma,
+                                                               float* dbeta, float* coef) {
+    __shared__ double red[2][16][64];
+    const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int r = gy; r < rows; r += 16) {
+            a += (double)part[((int64_t)r * 2 + 0) * C + c];
+            b += (double)part[((int64_t)r * 2 + 1) * C + c];
+        }
+    red[0][gy][cx] = a;
+    red[1][gy][cx] = b;
+    __syncthreads();
+    if (gy == 0 && c < C) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int j = 0; j < 16; ++j) { s1 += red[0][j][cx]; s2 += red[1][j][cx]; }
+        if (dbeta) dbeta[c] = (float)s1;
+        if (dgamma) dgamma[c] = (float)s2;
+        coef[c] = sc[c];
+        coef[C + c] = (float)(s1 * inv_count);
+        coef[2 * C + c] = (float)((double)sc[c] * (double)invstd[c] * s2 * inv_count);
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ c,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ coef, float* __restrict__ dc,
+                                                           int64_t nvec, int C) {
+    const int C4 = C / 4;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * EB) {
+        const int cv = (int)(i % C4) * 4;
+        v4f z = *(const v4f*)&dz[i * 4];
+        v4f x = *(const v4f*)&c[i * 4];
+        v4f k0 = *(const v4f*)&coef[cv], k1 = *(const v4f*)&coef[C + cv], k2 = *(const v4f*)&coef[2 * C + cv];
+        v4f mu = *(const v4f*)&mean[cv];
+        *(v4f*)&dc[i * 4] = k0 * (z - k1) - k2 * (x - mu);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// max-pool 3x3 s2 p1 over relu(sc*c+sh); GAP
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restrict__ c, const float* __restrict__ sc,
+                                                          const float* __restrict__ sh, float* __restrict__ y,
+                                                          uint8_t* __restrict__ am, int N, int H, int W, int C,
+                                                          int OH, int OW) {
+    const int C4 = C / 4;
+    const int64_t total = (int64_t)N * OH * OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int cv = (int)(i % C4) * 4;
+        int64_t p = i / C4;
+        const int ox = (int)(p % OW);
+        p /= OW;
+        const int oy = (int)(p % OH);
+        const int n = (int)(p / OH);
+        const v4f s4 = *(const v4f*)&sc[cv], h4 = *(const v4f*)&sh[cv];
+        v4f best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = oy * 2 - 1 + kh;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = ox * 2 - 1 + kw;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                v4f v = *(const v4f*)&c[((int64_t)(n * H + iy) * W + ix) * C + cv];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a = fmaxf(v[j] * s4[j] + h4[j], 0.f);
+                    if (a > best[j]) { best[j] = a; bi[j] = kh * 3 + kw; }
+                }
+            }
+        }
+        *(v4f*)&y[i * 4] = best;
+        *(uint32_t*)&am[i * 4] = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+    }
+}
+
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ am,
+                                                          float* __restrict__ da, int N, int H, int W, int C, int OH,
+                                                          int OW) {
+    const int C4 = C / 4;
+    const int64_t total = (int64_t)N * H * W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int cv = (int)(i % C4) * 4;
+        int64_t p = i / C4;
+        const int ix = (int)(p % W);
+        p /= W;
+        const int iy = (int)(p % H);
+        const int n = (int)(p / H);
+        v4f acc = {0, 0, 0, 0};
+        // output windows covering (iy, ix): oy*2-1 <= iy <= oy*2+1
+        for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {
+            if (oy >= OH) continue;
+            const int kh = iy - (oy * 2 - 1);
+            if (kh < 0 || kh > 2) continue;
+            for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox >= OW) continue;
+                const int kw = ix - (ox * 2 - 1);
+                if (kw < 0 || kw > 2) continue;
+                const int64_t o = ((int64_t)(n * OH + oy) * OW + ox) * C + cv;
+                const uint32_t a4 = *(const uint32_t*)&am[o];
+                const v4f g = *(const v4f*)&dy[o];
+                const uint32_t want = (uint32_t)(kh * 3 + kw);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (((a4 >> (8 * j)) & 0xffu) == want) acc[j] += g[j];
+            }
+        }
+        *(v4f*)&da[i * 4] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) gap_fwd_kernel(const float* __restrict__ y, float* __restrict__ out, int N,
+                                                      int HW, int C) {
+    const int C4 = C / 4;
+    const int64_t total = (int64_t)N * C4;
+    const float inv = 1.f / (float)HW;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int cv = (int)(i % C4) * 4;
+        const int64_t n = i / C4;
+        v4f a = {0, 0, 0, 0};
+        for (int p = 0; p < HW; ++p) a += *(const v4f*)&y[(n * HW + p) * C + cv];
+        *(v4f*)&out[n * C + cv] = a * inv;
+    }
+}
+__global__ void __launch_bounds__(256) gap_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dy, int N,
+                                                      int HW, int C) {
+    const int C4 = C / 4;
+    const int64_t total = (int64_t)N * HW * C4;
+    const float inv = 1.f / (float)HW;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        const int cv = (int)(i % C4) * 4;
+        const int64_t n = i / ((int64_t)C4 * HW);
+        *(v4f*)&dy[i * 4] = *(const v4f*)&dout[n * C + cv] * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout moves
+// ------------------------------------------------------------------------------------------------
+// x [B][P][S] -> out [B][S][P]   (P = R*C pixels), 32x32 LDS tiles
+__global__ void __launch_bounds__(256) slice_fold_kernel(const float* __restrict__ x, float* __restrict__ out, int P,
+                                                         int S) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, s0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 8 rows per pass
+    const float* xb = x + (int64_t)b * P * S;
+    float* ob = out + (int64_t)b * P * S;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int p = p0 + ty + 8 * j, s = s0 + tx;
+        tile[ty + 8 * j][tx] = (p < P && s < S) ? xb[(int64_t)p * S + s] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int s = s0 + ty + 8 * j, p = p0 + tx;
+        if (p < P && s < S) ob[(int64_t)s * P + p] = tile[tx][ty + 8 * j];
+    }
+}
+
+// 2x average pooling == F.interpolate(scale 0.5, align_corners=False, linear modes)
+__global__ void __launch_bounds__(256) downscale2_kernel(const float* __restrict__ x, float* __restrict__ out, int B,
+                                                         int R, int Cc, int S, int fs) {
+    const int OR = R / 2, OC = Cc / 2, OS = S / fs;
+    const int64_t total = (int64_t)B * OR * OC * OS;
+    const float inv = 1.f / (float)(4 * fs);
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        int64_t p = i;
+        const int os = (int)(p % OS); p /= OS;
+        const int oc = (int)(p % OC); p /= OC;
+        const int orr = (int)(p % OR);
+        const int b = (int)(p / OR);
+        float a = 0.f;
+        for (int dr = 0; dr < 2; ++dr)
+            for (int dc = 0; dc < 2; ++dc)
+                for (int ds = 0; ds < fs; ++ds)
+                    a += x[(((int64_t)b * R + 2 * orr + dr) * Cc + 2 * oc + dc) * S + os * fs + ds];
+        out[i] = a * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * D;
+    const int D4 = D / 4;
+    float s = 0.f;
+    for (int i = lane; i < D4; i += 64) { v4f v = *(const v4f*)&xr[i * 4]; s += v[0] + v[1] + v[2] + v[3]; }
+    const float m = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int i = lane; i < D4; i += 64) {
+        v4f v = *(const v4f*)&xr[i * 4] - m;
+        q += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    for (int i = lane; i < D4; i += 64) {
+        v4f v = (*(const v4f*)&xr[i * 4] - m) * rs;
+        v = v * *(const v4f*)&gamma[i * 4] + *(const v4f*)&beta[i * 4];
+        *(v4f*)&y[(int64_t)row * D + i * 4] = v;
+    }
+    if (lane == 0) { mean[row] = m; rstd[row] = rs; }
+}
+
+// dx per row (one wave per row) ...
+__global__ void __launch_bounds__(256) layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* __restrict__ dx,
+                                                               int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * D;
+    const float* gr = dy + (int64_t)row * D;
+    const int D4 = D / 4;
+    const float m = mean[row], rs = rstd[row];
+    float a = 0.f, b = 0.f;
+    for (int i = lane; i < D4; i += 64) {
+        v4f g = *(const v4f*)&gr[i * 4] * *(const v4f*)&gamma[i * 4];
+        v4f xh = (*(const v4f*)&xr[i * 4] - m) * rs;
+        a += g[0] + g[1] + g[2] + g[3];
+        b += g[0] * xh[0] + g[1] * xh[1] + g[2] * xh[2] + g[3] * xh[3];
+    }
+    a = wave_sum(a) / (float)D;
+    b = wave_sum(b) / (float)D;
+    for (int i = lane; i < D4; i += 64) {
+        v4f g = *(const v4f*)&gr[i * 4] * *(const v4f*)&gamma[i * 4];
+        v4f xh = (*(const v4f*)&xr[i * 4] - m) * rs;
+        *(v4f*)&dx[(int64_t)row * D + i * 4] = (g - a - xh * b) * rs;
+    }
+}
+// ... and the parameter gradients as column partials: part[blk][0] = sum dy*xhat, [1] = sum dy
+__global__ void __launch_bounds__(256) layernorm_bwd_param_kernel(const float* __restrict__ dy,
+                                                                  const float* __restrict__ x,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, int64_t rows, int D,
+                                                                  ColGeom geo, float* __restrict__ part) {
+    const int t = threadIdx.x, cvx = t % geo.CV, ry = t / geo.CV;
+    const int c0 = blockIdx.y * geo.CW + 4 * cvx;
+    const int64_t rbeg = (int64_t)blockIdx.x * geo.rpb;
+    const int64_t rend = min(rows, rbeg + (int64_t)geo.rpb);
+    v4f s[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int64_t r = rbeg + ry; r < rend; r += geo.RP) {
+        v4f g = *(const v4f*)&dy[r * D + c0];
+        v4f xh = (*(const v4f*)&x[r * D + c0] - mean[r]) * rstd[r];
+        s[0] += g * xh;
+        s[1] += g;
+    }
+    col_block_reduce<2>(s, part, blockIdx.x, D, blockIdx.y * geo.CW, geo.CV, geo.RP);
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax rows (attention), in place; one wave per row
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x, int64_t rows, int n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* xr = x + row * n;
+    float m = -INFINITY;
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, xr[i]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += expf(xr[i] - m);
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+    for (int i = lane; i < n; i += 64) xr[i] = expf(xr[i] - m) * inv;
+}
+// ds = p * (dp - sum(dp*p)) * scale, in place on dp
+__global__ void __launch_bounds__(256) softmax_bwd_rows_kernel(float* __restrict__ dp, const float* __restrict__ p,
+                                                               int64_t rows, int n, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* dr = dp + row * n;
+    const float* pr = p + row * n;
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += dr[i] * pr[i];
+    s = wave_sum(s);
+    for (int i = lane; i < n; i += 64) dr[i] = pr[i] * (dr[i] - s) * scale;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pointwise
+// ------------------------------------------------------------------------------------------------
+enum { PW_GELU_F, PW_GELU_B, PW_RELU_F, PW_RELU_B, PW_ADD };
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_d(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+template <int OP>
+__global__ void __launch_bounds__(256) pointwise_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ out, int64_t n) {
+    const int64_t nvec = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * EB) {
+        v4f x = *(const v4f*)&a[i * 4], y = {0, 0, 0, 0}, o;
+        if (OP == PW_GELU_B || OP == PW_RELU_B || OP == PW_ADD) y = *(const v4f*)&b[i * 4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (OP == PW_GELU_F) o[j] = gelu_f(x[j]);
+            else if (OP == PW_GELU_B) o[j] = x[j] * gelu_d(y[j]);       // a = dy, b = x
+            else if (OP == PW_RELU_F) o[j] = fmaxf(x[j], 0.f);
+            else if (OP == PW_RELU_B) o[j] = y[j] > 0.f ? x[j] : 0.f;   // a = dy, b = y
+            else o[j] = x[j] + y[j];
+        }
+        *(v4f*)&out[i * 4] = o;
+    }
+    // tail
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = nvec * 4 + threadIdx.x;
+        float x = a[i], y = (OP == PW_GELU_B || OP == PW_RELU_B || OP == PW_ADD) ? b[i] : 0.f, o;
+        if (OP == PW_GELU_F) o = gelu_f(x);
+        else if (OP == PW_GELU_B) o = x * gelu_d(y);
+        else if (OP == PW_RELU_F) o = fmaxf(x, 0.f);
+        else if (OP == PW_RELU_B) o = y > 0.f ? x : 0.f;
+        else o = x + y;
+        out[i] = o;
+    }
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                      float p, float inv_keep, uint64_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) {
+        const uint64_t h = mix64(seed ^ mix64((uint64_t)i));
+        const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+        y[i] = (u >= p) ? x[i] * inv_keep : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ p, float v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// losses (tiny: one block)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) focal_loss_kernel(const float* __restrict__ logits,
+                                                         const int64_t* __restrict__ target, float* loss,
+                                                         float* __restrict__ dlogits, int B, int C, float gamma,
+                                                         int mean, int focal) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    const float wgt = mean ? 1.f / (float)B : 1.f;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const float* x = logits + (int64_t)i * C;
+        float m = -INFINITY;
+        for (int j = 0; j < C; ++j) m = fmaxf(m, x[j]);
+        float s = 0.f;
+        for (int j = 0; j < C; ++j) s += expf(x[j] - m);
+        const float lse = m + logf(s);
+        const int tg = (int)target[i];
+        const float logpt = x[tg] - lse;
+        const float pt = expf(logpt);
+        float li, dl;  // loss_i, d loss_i / d logpt
+        if (focal) {
+            const float om = 1.f - pt;
+            const float pw = powf(om, gamma);
+            li = -pw * logpt;
+            const float pw1 = (gamma == 0.f) ? 0.f : gamma * powf(om, gamma - 1.f);
+            dl = -pw + pw1 * pt * logpt;
+        } else {
+            li = -logpt;
+            dl = -1.f;
+        }
+        acc += li;
+        for (int j = 0; j < C; ++j) {
+            const float pj = expf(x[j] - lse);
+            dlogits[(int64_t)i * C + j] = dl * ((j == tg ? 1.f : 0.f) - pj) * wgt;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = red[0] * wgt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam single-tensor update rule, coupled L2; adamw: decoupled)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float wd, float step_size,
+                                                   float bc2_sqrt, int adamw) {
+    const int64_t nvec = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * EB) {
+        v4f pv = *(const v4f*)&p[i * 4], gv = *(const v4f*)&g[i * 4];
+        v4f mv = *(const v4f*)&m[i * 4], vv = *(const v4f*)&v[i * 4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gj = gv[j], pj = pv[j];
+            if (adamw) pj *= (1.f - lr * wd);
+            else gj += wd * pj;
+            const float mj = mv[j] + (gj - mv[j]) * (1.f - b1);
+            const float vj = vv[j] * b2 + (1.f - b2) * gj * gj;
+            const float denom = sqrtf(vj) / bc2_sqrt + eps;
+            pv[j] = pj - step_size * (mj / denom);
+            mv[j] = mj;
+            vv[j] = vj;
+        }
+        *(v4f*)&p[i * 4] = pv;
+        *(v4f*)&m[i * 4] = mv;
+        *(v4f*)&v[i * 4] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = nvec * 4 + threadIdx.x;
+        float gj = g[i], pj = p[i];
+        if (adamw) pj *= (1.f - lr * wd);
+        else gj += wd * pj;
+        const float mj = m[i] + (gj - m[i]) * (1.f - b1);
+        const float vj = v[i] * b2 + (1.f - b2) * gj * gj;
+        p[i] = pj - step_size * (mj / (sqrtf(vj) / bc2_sqrt + eps));
+        m[i] = mj;
+        v[i] = vj;
+    }
+}
+
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+#define STREAM ((hipStream_t)stream)
+
+extern "C" int koaf_bn_finalize(const float* stats, int32_t rows, int32_t C, int64_t count, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var,
+                                int64_t* num_batches_tracked, float momentum, float eps, int32_t train, float* mean,
+                                float* invstd, float* sc, float* sh, void* stream) {
+    KOAF_REQUIRE(C > 0 && mean && invstd && sc && sh && running_mean && running_var, "koaf_bn_finalize: bad args");
+    KOAF_REQUIRE(!train || (stats && rows > 0 && count > 0), "koaf_bn_finalize: train mode needs stats");
+    const double inv = train ? 1.0 / (double)count : 0.0;
+    const double unbias = (train && count > 1) ? (double)count / (double)(count - 1) : 1.0;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, STREAM, stats, rows, C, inv, unbias,
+                       gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, train, mean,
+                       invstd, sc, sh);
+    return koaf_check_launch("koaf_bn_finalize");
+}
+
+extern "C" int koaf_bn_add_relu(const float* c, const float* sc, const float* sh, const float* idt, const float* idsc,
+                                const float* idsh, float* y, int64_t rows, int32_t C, void* stream) {
+    KOAF_REQUIRE(c && sc && sh && y && rows > 0 && C > 0 && C % 4 == 0, "koaf_bn_add_relu: bad args");
+    KOAF_REQUIRE(al16(c) && al16(y) && al16(sc) && al16(sh) && (!idt || al16(idt)), "koaf_bn_add_relu: unaligned");
+    KOAF_REQUIRE((idsc == nullptr) == (idsh == nullptr), "koaf_bn_add_relu: idsc/idsh come together");
+    const int64_t nvec = rows * (C / 4);
+    hipLaunchKernelGGL(bn_add_relu_kernel, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, c, sc, sh, idt, idsc, idsh, y,
+                       nvec, C / 4);
+    return koaf_check_launch("koaf_bn_add_relu");
+}
+extern "C" int koaf_bn_relu(const float* c, const float* sc, const float* sh, float* y, int64_t rows, int32_t C,
+                            void* stream) {
+    return koaf_bn_add_relu(c, sc, sh, nullptr, nullptr, nullptr, y, rows, C, stream);
+}
+
+extern "C" int koaf_colstats(const float* x, int64_t rows, int32_t C, float* part, int32_t* part_rows, void* stream) {
+    ColGeom g;
+    KOAF_REQUIRE(x && part && part_rows && rows > 0, "koaf_colstats: bad args");
+    KOAF_REQUIRE(col_geom(rows, C, 1024, &g), "koaf_colstats: unsupported C=%d", C);
+    hipLaunchKernelGGL(colstats_kernel, dim3(g.nblk, g.nchunk), dim3(256), 0, STREAM, x, rows, C, g, part, 1);
+    *part_rows = g.nblk;
+    return koaf_check_launch("koaf_colstats");
+}
+extern "C" int32_t koaf_colpart_rows(int64_t rows, int32_t C) {
+    ColGeom g;
+    if (!col_geom(rows, C, 1024, &g)) return -1;
+    return g.nblk;
+}
+
+extern "C" int koaf_bn_bwd_reduce(const float* g, const float* c, const float* ymask, const float* sc, const float* sh,
+                                  const float* mean, const float* invstd, int32_t mask_mode, float* dz_out, float* part,
+                                  int32_t* part_rows, int64_t rows, int32_t C, void* stream) {
+    ColGeom geo;
+    KOAF_REQUIRE(g && c && mean && invstd && part && part_rows && rows > 0, "koaf_bn_bwd_reduce: bad args");
+    KOAF_REQUIRE(mask_mode != 1 || ymask, "koaf_bn_bwd_reduce: mask_mode 1 needs ymask");
+    KOAF_REQUIRE(mask_mode != 2 || (sc && sh), "koaf_bn_bwd_reduce: mask_mode 2 needs sc/sh");
+    KOAF_REQUIRE(col_geom(rows, C, 1024, &geo), "koaf_bn_bwd_reduce: unsupported C=%d", C);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(geo.nblk, geo.nchunk), dim3(256), 0, STREAM, g, c, ymask, sc, sh,
+                       mean, invstd, mask_mode, dz_out, rows, C, geo, part);
+    *part_rows = geo.nblk;
+    return koaf_check_launch("koaf_bn_bwd_reduce");
+}
+extern "C" int koaf_bn_bwd_finalize(const float* part, int32_t part_rows, int32_t C, int64_t count, const float* sc,
+                                    const float* invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
+    KOAF_REQUIRE(part && part_rows > 0 && C > 0 && count > 0 && sc && invstd && coef, "koaf_bn_bwd_finalize: bad args");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, STREAM, part, part_rows, C,
+                       1.0 / (double)count, sc, invstd, dgamma, dbeta, coef);
+    return koaf_check_launch("koaf_bn_bwd_finalize");
+}
+extern "C" int koaf_bn_bwd_apply(const float* dz, const float* c, const float* mean, const float* coef, float* dc,
+                                 int64_t rows, int32_t C, void* stream) {
+    KOAF_REQUIRE(dz && c && mean && coef && dc && rows > 0 && C % 4 == 0, "koaf_bn_bwd_apply: bad args");
+    const int64_t nvec = rows * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, dz, c, mean, coef, dc, nvec, C);
+    return koaf_check_launch("koaf_bn_bwd_apply");
+}
+
+extern "C" int koaf_maxpool_fwd(const float* c, const float* sc, const float* sh, float* y, uint8_t* argmax, int32_t N,
+                                int32_t H, int32_t W, int32_t C, void* stream) {
+    KOAF_REQUIRE(c && sc && sh && y && argmax && N > 0 && H > 0 && W > 0 && C % 4 == 0, "koaf_maxpool_fwd: bad args");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const int64_t nvec = (int64_t)N * OH * OW * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, c, sc, sh, y, argmax, N, H, W, C,
+                       OH, OW);
+    return koaf_check_launch("koaf_maxpool_fwd");
+}
+extern "C" int koaf_maxpool_bwd(const float* dy, const uint8_t* argmax, float* da, int32_t N, int32_t H, int32_t W,
+                                int32_t C, void* stream) {
+    KOAF_REQUIRE(dy && argmax && da && N > 0 && C % 4 == 0, "koaf_maxpool_bwd: bad args");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const int64_t nvec = (int64_t)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, dy, argmax, da, N, H, W, C, OH,
+                       OW);
+    return koaf_check_launch("koaf_maxpool_bwd");
+}
+extern "C" int koaf_gap_fwd(const float* y, float* out, int32_t N, int32_t HW, int32_t C, void* stream) {
+    KOAF_REQUIRE(y && out && N > 0 && HW > 0 && C % 4 == 0, "koaf_gap_fwd: bad args");
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(ew_grid((int64_t)N * C / 4)), dim3(EB), 0, STREAM, y, out, N, HW, C);
+    return koaf_check_launch("koaf_gap_fwd");
+}
+extern "C" int koaf_gap_bwd(const float* dout, float* dy, int32_t N, int32_t HW, int32_t C, void* stream) {
+    KOAF_REQUIRE(dout && dy && N > 0 && HW > 0 && C % 4 == 0, "koaf_gap_bwd: bad args");
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(ew_grid((int64_t)N * HW * C / 4)), dim3(EB), 0, STREAM, dout, dy, N, HW,
+                       C);
+    return koaf_check_launch("koaf_gap_bwd");
+}
+
+extern "C" int koaf_slice_fold(const float* x, float* out, int32_t B, int32_t R, int32_t Cc, int32_t S, void* stream) {
+    KOAF_REQUIRE(x && out && B > 0 && R > 0 && Cc > 0 && S > 0 && B <= 65535, "koaf_slice_fold: bad args");
+    const int P = R * Cc;
+    dim3 grid((P + 31) / 32, (S + 31) / 32, B);
+    hipLaunchKernelGGL(slice_fold_kernel, grid, dim3(256), 0, STREAM, x, out, P, S);
+    return koaf_check_launch("koaf_slice_fold");
+}
+extern "C" int koaf_downscale2(const float* x, float* out, int32_t B, int32_t R, int32_t Cc, int32_t S, int32_t fs,
+                               void* stream) {
+    KOAF_REQUIRE(x && out && B > 0 && R % 2 == 0 && Cc % 2 == 0 && (fs == 1 || fs == 2) && S % fs == 0,
+                 "koaf_downscale2: needs even R,C (and S if fs==2)");
+    const int64_t total = (int64_t)B * (R / 2) * (Cc / 2) * (S / fs);
+    hipLaunchKernelGGL(downscale2_kernel, dim3(ew_grid(total)), dim3(EB), 0, STREAM, x, out, B, R, Cc, S, fs);
+    return koaf_check_launch("koaf_downscale2");
+}
+
+extern "C" int koaf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                  float* rstd, int32_t rows, int32_t D, float eps, void* stream) {
+    KOAF_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0 && D % 4 == 0, "koaf_layernorm_fwd: bad args");
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, STREAM, x, gamma, beta, y, mean, rstd,
+                       rows, D, eps);
+    return koaf_check_launch("koaf_layernorm_fwd");
+}
+extern "C" int64_t koaf_layernorm_bwd_ws(int32_t rows, int32_t D) {
+    ColGeom g;
+    if (!col_geom(rows, D, 256, &g)) return -1;
+    return (int64_t)g.nblk * 2 * D;
+}
+extern "C" int koaf_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                  const float* rstd, float* dx, float* dgamma, float* dbeta, float* part, int32_t rows,
+                                  int32_t D, void* stream) {
+    ColGeom g;
+    KOAF_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && part && rows > 0,
+                 "koaf_layernorm_bwd: bad args");
+    KOAF_REQUIRE(col_geom(rows, D, 256, &g), "koaf_layernorm_bwd: unsupported D=%d", D);
+    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((rows + 3) / 4), dim3(256), 0, STREAM, dy, x, gamma, mean, rstd,
+                       dx, rows, D);
+    hipLaunchKernelGGL(layernorm_bwd_param_kernel, dim3(g.nblk, g.nchunk), dim3(256), 0, STREAM, dy, x, mean, rstd,
+                       (int64_t)rows, D, g, part);
+    hipLaunchKernelGGL(colfinal_kernel<2>, dim3((D + 63) / 64), dim3(1024), 0, STREAM, part, g.nblk, D, dgamma, dbeta);
+    return koaf_check_launch("koaf_layernorm_bwd");
+}
+
+extern "C" int koaf_softmax_rows(float* x, int64_t rows, int32_t n, void* stream) {
+    KOAF_REQUIRE(x && rows > 0 && n > 0, "koaf_softmax_rows: bad args");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, STREAM, x, rows, n);
+    return koaf_check_launch("koaf_softmax_rows");
+}
+extern "C" int koaf_softmax_bwd_rows(float* dp, const float* p, int64_t rows, int32_t n, float scale, void* stream) {
+    KOAF_REQUIRE(dp && p && rows > 0 && n > 0, "koaf_softmax_bwd_rows: bad args");
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, STREAM, dp, p, rows, n,
+                       scale);
+    return koaf_check_launch("koaf_softmax_bwd_rows");
+}
+
+#define PW_LAUNCH(OP, a, b, out, n, name)                                                                      \
+    KOAF_REQUIRE((a) && (out) && (n) > 0, name ": bad args");                                                  \
+    KOAF_REQUIRE(al16(a) && al16(out) && (!(b) || al16(b)), name ": unaligned");                               \
+    hipLaunchKernelGGL(pointwise_kernel<OP>, dim3(ew_grid(((n) + 3) / 4)), dim3(EB), 0, STREAM, a, b, out, n); \
+    return koaf_check_launch(name)
+
+extern "C" int koaf_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
+    PW_LAUNCH(PW_GELU_F, x, (const float*)nullptr, y, n, "koaf_gelu_fwd");
+}
+extern "C" int koaf_gelu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream) {
+    KOAF_REQUIRE(x, "koaf_gelu_bwd: bad args");
+    PW_LAUNCH(PW_GELU_B, dy, x, dx, n, "koaf_gelu_bwd");
+}
+extern "C" int koaf_relu_fwd(const float* x, float* y, int64_t n, void* stream) {
+    PW_LAUNCH(PW_RELU_F, x, (const float*)nullptr, y, n, "koaf_relu_fwd");
+}
+extern "C" int koaf_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+    KOAF_REQUIRE(y, "koaf_relu_bwd: bad args");
+    PW_LAUNCH(PW_RELU_B, dy, y, dx, n, "koaf_relu_bwd");
+}
+extern "C" int koaf_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    KOAF_REQUIRE(b, "koaf_add: bad args");
+    PW_LAUNCH(PW_ADD, a, b, out, n, "koaf_add");
+}
+extern "C" int koaf_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+    KOAF_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "koaf_dropout: bad args");
+    hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(EB), 0, STREAM, x, y, n, p, 1.f / (1.f - p), seed);
+    return koaf_check_launch("koaf_dropout");
+}
+extern "C" int koaf_fill(float* p, float value, int64_t n, void* stream) {
+    KOAF_REQUIRE(p && n > 0, "koaf_fill: bad args");
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(EB), 0, STREAM, p, value, n);
+    return koaf_check_launch("koaf_fill");
+}
+
+extern "C" int koaf_colsum(const float* x, float* out, int32_t rows, int32_t C, float* part, void* stream) {
+    KOAF_REQUIRE(x && out && rows > 0 && C > 0, "koaf_colsum: bad args");
+    ColGeom g;
+    if (part && al16(x) && col_geom(rows, C, 256, &g)) {
+        hipLaunchKernelGGL(colstats_kernel, dim3(g.nblk, g.nchunk), dim3(256), 0, STREAM, x, (int64_t)rows, C, g, part,
+                           0);
+        hipLaunchKernelGGL(colfinal_kernel<1>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, part, g.nblk, C, out,
+                           (float*)nullptr);
+    } else {
+        hipLaunchKernelGGL(colsum_small_kernel, dim3((C + 255) / 256), dim3(256), 0, STREAM, x, rows, C, out);
+    }
+    return koaf_check_launch("koaf_colsum");
+}
+extern "C" int64_t koaf_colsum_ws(int32_t rows, int32_t C) {
+    ColGeom g;
+    if (!col_geom(rows, C, 256, &g)) return 0;
+    return (int64_t)g.nblk * C;
+}
+
+extern "C" int koaf_focal_loss(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t B,
+                               int32_t C, float gamma, int32_t reduction_mean, void* stream) {
+    KOAF_REQUIRE(logits && target && loss && dlogits && B > 0 && C > 0, "koaf_focal_loss: bad args");
+    hipLaunchKernelGGL(focal_loss_kernel, dim3(1), dim3(256), 0, STREAM, logits, target, loss, dlogits, B, C, gamma,
+                       reduction_mean, 1);
+    return koaf_check_launch("koaf_focal_loss");
+}
+extern "C" int koaf_ce_loss(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t B,
+                            int32_t C, void* stream) {
+    KOAF_REQUIRE(logits && target && loss && dlogits && B > 0 && C > 0, "koaf_ce_loss: bad args");
+    hipLaunchKernelGGL(focal_loss_kernel, dim3(1), dim3(256), 0, STREAM, logits, target, loss, dlogits, B, C, 0.f, 1,
+                       0);
+    return koaf_check_launch("koaf_ce_loss");
+}
+
+extern "C" int koaf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int32_t step, int32_t adamw, void* stream) {
+    KOAF_REQUIRE(p && g && m && v && n > 0 && step >= 1, "koaf_adam_step: bad args");
+    KOAF_REQUIRE(al16(p) && al16(g) && al16(m) && al16(v), "koaf_adam_step: unaligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EB), 0, STREAM, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, step_size, bc2_sqrt, adamw);
+    return koaf_check_launch("koaf_adam_step");
+}

@@ -1,0 +1,90 @@
+"""Pieces shared by the six registry models."""
+import torch
+from torch import nn
+
+from .. import functional as KF
+from .. import ops
+from ..arena import get_arena
+from ._core_fes import dict_fes
+from ._encoder import KoafTrunk
+
+
+def build_trunk(arch, pretrained, with_gap):
+    """`nn.Sequential(*list(fe.children())[:-1 or :-2])` of the reference (e.g. _xrNmrMcP.py:40-59)."""
+    fe = dict_fes[arch](pretrained=pretrained)
+    ch = list(fe.children())
+    ch = ch[:-1] if with_gap else ch[:-2]
+    return KoafTrunk(*ch)
+
+
+class KoafDropout2d(nn.Module):
+    """nn.Dropout2d on the (N,C,1,1) GAP'd encoder output (_xrNmrMcP.py:62-72) == per-(image,channel)
+    dropout; on the libkoaf counter-based generator."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = float(p)
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        if x.shape[2] != 1 or x.shape[3] != 1:
+            raise NotImplementedError("Dropout2d on a spatial (with_gap=false) encoder output is not built")
+        return KF.dropout(x, self.p, True)
+
+    def extra_repr(self):
+        return f"p={self.p}"
+
+
+def make_drop(p):
+    return KoafDropout2d(p) if p else nn.Identity()
+
+
+def fold_slices(x, dims_view="rc"):
+    """(B,1,R,C,S) -> single-channel image batch for the 2-D trunk (the 1->3 repeat is folded into conv1).
+    rc: "b ch r c s -> (b s) ch r c" (_xrNmrMcP.py:209); cs / rs: _mrN_cnn_trf.py:112-117."""
+    B, ch, R, C, S = x.shape
+    if ch != 1:
+        raise ValueError("koafusion volumes are single-channel")
+    x = x.contiguous()
+    if dims_view == "rc":
+        return ops.slice_fold(x, B, R, C, S).view(B * S, 1, R, C)
+    if dims_view == "cs":
+        return x.view(B * R, 1, C, S)
+    if dims_view == "rs":
+        return x.view(B, R, C, S).permute(0, 2, 1, 3).contiguous().view(B * C, 1, R, S)
+    raise ValueError("Unsupported `model.fe.dims_view`")
+
+
+def tokens(feat, B):
+    """"(b s) ch d0 d1 -> b (s d0 d1) ch" on the trunk output (an NHWC buffer viewed as NCHW)."""
+    N, C, h, w = feat.shape
+    t = feat.permute(0, 2, 3, 1)            # (N,h,w,C): the memory order
+    return t.reshape(B, (N // B) * h * w, C)
+
+
+def adopt(model, *inputs):
+    for t in inputs:
+        if not t.is_cuda:
+            raise RuntimeError("koaf models run on a HIP device only (no CPU fallback); move model and inputs to cuda")
+    return get_arena(model)
+
+
+def finish(config, res_out):
+    from collections import OrderedDict
+    endpoints = OrderedDict()
+    endpoints["main"] = res_out
+    if config.output_type == "main":
+        return endpoints["main"]
+    elif config.output_type == "dict":
+        return endpoints
+    raise ValueError(f"Unknown output_type: {config.output_type}")
+
+
+def maybe_restore(model, config, path_weights):
+    if config["restore_weights"]:
+        model.load_state_dict(torch.load(path_weights, map_location="cpu"))
+
+
+MAPPING_CH = {"resnet18": 512, "resnet34": 512, "resnet50": 2048, "resnext50_32x4d": 2048}
+MAPPING_SPAT = {320: 10, 160: 5, 128: 4, 96: 3, 64: 2, 32: 1, 350: 11, 25: 1}

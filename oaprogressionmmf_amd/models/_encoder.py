@@ -1,0 +1,245 @@
+"""The slice-wise 2-D CNN encoder as ONE fused HIP schedule (forward and backward).
+
+Reference: the `nn.Sequential(*list(resnet.children())[:-1])` trunks of
+koafusion/models/_xrNmrMcP.py:47-59 / _xr1_cnn.py:17-21 executing koafusion/models/_torchvision.py
+(stem :170-174, Bottleneck.forward :118-138, BasicBlock.forward :62-80, avgpool :182).
+
+MI355X-first layout of the computation (all activations NHWC fp32, rows = (image, pixel)):
+  * every conv is an implicit GEMM on the fp32 MFMA kernel (koaf_gemm.hip); its epilogue emits the
+    per-channel partial sums the following train-mode BatchNorm needs;
+  * BatchNorm+ReLU are never materialised: the consumer conv applies relu(sc*x+sh) while it loads its
+    operand (forward A operand, wgrad B operand), so each conv output is written once and only the raw
+    conv outputs are kept for backward;
+  * the bottleneck tail relu(bn3(c3) + identity) is one elementwise kernel; backward runs the
+    BatchNorm reductions / applies as HBM-bound kernels between the dgrad / wgrad GEMMs, and the
+    identity gradient is added in the conv1-dgrad epilogue;
+  * the 3 identical input channels of `repeat(..., k=3)` are folded into the stem weights;
+  * ResNeXt's grouped 3x3 runs on the same GEMM as 64-channel block-diagonal slabs.
+Parameter gradients are written straight into the flat gradient arena.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from ..arena import deliver_grad, grad_target, packed_weight
+from ._core_fes import BasicBlock, Bottleneck
+
+
+class _Rec:
+    __slots__ = ("kind", "blk", "yin", "c1", "s1", "c2", "s2", "c3", "s3", "cd", "sd", "y", "dims", "wexp")
+
+    def __init__(self):
+        for k in self.__slots__:
+            setattr(self, k, None)
+
+
+def _conv_fwd(x, conv, N, H, W, in_saved, train):
+    w = packed_weight(conv.weight)
+    cin, cout = conv.in_channels, conv.out_channels
+    k, s, p, g = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.groups
+    sc, sh = (in_saved[2], in_saved[3]) if in_saved is not None else (None, None)
+    wexp = None
+    if g == 1:
+        y, part = ops.conv2d_fwd(x, w, N, H, W, cin, cout, k, k, s, p, sc, sh, stats=train)
+    else:
+        if k != 3 or p != 1 or cin != cout:
+            raise NotImplementedError("grouped convolution other than the ResNeXt 3x3 is not built")
+        wexp = ops.gconv_expand_w(w, cin, g)
+        y, part = ops.gconv3x3_fwd(x, wexp, N, H, W, cin, s, sc, sh, stats=train)
+    return y, part, ops.conv_out(H, k, s, p), ops.conv_out(W, k, s, p), wexp
+
+
+def _bn_fin(bn, part, count):
+    train = bn.training or bn.running_mean is None
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not built")
+    return ops.bn_finalize(part if train else None, bn.num_features, count, bn.weight.detach(), bn.bias.detach(),
+                           bn.running_mean, bn.running_var, bn.num_batches_tracked if train else None, bn.momentum,
+                           bn.eps, train)
+
+
+def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True):
+    """weight gradient (x transformed on load by in_saved) and data gradient of one conv."""
+    w = packed_weight(conv.weight)
+    cin, cout = conv.in_channels, conv.out_channels
+    k, s, p, g = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.groups
+    sc, sh = (in_saved[2], in_saved[3]) if in_saved is not None else (None, None)
+    gw, acc = grad_target(conv.weight)
+    if g == 1:
+        ops.conv2d_wgrad(dc, x, gw, N, H, W, cin, cout, k, k, s, p, sc, sh)
+    else:
+        dwexp = ops.gconv3x3_wgrad(dc, x, N, H, W, cin, s, sc, sh)
+        ops.gconv_compress_dw(dwexp, gw, cin, g)
+    deliver_grad(conv.weight, gw, acc)
+    if not need_dx:
+        return None
+    if g == 1:
+        return ops.conv2d_dgrad(dc, w, N, H, W, cin, cout, k, k, s, p, residual=residual)
+    assert residual is None
+    return ops.gconv3x3_dgrad(dc, wexp, N, H, W, cin, s)
+
+
+def _bn_bwd(bn, g, c, saved, rows, mask_mode, ymask=None, dz_out=None, dc_out=None):
+    C = bn.num_features
+    gg, ag = grad_target(bn.weight)
+    gb, ab = grad_target(bn.bias)
+    dc = ops.bn_bwd(g, c, saved, rows, C, rows, gg, gb, mask_mode, ymask=ymask, dz_out=dz_out, dc_out=dc_out)
+    deliver_grad(bn.weight, gg, ag)
+    deliver_grad(bn.bias, gb, ab)
+    return dc
+
+
+class EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, trunk, anchor):
+        st = trunk._koaf_layout()
+        keep = torch.is_grad_enabled() and anchor.requires_grad
+        if x.dim() == 4:
+            if x.shape[1] != 1:
+                raise ValueError("KoafTrunk takes the single-channel image (the 1->3 repeat is folded into conv1)")
+            N, _, H, W = x.shape
+        else:
+            N, H, W = x.shape
+        x = x.contiguous()
+        conv1, bn1 = st["conv1"], st["bn1"]
+        train = bn1.training
+        w1t = ops.stem_fold_w(packed_weight(conv1.weight))
+        c0 = ops.stem_fwd(x, w1t, N, H, W)
+        H1, W1 = c0.shape[1], c0.shape[2]
+        part = ops.colstats(c0, N * H1 * W1, 64) if train else None
+        s0 = _bn_fin(bn1, part, N * H1 * W1)
+        y, am = ops.maxpool_fwd(c0, s0, N, H1, W1, 64)
+        Hc, Wc = y.shape[1], y.shape[2]
+        recs = []
+        for blk in st["blocks"]:
+            r = _Rec()
+            r.blk, r.yin = blk, y
+            if isinstance(blk, Bottleneck):
+                r.kind = "bottleneck"
+                r.c1, part, _, _, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, train)
+                r.s1 = _bn_fin(blk.bn1, part, N * Hc * Wc)
+                r.c2, part, OH, OW, r.wexp = _conv_fwd(r.c1, blk.conv2, N, Hc, Wc, r.s1, train)
+                r.s2 = _bn_fin(blk.bn2, part, N * OH * OW)
+                r.c3, part, _, _, _ = _conv_fwd(r.c2, blk.conv3, N, OH, OW, r.s2, train)
+                r.s3 = _bn_fin(blk.bn3, part, N * OH * OW)
+                last_c, last_s, cout = r.c3, r.s3, blk.conv3.out_channels
+            elif isinstance(blk, BasicBlock):
+                r.kind = "basic"
+                r.c1, part, OH, OW, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, train)
+                r.s1 = _bn_fin(blk.bn1, part, N * OH * OW)
+                r.c2, part, _, _, _ = _conv_fwd(r.c1, blk.conv2, N, OH, OW, r.s1, train)
+                r.s2 = _bn_fin(blk.bn2, part, N * OH * OW)
+                last_c, last_s, cout = r.c2, r.s2, blk.conv2.out_channels
+            else:
+                raise TypeError(f"unsupported block {type(blk)}")
+            rows_o = N * OH * OW
+            if blk.downsample is not None:
+                r.cd, part, _, _, _ = _conv_fwd(y, blk.downsample[0], N, Hc, Wc, None, train)
+                r.sd = _bn_fin(blk.downsample[1], part, rows_o)
+                ynew = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=r.cd, idsaved=r.sd)
+            else:
+                ynew = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=y)
+            r.y = ynew
+            r.dims = (N, Hc, Wc, OH, OW)
+            y, Hc, Wc = ynew, OH, OW
+            if keep:
+                recs.append(r)
+        C = y.shape[-1]
+        if st["gap"]:
+            out = ops.gap_fwd(y, N, Hc * Wc, C).view(N, C, 1, 1)
+        else:
+            out = y.permute(0, 3, 1, 2)  # (N,C,h,w) view of the NHWC buffer
+        if keep:
+            ctx.state = dict(x=x, c0=c0, s0=s0, am=am, recs=recs, dims=(N, H, W, H1, W1), last=(Hc, Wc, C),
+                             st=st)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        S = ctx.state
+        ctx.state = None
+        st = S["st"]
+        N, H, W, H1, W1 = S["dims"]
+        Hc, Wc, C = S["last"]
+        if st["gap"]:
+            dy = ops.gap_bwd(gout.reshape(N, C).contiguous(), N, Hc * Wc, C).view(N, Hc, Wc, C)
+        else:
+            dy = gout.permute(0, 2, 3, 1).contiguous()
+            if dy.data_ptr() == gout.data_ptr():
+                dy = dy.clone()  # masked in place below
+        recs = S["recs"]
+        while recs:
+            r = recs.pop()
+            blk = r.blk
+            N, Hi, Wi, OH, OW = r.dims
+            rows_o, rows_i = N * OH * OW, N * Hi * Wi
+            if r.kind == "bottleneck":
+                # tail: dz = dy*[y>0] (in place), BN3
+                dc3 = _bn_bwd(blk.bn3, dy, r.c3, r.s3, rows_o, 1, ymask=r.y, dz_out=dy)
+                dz = dy
+                da2 = _conv_bwd(blk.conv3, dc3, r.c2, N, OH, OW, r.s2, None)
+                del dc3
+                dc2 = _bn_bwd(blk.bn2, da2, r.c2, r.s2, rows_o, 2, dc_out=da2)
+                da1 = _conv_bwd(blk.conv2, dc2, r.c1, N, Hi, Wi, r.s1, r.wexp)
+                del dc2, da2
+                dc1 = _bn_bwd(blk.bn1, da1, r.c1, r.s1, rows_i, 2, dc_out=da1)
+                first = blk.conv1
+            else:
+                dc2 = _bn_bwd(blk.bn2, dy, r.c2, r.s2, rows_o, 1, ymask=r.y, dz_out=dy)
+                dz = dy
+                da1 = _conv_bwd(blk.conv2, dc2, r.c1, N, OH, OW, r.s1, None)
+                del dc2
+                dc1 = _bn_bwd(blk.bn1, da1, r.c1, r.s1, rows_o, 2, dc_out=da1)
+                first = blk.conv1
+            if blk.downsample is not None:
+                dcd = _bn_bwd(blk.downsample[1], dz, r.cd, r.sd, rows_o, 0, dc_out=dz)
+                t = _conv_bwd(blk.downsample[0], dcd, r.yin, N, Hi, Wi, None, None)
+                dy = _conv_bwd(first, dc1, r.yin, N, Hi, Wi, None, None, residual=t)
+                del t, dcd
+            else:
+                dy = _conv_bwd(first, dc1, r.yin, N, Hi, Wi, None, None, residual=dz)
+            del dc1, da1, dz, r
+        # stem: max-pool, BN0, conv1 weight gradient (no data gradient: the input is a leaf)
+        conv1, bn1 = st["conv1"], st["bn1"]
+        da0 = ops.maxpool_bwd(dy, S["am"], N, H1, W1, 64)
+        dc0 = _bn_bwd(bn1, da0, S["c0"], S["s0"], N * H1 * W1, 2, dc_out=da0)
+        gw, acc = grad_target(conv1.weight)
+        ops.stem_wgrad(dc0, S["x"], gw, N, H, W)
+        deliver_grad(conv1.weight, gw, acc)
+        return None, None, None
+
+
+class KoafTrunk(nn.Sequential):
+    """`nn.Sequential(*children)` with the reference's child indices (state_dict keys `0.weight`,
+    `1.running_mean`, `4.0.conv1.weight`, ...), executed as the fused HIP schedule above.
+
+    forward(x): x = the SINGLE-channel image batch (N,1,H,W); returns (N,C,1,1) with the GAP child
+    present, else (N,C,h,w)."""
+
+    def _koaf_layout(self):
+        lay = self.__dict__.get("_koaf_lay")
+        if lay is not None:
+            return lay
+        ch = list(self.children())
+        if not (len(ch) >= 8 and isinstance(ch[0], nn.Conv2d) and isinstance(ch[1], nn.BatchNorm2d)
+                and isinstance(ch[3], nn.MaxPool2d)):
+            raise TypeError("KoafTrunk expects the children of a koaf ResNet (conv1, bn1, relu, maxpool, layer1-4[, avgpool])")
+        c1 = ch[0]
+        if c1.kernel_size != (7, 7) or c1.stride != (2, 2) or c1.padding != (3, 3) or c1.out_channels != 64:
+            raise NotImplementedError("stem other than 7x7/s2/p3 -> 64 is not built")
+        blocks = []
+        gap = False
+        for m in ch[4:]:
+            if isinstance(m, nn.Sequential):
+                blocks.extend(list(m.children()))
+            elif isinstance(m, nn.AdaptiveAvgPool2d):
+                gap = True
+            else:
+                raise TypeError(f"unexpected trunk child {type(m)}")
+        lay = dict(conv1=ch[0], bn1=ch[1], blocks=blocks, gap=gap)
+        self.__dict__["_koaf_lay"] = lay
+        return lay
+
+    def forward(self, x):
+        lay = self._koaf_layout()
+        return EncoderFn.apply(x, self, lay["conv1"].weight)

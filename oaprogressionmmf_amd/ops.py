@@ -1,0 +1,342 @@
+"""Tensor-level wrappers over the libkoaf C ABI.
+
+Every function takes/returns `torch.Tensor`s that live on a HIP device (torch is used for device
+memory and streams only) and launches hand-written gfx950 kernels on torch's current stream.
+Activations are NHWC fp32.  Nothing here falls back to torch math: a CPU tensor or a missing
+library raises.
+"""
+import ctypes
+
+import torch
+
+from ._lib import KoafGemm, KoafError, check, lib
+
+_i32 = ctypes.c_int32
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise KoafError("koaf ops need tensors on a HIP device (no CPU fallback exists)")
+    if t.dtype not in (torch.float32, torch.int64, torch.uint8):
+        raise KoafError(f"unexpected dtype {t.dtype}")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+def conv_out(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------
+def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, stats=False):
+    """x [N,H,W,Cin] (any view with that memory), w packed [Cout,KH,KW,Cin] -> y [N,OH,OW,Cout],
+    (part, rows) per-tile column statistics if stats."""
+    L = lib()
+    OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
+    y = _empty((N, OH, OW, Cout), x)
+    part, rows = None, _i32(0)
+    if stats:
+        nrows = L.koaf_conv2d_stats_rows(N * OH * OW, Cout)
+        part = _empty((nrows, 2, Cout), x)
+    check(L.koaf_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
+                            _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _stream()), "conv2d_fwd")
+    if stats:
+        assert rows.value == part.shape[0], (rows.value, part.shape)
+    return y, part
+
+
+def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None):
+    L = lib()
+    dx = _empty((N, H, W, Cin), dy)
+    check(L.koaf_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(residual),
+                              _stream()), "conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(dy, x, dw, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None):
+    """writes dw (packed [Cout,KH,KW,Cin] memory)"""
+    L = lib()
+    ws = L.koaf_conv2d_wgrad_ws(N, H, W, Cin, Cout, KH, KW, stride, pad)
+    slabs = _empty((ws,), dy) if ws > 0 else None
+    check(L.koaf_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
+                              _ptr(in_sh), _ptr(slabs), _stream()), "conv2d_wgrad")
+    return dw
+
+
+def gconv_expand_w(w, C, groups):
+    wexp = _empty((C // 64, 64, 9, 64), w)
+    check(lib().koaf_gconv_expand_w(_ptr(w), _ptr(wexp), C, groups, _stream()), "gconv_expand_w")
+    return wexp
+
+
+def gconv_compress_dw(dwexp, dw, C, groups):
+    check(lib().koaf_gconv_compress_dw(_ptr(dwexp), _ptr(dw), C, groups, _stream()), "gconv_compress_dw")
+    return dw
+
+
+def gconv3x3_fwd(x, wexp, N, H, W, C, stride, in_sc=None, in_sh=None, stats=False):
+    L = lib()
+    OH, OW = conv_out(H, 3, stride, 1), conv_out(W, 3, stride, 1)
+    y = _empty((N, OH, OW, C), x)
+    part, rows = None, _i32(0)
+    if stats:
+        part = _empty(((N * OH * OW + 127) // 128, 2, C), x)
+    check(L.koaf_gconv3x3_fwd(_ptr(x), _ptr(wexp), _ptr(y), N, H, W, C, stride, _ptr(in_sc), _ptr(in_sh), _ptr(part),
+                              ctypes.addressof(rows), _stream()), "gconv3x3_fwd")
+    return y, part
+
+
+def gconv3x3_dgrad(dy, wexp, N, H, W, C, stride):
+    dx = _empty((N, H, W, C), dy)
+    check(lib().koaf_gconv3x3_dgrad(_ptr(dy), _ptr(wexp), _ptr(dx), N, H, W, C, stride, _stream()), "gconv3x3_dgrad")
+    return dx
+
+
+def gconv3x3_wgrad(dy, x, N, H, W, C, stride, in_sc=None, in_sh=None):
+    L = lib()
+    ws = L.koaf_gconv3x3_wgrad_ws(N, H, W, C, stride)
+    slabs = _empty((ws,), dy)
+    dwexp = _empty((C // 64, 64, 9, 64), dy)
+    check(L.koaf_gconv3x3_wgrad(_ptr(dy), _ptr(x), _ptr(dwexp), N, H, W, C, stride, _ptr(in_sc), _ptr(in_sh),
+                                _ptr(slabs), _stream()), "gconv3x3_wgrad")
+    return dwexp
+
+
+def stem_fold_w(w):
+    w1t = _empty((49, 64), w)
+    check(lib().koaf_stem_fold_w(_ptr(w), _ptr(w1t), _stream()), "stem_fold_w")
+    return w1t
+
+
+def stem_fwd(x, w1t, N, H, W):
+    y = _empty((N, conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3), 64), x)
+    check(lib().koaf_stem_fwd(_ptr(x), _ptr(w1t), _ptr(y), N, H, W, _stream()), "stem_fwd")
+    return y
+
+
+def stem_wgrad(dy, x, dw, N, H, W):
+    """writes dw (packed [64,7,7,3] memory)"""
+    L = lib()
+    slabs = _empty((L.koaf_stem_wgrad_ws(N, H, W),), dy)
+    dw1t = _empty((49, 64), dy)
+    check(L.koaf_stem_wgrad(_ptr(dy), _ptr(x), _ptr(dw1t), N, H, W, _ptr(slabs), _stream()), "stem_wgrad")
+    check(L.koaf_stem_unfold_dw(_ptr(dw1t), _ptr(dw), _stream()), "stem_unfold_dw")
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------
+# batch norm
+# ------------------------------------------------------------------------------------------------
+def colstats(x, rows, C):
+    L = lib()
+    part = _empty((L.koaf_colpart_rows(rows, C), 2, C), x)
+    r = _i32(0)
+    check(L.koaf_colstats(_ptr(x), rows, C, _ptr(part), ctypes.addressof(r), _stream()), "colstats")
+    return part
+
+
+def bn_finalize(part, C, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, train):
+    """-> saved [4][C] = mean, invstd, sc, sh"""
+    saved = _empty((4, C), gamma if gamma is not None else running_mean)
+    rows = part.shape[0] if part is not None else 0
+    check(lib().koaf_bn_finalize(_ptr(part), rows, C, count, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                 _ptr(running_var), _ptr(nbt), momentum, eps, 1 if train else 0, _ptr(saved[0]),
+                                 _ptr(saved[1]), _ptr(saved[2]), _ptr(saved[3]), _stream()), "bn_finalize")
+    return saved
+
+
+def bn_add_relu(c, saved, rows, C, idt=None, idsaved=None, out=None):
+    y = out if out is not None else torch.empty_like(c)
+    check(lib().koaf_bn_add_relu(_ptr(c), _ptr(saved[2]), _ptr(saved[3]), _ptr(idt),
+                                 _ptr(idsaved[2]) if idsaved is not None else None,
+                                 _ptr(idsaved[3]) if idsaved is not None else None, _ptr(y), rows, C, _stream()),
+          "bn_add_relu")
+    return y
+
+
+def bn_bwd(g, c, saved, rows, C, count, dgamma, dbeta, mask_mode, ymask=None, dz_out=None, dc_out=None):
+    """Full BatchNorm(+ReLU mask) backward: returns dc.  g is the upstream gradient; with a mask the
+    masked gradient dz is written to dz_out (default: in place over g)."""
+    L = lib()
+    if mask_mode != 0 and dz_out is None:
+        dz_out = g  # mask in place
+    part = _empty((L.koaf_colpart_rows(rows, C), 2, C), g)
+    r = _i32(0)
+    check(L.koaf_bn_bwd_reduce(_ptr(g), _ptr(c), _ptr(ymask), _ptr(saved[2]), _ptr(saved[3]), _ptr(saved[0]),
+                               _ptr(saved[1]), mask_mode, _ptr(dz_out), _ptr(part), ctypes.addressof(r), rows, C,
+                               _stream()), "bn_bwd_reduce")
+    coef = _empty((3, C), g)
+    check(L.koaf_bn_bwd_finalize(_ptr(part), r.value, C, count, _ptr(saved[2]), _ptr(saved[1]), _ptr(dgamma),
+                                 _ptr(dbeta), _ptr(coef), _stream()), "bn_bwd_finalize")
+    dz = dz_out if dz_out is not None else g
+    dc = dc_out if dc_out is not None else torch.empty_like(c)
+    check(L.koaf_bn_bwd_apply(_ptr(dz), _ptr(c), _ptr(saved[0]), _ptr(coef), _ptr(dc), rows, C, _stream()),
+          "bn_bwd_apply")
+    return dc
+
+
+def maxpool_fwd(c, saved, N, H, W, C):
+    OH, OW = conv_out(H, 3, 2, 1), conv_out(W, 3, 2, 1)
+    y = _empty((N, OH, OW, C), c)
+    am = _empty((N, OH, OW, C), c, dtype=torch.uint8)
+    check(lib().koaf_maxpool_fwd(_ptr(c), _ptr(saved[2]), _ptr(saved[3]), _ptr(y), _ptr(am), N, H, W, C, _stream()),
+          "maxpool_fwd")
+    return y, am
+
+
+def maxpool_bwd(dy, am, N, H, W, C):
+    da = _empty((N, H, W, C), dy)
+    check(lib().koaf_maxpool_bwd(_ptr(dy), _ptr(am), _ptr(da), N, H, W, C, _stream()), "maxpool_bwd")
+    return da
+
+
+def gap_fwd(y, N, HW, C):
+    out = _empty((N, C), y)
+    check(lib().koaf_gap_fwd(_ptr(y), _ptr(out), N, HW, C, _stream()), "gap_fwd")
+    return out
+
+
+def gap_bwd(dout, N, HW, C):
+    dy = _empty((N, HW, C), dout)
+    check(lib().koaf_gap_bwd(_ptr(dout), _ptr(dy), N, HW, C, _stream()), "gap_bwd")
+    return dy
+
+
+# ------------------------------------------------------------------------------------------------
+# input plumbing
+# ------------------------------------------------------------------------------------------------
+def slice_fold(x, B, R, Cc, S):
+    out = _empty((B * S, R, Cc), x)
+    check(lib().koaf_slice_fold(_ptr(x), _ptr(out), B, R, Cc, S, _stream()), "slice_fold")
+    return out
+
+
+def downscale2(x, B, R, Cc, S, fs):
+    out = _empty((B, R // 2, Cc // 2, S // fs), x)
+    check(lib().koaf_downscale2(_ptr(x), _ptr(out), B, R, Cc, S, fs, _stream()), "downscale2")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# transformer pieces
+# ------------------------------------------------------------------------------------------------
+def linear_fwd(x, w, b, M, N, K, residual=None):
+    y = _empty((M, N), x)
+    check(lib().koaf_linear_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(residual), _ptr(y), M, N, K, _stream()), "linear_fwd")
+    return y
+
+
+def linear_dgrad(dy, w, M, N, K, residual=None):
+    dx = _empty((M, K), dy)
+    check(lib().koaf_linear_dgrad(_ptr(dy), _ptr(w), _ptr(residual), _ptr(dx), M, N, K, _stream()), "linear_dgrad")
+    return dx
+
+
+def linear_wgrad(dy, x, dw, db, M, N, K):
+    L = lib()
+    ws = None
+    if db is not None:
+        n = L.koaf_colsum_ws(M, N)
+        ws = _empty((n,), dy) if n > 0 else None
+    check(L.koaf_linear_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(ws), M, N, K, _stream()), "linear_wgrad")
+
+
+def layernorm_fwd(x, gamma, beta, rows, D, eps):
+    y = torch.empty_like(x)
+    mean = _empty((rows,), x)
+    rstd = _empty((rows,), x)
+    check(lib().koaf_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, D, eps,
+                                   _stream()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, rows, D):
+    L = lib()
+    dx = torch.empty_like(x)
+    part = _empty((L.koaf_layernorm_bwd_ws(rows, D),), x)
+    check(L.koaf_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dgamma),
+                               _ptr(dbeta), _ptr(part), rows, D, _stream()), "layernorm_bwd")
+    return dx
+
+
+def attention_fwd(qkv, B, n, h, d, scale):
+    attn = _empty((B, h, n, n), qkv)
+    out = _empty((B, n, h * d), qkv)
+    check(lib().koaf_attention_fwd(_ptr(qkv), _ptr(attn), _ptr(out), B, n, h, d, scale, _stream()), "attention_fwd")
+    return out, attn
+
+
+def attention_bwd(dout, qkv, attn, B, n, h, d, scale):
+    dqkv = torch.empty_like(qkv)
+    ws = torch.empty_like(attn)
+    check(lib().koaf_attention_bwd(_ptr(dout), _ptr(qkv), _ptr(attn), _ptr(dqkv), _ptr(ws), B, n, h, d, scale,
+                                   _stream()), "attention_bwd")
+    return dqkv
+
+
+def gelu_fwd(x):
+    y = torch.empty_like(x)
+    check(lib().koaf_gelu_fwd(_ptr(x), _ptr(y), x.numel(), _stream()), "gelu_fwd")
+    return y
+
+
+def gelu_bwd(dy, x):
+    dx = torch.empty_like(x)
+    check(lib().koaf_gelu_bwd(_ptr(dy), _ptr(x), _ptr(dx), x.numel(), _stream()), "gelu_bwd")
+    return dx
+
+
+def relu_fwd(x):
+    y = torch.empty_like(x)
+    check(lib().koaf_relu_fwd(_ptr(x), _ptr(y), x.numel(), _stream()), "relu_fwd")
+    return y
+
+
+def relu_bwd(dy, y):
+    dx = torch.empty_like(y)
+    check(lib().koaf_relu_bwd(_ptr(dy), _ptr(y), _ptr(dx), y.numel(), _stream()), "relu_bwd")
+    return dx
+
+
+def dropout(x, p, seed):
+    y = torch.empty_like(x)
+    check(lib().koaf_dropout(_ptr(x), _ptr(y), x.numel(), p, seed, _stream()), "dropout")
+    return y
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    check(lib().koaf_add(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "add")
+    return out
+
+
+def focal_loss(logits, target, gamma, mean=True, focal=True):
+    B, C = logits.shape
+    loss = _empty((), logits)
+    dl = torch.empty_like(logits)
+    if focal:
+        check(lib().koaf_focal_loss(_ptr(logits), _ptr(target), _ptr(loss), _ptr(dl), B, C, gamma, 1 if mean else 0,
+                                    _stream()), "focal_loss")
+    else:
+        check(lib().koaf_ce_loss(_ptr(logits), _ptr(target), _ptr(loss), _ptr(dl), B, C, _stream()), "ce_loss")
+    return loss, dl
+
+
+def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, adamw=False):
+    check(lib().koaf_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, b1, b2, eps, wd, step, 1 if adamw else 0,
+                               _stream()), "adam_step")
+
+
+def gemm(desc: KoafGemm):
+    check(lib().koaf_gemm(ctypes.byref(desc), _stream()), "gemm")

@@ -1,0 +1,460 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  A functional CPU restatement (stock torch fp32 ops over a flat
+{reference state_dict key: tensor} dictionary) of the koafusion train-step hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this module; the
+product package `oaprogressionmmf_amd` never does (it has no CPU path at all).
+
+Parity status: PINNED.  The reference itself holds no tests or golden vectors, so this
+restatement is pinned against outputs of the reference run in the build container:
+tests/golden/*.npz|json produced by tests/golden/make_golden.py (which imports /root/reference), checked in
+tests/test_oracle_golden.py.  Third-party arithmetic (conv, batch_norm, layer_norm, softmax, erf-GELU,
+interpolate, Adam) is PyTorch's CPU backend here as in the reference (torch 2.10.0 here vs the reference's
+pin torch==2.5.1, env_base.yml:14 -- version skew recorded in every fixture).
+
+Each function cites the reference lines it restates.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+# arch -> (block kind, blocks per stage, groups, width_per_group); koafusion/models/_torchvision.py:263-330
+ARCHS = {
+    "resnet18": ("basic", [2, 2, 2, 2], 1, 64),
+    "resnet34": ("basic", [3, 4, 6, 3], 1, 64),
+    "resnet50": ("bottleneck", [3, 4, 6, 3], 1, 64),
+    "resnext50_32x4d": ("bottleneck", [3, 4, 6, 3], 32, 4),
+}
+OUT_CH = {"resnet18": 512, "resnet34": 512, "resnet50": 2048, "resnext50_32x4d": 2048}
+SPAT = {320: 10, 160: 5, 128: 4, 96: 3, 64: 2, 32: 1, 350: 11, 25: 1}   # _xrNmrMcP.py:104-105
+
+
+# ------------------------------------------------------------------------------------------------
+# state-dict specifications (key, shape, dtype) -- the bit-exact bookkeeping of the constructors
+# ------------------------------------------------------------------------------------------------
+def _bn_spec(p, c):
+    return [(p + ".weight", (c,), torch.float32), (p + ".bias", (c,), torch.float32),
+            (p + ".running_mean", (c,), torch.float32), (p + ".running_var", (c,), torch.float32),
+            (p + ".num_batches_tracked", (), torch.int64)]
+
+
+def trunk_spec(pfx, arch):
+    """nn.Sequential(conv1, bn1, relu, maxpool, layer1..4[, avgpool]) -> indices 0,1,4,5,6,7
+    (_torchvision.py:170-182 sliced by _xrNmrMcP.py:47-59)."""
+    kind, layers, groups, wpg = ARCHS[arch]
+    exp = 4 if kind == "bottleneck" else 1
+    spec = [(f"{pfx}.0.weight", (64, 3, 7, 7), torch.float32)] + _bn_spec(f"{pfx}.1", 64)
+    inpl = 64
+    for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), layers)):
+        for b in range(nblk):
+            stride = 2 if (b == 0 and li > 0) else 1
+            p = f"{pfx}.{4 + li}.{b}"
+            if kind == "bottleneck":
+                width = int(planes * (wpg / 64.0)) * groups
+                spec += [(p + ".conv1.weight", (width, inpl, 1, 1), torch.float32)] + _bn_spec(p + ".bn1", width)
+                spec += [(p + ".conv2.weight", (width, width // groups, 3, 3), torch.float32)] + _bn_spec(p + ".bn2", width)
+                spec += [(p + ".conv3.weight", (planes * 4, width, 1, 1), torch.float32)] + _bn_spec(p + ".bn3", planes * 4)
+            else:
+                spec += [(p + ".conv1.weight", (planes, inpl, 3, 3), torch.float32)] + _bn_spec(p + ".bn1", planes)
+                spec += [(p + ".conv2.weight", (planes, planes, 3, 3), torch.float32)] + _bn_spec(p + ".bn2", planes)
+            if b == 0 and (stride != 1 or inpl != planes * exp):
+                spec += [(p + ".downsample.0.weight", (planes * exp, inpl, 1, 1), torch.float32)]
+                spec += _bn_spec(p + ".downsample.1", planes * exp)
+            inpl = planes * exp
+    return spec
+
+
+def _lin_spec(p, o, i, bias=True):
+    s = [(p + ".weight", (o, i), torch.float32)]
+    if bias:
+        s.append((p + ".bias", (o,), torch.float32))
+    return s
+
+
+def _ln_spec(p, d):
+    return [(p + ".weight", (d,), torch.float32), (p + ".bias", (d,), torch.float32)]
+
+
+def feat_spec(pfx, num_patches, dim, depth, mlp_dim, num_classes, with_cls, num_outputs=1):
+    """FeaT.__init__ (_core_trf.py:75-116)"""
+    spec = []
+    ncls = 1 if with_cls else 0
+    if with_cls:
+        spec.append((pfx + ".cls_token", (1, 1, dim), torch.float32))
+    spec.append((pfx + ".pos_embedding", (1, num_patches + ncls, dim), torch.float32))
+    spec += _lin_spec(pfx + ".patch_to_embedding", dim, dim)
+    for d in range(depth):
+        t = pfx + ".transformer"
+        spec += _ln_spec(f"{t}.prenorm_0_{d}", dim)
+        spec += _lin_spec(f"{t}.attn_{d}.to_qkv", 3 * dim, dim, bias=False)
+        spec += _lin_spec(f"{t}.attn_{d}.to_out.0", dim, dim)
+        spec += _ln_spec(f"{t}.prenorm_1_{d}", dim)
+        spec += _lin_spec(f"{t}.ff_{d}.net.0", mlp_dim, dim)
+        spec += _lin_spec(f"{t}.ff_{d}.net.3", dim, mlp_dim)
+    for i in range(num_outputs):
+        h = f"{pfx}.mlp_head{i}"
+        spec += _ln_spec(h + ".0", dim) + _lin_spec(h + ".1", mlp_dim, dim) + _lin_spec(h + ".4", num_classes, mlp_dim)
+    return spec
+
+
+def _shape_in(cfg, i):
+    t = cfg["input_size"][i]
+    if cfg["downscale"]:
+        t = [round(s * d) for s, d in zip(t, cfg["downscale"][i])]
+    return list(t)
+
+
+def model_spec(cfg):
+    """-> (spec list, vs bookkeeping dict) for a registry model config (plain nested dict)."""
+    name = cfg["name"]
+    vs = {}
+    a = cfg["agg"]
+    ncls = cfg["output_channels"]
+    if name == "XR1Cnn":                                            # _xr1_cnn.py:9-43
+        arch = cfg["fe"]["arch"]
+        spec = trunk_spec("_fe", arch)
+        spec += _lin_spec("_agg.1", a["hidden_size"], OUT_CH[arch]) + _lin_spec("_final", ncls, a["hidden_size"])
+        return spec, vs
+    if name == "MR1CnnTrf":                                         # _mrN_cnn_trf.py:12-93
+        fe = cfg["fe"]
+        if fe["arch"] not in ("resnet18", "resnet34", "resnet50"):
+            raise ValueError("Unsupported `model.fe.arch`")
+        vs["fe_out_ch"] = OUT_CH[fe["arch"]]
+        vs["shape_in"] = _shape_in(cfg, 0)
+        if fe["with_gap"]:
+            vs["fe_out_spat"] = (1, 1, 1)
+        else:
+            mp = {320: 10, 160: 5, 128: 4, 96: 3, 64: 2, 32: 1}
+            vs["fe_out_spat"] = tuple(mp[e] for e in vs["shape_in"])
+        sp, si = vs["fe_out_spat"], vs["shape_in"]
+        dv = fe["dims_view"]
+        if dv == "rc":
+            vs["agg_in_len"] = si[2] * (sp[0] * sp[1])
+        elif dv == "cs":
+            vs["agg_in_len"] = si[0] * (sp[1] * sp[2])
+        elif dv == "rs":
+            vs["agg_in_len"] = si[1] * (sp[0] * sp[2])
+        else:
+            raise ValueError("Unsupported `model.fe.dims_view`")
+        vs["agg_in_depth"] = vs["fe_out_ch"]
+        spec = trunk_spec("_fe", fe["arch"])
+        spec += feat_spec("_agg", vs["agg_in_len"], vs["agg_in_depth"], a["depth"], a["mlp_dim"], ncls, True)
+        return spec, vs
+    if name == "MR2CnnTrf":                                         # _mrN_cnn_trf.py:144-222
+        fe = cfg["fe"]
+        vs["fe_out_ch"] = OUT_CH[fe["arch"]]
+        if fe["with_gap"]:
+            vs["fe_out_spat"] = (1, 1)
+        elif cfg["input_size"][0][0] == 320:
+            vs["fe_out_spat"] = (5, 5)
+        else:
+            raise ValueError("Unspecified `model.fe` output shape for given `model.input_size`")
+        vs["agg_in_len"] = (a["num_slices"][0] + a["num_slices"][1]) * math.prod(vs["fe_out_spat"])
+        vs["agg_in_depth"] = vs["fe_out_ch"]
+        spec = trunk_spec("_fe0", fe["arch"]) + trunk_spec("_fe1", fe["arch"])
+        spec += feat_spec("_agg", vs["agg_in_len"], vs["agg_in_depth"], a["depth"], a["mlp_dim"], ncls, True)
+        return spec, vs
+    # XR + MRI families: _xr1mrN.py:11-103,160-300 ; _xrNmrMcP.py:32-182
+    fe = cfg["fe"]
+    n_mr = {"XR1MR1CnnTrf": 1, "XR1MR2CnnTrf": 2, "XR1MR2C1CnnTrf": 2}[name]
+    has_clin = name == "XR1MR2C1CnnTrf"
+    assert fe["xr"]["arch"] in OUT_CH and fe["mr"]["arch"] in OUT_CH
+    vs["fe0_out_ch"] = OUT_CH[fe["xr"]["arch"]]
+    vs["fe1_out_ch" if n_mr == 1 else "fe12_out_ch"] = OUT_CH[fe["mr"]["arch"]]
+    n_in = 1 + n_mr + (1 if has_clin else 0)
+    shapes = [_shape_in(cfg, i) for i in range(n_in)]
+    for i, s in enumerate(shapes):
+        vs[f"fe{i}_shape_in"] = s
+    assert all(e in SPAT for e in shapes[0])
+    for i in range(1, 1 + n_mr):
+        assert all(e in SPAT for e in shapes[i][:2])
+    vs["fe0_out_spat"] = (1, 1) if fe["xr"]["with_gap"] else tuple(SPAT[e] for e in shapes[0])
+    for i in range(1, 1 + n_mr):
+        vs[f"fe{i}_out_spat"] = (1, 1) if fe["mr"]["with_gap"] else tuple(SPAT[e] for e in shapes[i][:2])
+    if has_clin:
+        vs["fe3_out_spat"] = (1,)
+    vs["agg_in_len_0"] = math.prod(vs["fe0_out_spat"])
+    for i in range(1, 1 + n_mr):
+        vs[f"agg_in_len_{i}"] = a["num_slices"][i] * math.prod(vs[f"fe{i}_out_spat"])
+    if has_clin:
+        vs["agg_in_len_3"] = a["num_slices"][3] * math.prod(vs["fe3_out_spat"])
+    d = OUT_CH[fe["mr"]["arch"]]
+    vs["agg_in_depth"] = d
+    spec = trunk_spec("_fe0", fe["xr"]["arch"])
+    for i in range(1, 1 + n_mr):
+        spec += trunk_spec(f"_fe{i}", fe["mr"]["arch"])
+    if has_clin:
+        spec += _lin_spec("_fe3._fe.0", fe["clin"]["dim_out"], fe["clin"]["dim_in"])
+    if n_mr == 1:
+        spec += feat_spec("_agg", vs["agg_in_len_0"] + vs["agg_in_len_1"], d, a["depth"], a["mlp_dim"], ncls, True)
+    else:
+        spec += feat_spec("_agg_1", vs["agg_in_len_1"], d, a["depth"], a["mlp_dim"], ncls, False)
+        spec += feat_spec("_agg_2", vs["agg_in_len_2"], d, a["depth"], a["mlp_dim"], ncls, False)
+        tot = vs["agg_in_len_0"] + vs["agg_in_len_1"] + vs["agg_in_len_2"] + (vs["agg_in_len_3"] if has_clin else 0)
+        spec += feat_spec("_agg_final", tot, d, a["depth"], a["mlp_dim"], ncls, True)
+    return spec, vs
+
+
+def new_state(cfg, fill=None):
+    """Allocate the model state {key: tensor}; `fill(key, shape, is_int) -> ndarray` sets the values."""
+    spec, vs = model_spec(cfg)
+    sd = OrderedDict()
+    for k, shape, dt in spec:
+        if fill is not None:
+            sd[k] = torch.from_numpy(fill(k, shape, dt == torch.int64)).to(dt).reshape(shape).clone()
+        else:
+            sd[k] = torch.zeros(shape, dtype=dt)
+    return sd, vs
+
+
+def is_param(key):
+    leaf = key.rsplit(".", 1)[-1]
+    return leaf not in ("running_mean", "running_var", "num_batches_tracked")
+
+
+# ------------------------------------------------------------------------------------------------
+# encoders
+# ------------------------------------------------------------------------------------------------
+def _bn(x, sd, p, train):
+    """nn.BatchNorm2d forward incl. running-stat update (_torchvision.py:121,124,128; torch semantics)"""
+    if train:
+        sd[p + ".num_batches_tracked"] += 1
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                        training=train, momentum=0.1, eps=1e-5)
+
+
+def _bottleneck(x, sd, p, train, stride, groups):
+    """Bottleneck.forward (_torchvision.py:118-138): 1x1 -> 3x3(stride, groups) -> 1x1, residual, ReLU"""
+    out = torch.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"]), sd, p + ".bn1", train))
+    out = torch.relu(_bn(F.conv2d(out, sd[p + ".conv2.weight"], stride=stride, padding=1, groups=groups), sd,
+                         p + ".bn2", train))
+    out = _bn(F.conv2d(out, sd[p + ".conv3.weight"]), sd, p + ".bn3", train)
+    idt = x
+    if (p + ".downsample.0.weight") in sd:
+        idt = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride), sd, p + ".downsample.1", train)
+    return torch.relu(out + idt)
+
+
+def _basic(x, sd, p, train, stride):
+    """BasicBlock.forward (_torchvision.py:62-80)"""
+    out = torch.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"], stride=stride, padding=1), sd, p + ".bn1", train))
+    out = _bn(F.conv2d(out, sd[p + ".conv2.weight"], padding=1), sd, p + ".bn2", train)
+    idt = x
+    if (p + ".downsample.0.weight") in sd:
+        idt = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride), sd, p + ".downsample.1", train)
+    return torch.relu(out + idt)
+
+
+def trunk(x1, sd, pfx, arch, train, with_gap=True):
+    """ResNet children [:-1] (or [:-2]) applied to the 1->3 channel-repeated image
+    (_torchvision.py:226-240 without flatten/fc; repeat: _xrNmrMcP.py:211-213)."""
+    kind, layers, groups, _ = ARCHS[arch]
+    x = x1.expand(-1, 3, -1, -1) if x1.shape[1] == 1 else x1
+    x = F.conv2d(x, sd[pfx + ".0.weight"], stride=2, padding=3)
+    x = torch.relu(_bn(x, sd, pfx + ".1", train))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    for li, nblk in enumerate(layers):
+        for b in range(nblk):
+            stride = 2 if (b == 0 and li > 0) else 1
+            p = f"{pfx}.{4 + li}.{b}"
+            x = _bottleneck(x, sd, p, train, stride, groups) if kind == "bottleneck" else _basic(x, sd, p, train, stride)
+    if with_gap:
+        x = F.adaptive_avg_pool2d(x, (1, 1))
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# transformer (koafusion/models/_core_trf.py)
+# ------------------------------------------------------------------------------------------------
+def attention(x, sd, p, heads):
+    """Attention.forward (:167-182): scale = dim^-0.5 with the FULL width (:160); '(qkv h d)' split (:170)"""
+    b, n, dim = x.shape
+    d = dim // heads
+    qkv = F.linear(x, sd[p + ".to_qkv.weight"])
+    q, k, v = qkv.reshape(b, n, 3, heads, d).permute(2, 0, 3, 1, 4)
+    dots = torch.matmul(q, k.transpose(-1, -2)) * (dim ** -0.5)
+    attn = dots.softmax(dim=-1)
+    out = torch.matmul(attn, v).permute(0, 2, 1, 3).reshape(b, n, dim)
+    return F.linear(out, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"]), attn
+
+
+def transformer(x, sd, p, depth, heads):
+    """Transformer.forward (:195-205): pre-LN, residual after attention and after the MLP, no final LN"""
+    attns = []
+    dim = x.shape[-1]
+    for d in range(depth):
+        o = F.layer_norm(x, (dim,), sd[f"{p}.prenorm_0_{d}.weight"], sd[f"{p}.prenorm_0_{d}.bias"], 1e-5)
+        o, a = attention(o, sd, f"{p}.attn_{d}", heads)
+        attns.append(a)
+        x = o + x
+        f = F.layer_norm(x, (dim,), sd[f"{p}.prenorm_1_{d}.weight"], sd[f"{p}.prenorm_1_{d}.bias"], 1e-5)
+        f = F.linear(F.gelu(F.linear(f, sd[f"{p}.ff_{d}.net.0.weight"], sd[f"{p}.ff_{d}.net.0.bias"])),
+                     sd[f"{p}.ff_{d}.net.3.weight"], sd[f"{p}.ff_{d}.net.3.bias"])
+        x = f + x
+    return x, attns
+
+
+def feat(features, sd, p, depth, heads, with_cls, num_outputs=1):
+    """FeaT.forward (:118-138) -> (outputs (B,num_outputs,classes), states, attentions)"""
+    x = F.linear(features, sd[p + ".patch_to_embedding.weight"], sd[p + ".patch_to_embedding.bias"])
+    if with_cls:
+        x = torch.cat((sd[p + ".cls_token"].expand(features.shape[0], -1, -1), x), dim=1)
+    x = x + sd[p + ".pos_embedding"]
+    states, attns = transformer(x, sd, p + ".transformer", depth, heads)
+    dim = x.shape[-1]
+    outs = []
+    for i in range(num_outputs):
+        h = f"{p}.mlp_head{i}"
+        t = F.layer_norm(states[:, i], (dim,), sd[h + ".0.weight"], sd[h + ".0.bias"], 1e-5)
+        t = F.gelu(F.linear(t, sd[h + ".1.weight"], sd[h + ".1.bias"]))
+        outs.append(F.linear(t, sd[h + ".4.weight"], sd[h + ".4.bias"]))
+    return torch.stack(outs, dim=1), states, attns
+
+
+# ------------------------------------------------------------------------------------------------
+# registry models: forward(cfg, sd, inputs, train) -> logits (B, classes).  Dropout p must be 0 (or
+# eval): torch's dropout stream is not reproduced by the product.
+# ------------------------------------------------------------------------------------------------
+def _fold(x, view="rc"):
+    b, ch, r, c, s = x.shape
+    if view == "rc":
+        return x.permute(0, 4, 1, 2, 3).reshape(b * s, ch, r, c)      # "b ch r c s -> (b s) ch r c"
+    if view == "cs":
+        return x.permute(0, 2, 1, 3, 4).reshape(b * r, ch, c, s)      # "(b r) ch c s"
+    if view == "rs":
+        return x.permute(0, 3, 1, 2, 4).reshape(b * c, ch, r, s)      # "(b c) ch r s"
+    raise ValueError("Unsupported `model.fe.dims_view`")
+
+
+def _tok(f, b):
+    n, c, h, w = f.shape                                               # "(b s) ch d0 d1 -> b (s d0 d1) ch"
+    return f.reshape(b, n // b, c, h * w).permute(0, 1, 3, 2).reshape(b, (n // b) * h * w, c)
+
+
+def forward(cfg, sd, inputs, train):
+    name = cfg["name"]
+    a = cfg["agg"]
+    if name == "XR1Cnn":                                            # _xr1_cnn.py:48-81
+        f = trunk(inputs[0], sd, "_fe", cfg["fe"]["arch"], train).flatten(1)
+        h = torch.relu(F.linear(f, sd["_agg.1.weight"], sd["_agg.1.bias"]))
+        return F.linear(h, sd["_final.weight"], sd["_final.bias"])
+    if name == "MR1CnnTrf":                                         # _mrN_cnn_trf.py:99-141
+        fe = cfg["fe"]
+        b = inputs[0].shape[0]
+        f = trunk(_fold(inputs[0], fe["dims_view"]), sd, "_fe", fe["arch"], train, fe["with_gap"])
+        out, _, _ = feat(_tok(f, b), sd, "_agg", a["depth"], a["heads"], True)
+        return out.reshape(b, -1)
+    if name == "MR2CnnTrf":                                         # _mrN_cnn_trf.py:228-272
+        fe = cfg["fe"]
+        b = inputs[0].shape[0]
+        f0 = _tok(trunk(_fold(inputs[0]), sd, "_fe0", fe["arch"], train, fe["with_gap"]), b)
+        f1 = _tok(trunk(_fold(inputs[1]), sd, "_fe1", fe["arch"], train, fe["with_gap"]), b)
+        out, _, _ = feat(torch.cat([f0, f1], 1), sd, "_agg", a["depth"], a["heads"], True)
+        return out.reshape(b, -1)
+    fe = cfg["fe"]
+    gap = bool(fe["xr"]["with_gap"] or fe["mr"]["with_gap"])       # Q7
+    b = inputs[0].shape[0]
+    t0 = _tok(trunk(inputs[0], sd, "_fe0", fe["xr"]["arch"], train, gap), b)
+    t1 = _tok(trunk(_fold(inputs[1]), sd, "_fe1", fe["mr"]["arch"], train, gap), b)
+    if name == "XR1MR1CnnTrf":                                      # _xr1mrN.py:109-157
+        out, _, _ = feat(torch.cat([t0, t1], 1), sd, "_agg", a["depth"], a["heads"], True)
+        return out.reshape(b, -1)
+    t2 = _tok(trunk(_fold(inputs[2]), sd, "_fe2", fe["mr"]["arch"], train, gap), b)
+    _, s1, _ = feat(t1, sd, "_agg_1", a["depth"], a["heads"], False)   # heads computed and dropped (Q4)
+    _, s2, _ = feat(t2, sd, "_agg_2", a["depth"], a["heads"], False)
+    toks = [t0, s1, s2]
+    if name == "XR1MR2C1CnnTrf":                                    # _xrNmrMcP.py:188-264, FeatC1 :11-29
+        toks.append(F.gelu(F.linear(inputs[3], sd["_fe3._fe.0.weight"], sd["_fe3._fe.0.bias"])))
+    out, _, _ = feat(torch.cat(toks, 1), sd, "_agg_final", a["depth"], a["heads"], True)
+    return out.reshape(b, -1)
+
+
+# ------------------------------------------------------------------------------------------------
+# loss, downscale, schedules, optimizer
+# ------------------------------------------------------------------------------------------------
+def focal_loss(logits, target, gamma=2.0, reduction="mean"):
+    """FocalLoss.forward (koafusion/various/_losses.py:101-108)"""
+    logpt = -F.cross_entropy(logits, target, reduction="none")
+    pt = torch.exp(logpt)
+    loss = -((1 - pt) ** gamma) * logpt
+    return loss.mean() if reduction == "mean" else loss.sum()
+
+
+def interpolate(x, scale_factor):
+    """PTInterpolate.__call__ (koafusion/preproc/_pt.py:179-200)"""
+    mode = {3: "linear", 4: "bilinear", 5: "trilinear"}[x.ndim]
+    return F.interpolate(x, scale_factor=scale_factor, recompute_scale_factor=True, align_corners=False, mode=mode)
+
+
+def lr_factor_static_decay(epoch, epochs_warmup, epochs_static, warmup_factor=0.1, decay_factor=0.9):
+    """CustomWarmupStaticDecayLR's lambda (koafusion/various/_optimizers.py:6-27)"""
+    end_w = epochs_warmup
+    end_s = end_w + epochs_static
+    if epoch <= end_w:
+        return warmup_factor + (1. - warmup_factor) * epoch / float(epochs_warmup)
+    elif end_w < epoch <= end_s:
+        return 1.
+    return decay_factor ** (epoch - end_s)
+
+
+def lr_factor_multistep(epoch, epochs_warmup, mstep_milestones, warmup_factor=0.1, mstep_factor=0.1):
+    """CustomWarmupMultiStepLR's lambda (koafusion/various/_optimizers.py:32-44)"""
+    if epoch <= epochs_warmup:
+        return warmup_factor + (1. - warmup_factor) * epoch / float(epochs_warmup)
+    return mstep_factor ** sum(epoch >= epochs_warmup + e for e in mstep_milestones)
+
+
+def adam_step(params, grads, state, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4):
+    """torch.optim.Adam single-tensor rule with coupled L2 (train_prog_fus.py:88-91 -> torch/optim/adam.py);
+    params/grads: lists of tensors (grad None = skipped); state: dict filled in place."""
+    b1, b2 = betas
+    for i, (p, g) in enumerate(zip(params, grads)):
+        if g is None:
+            continue
+        st = state.setdefault(i, dict(step=0, m=torch.zeros_like(p), v=torch.zeros_like(p)))
+        st["step"] += 1
+        g = g + weight_decay * p
+        st["m"].lerp_(g, 1 - b1)
+        st["v"].mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1 = 1 - b1 ** st["step"]
+        bc2 = 1 - b2 ** st["step"]
+        denom = (st["v"].sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(st["m"], denom, value=-(lr / bc1))
+
+
+class OracleModel:
+    """Convenience holder: parameters are leaf tensors with requires_grad, buffers plain tensors."""
+
+    def __init__(self, cfg, fill=None):
+        self.cfg = cfg
+        self.sd, self.vs = new_state(cfg, fill)
+        for k, v in self.sd.items():
+            if is_param(k):
+                v.requires_grad_(True)
+        self.opt_state = {}
+
+    def named_parameters(self):
+        return [(k, v) for k, v in self.sd.items() if is_param(k)]
+
+    def named_buffers(self):
+        return [(k, v) for k, v in self.sd.items() if not is_param(k)]
+
+    def __call__(self, *inputs, train=False):
+        return forward(self.cfg, self.sd, list(inputs), train)
+
+    def zero_grad(self):
+        for _, p in self.named_parameters():
+            p.grad = None
+
+    def train_step(self, inputs, target, lr=1e-4, weight_decay=1e-4, optimize=True):
+        """one iteration of the step body of koafusion/run/train_prog_fus.py:132-168"""
+        self.zero_grad()
+        logits = self(*inputs, train=True)
+        loss = focal_loss(logits.squeeze(1), target.long().squeeze(1))
+        loss.backward()
+        if optimize:
+            ps = [p for _, p in self.named_parameters()]
+            with torch.no_grad():
+                adam_step(ps, [p.grad for p in ps], self.opt_state, lr=lr, weight_decay=weight_decay)
+        return logits.detach(), loss.detach()

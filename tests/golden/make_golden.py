@@ -1,0 +1,352 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE (imported from
+/root/reference, read-only) on CPU with procedural weights/inputs (tests/procedural.py).
+
+Only DATA leaves this script (.npz / .json of inputs' seeds and expected outputs); no reference source,
+bytecode or pickle is written into the repo.  Import recipe: torchvision is absent, so
+`torchvision.models.resnet18/34/50` are served from the reference's own verbatim copy
+koafusion/models/_torchvision.py; _losses.py / _optimizers.py are loaded by path (the package
+__init__ of koafusion.various imports cv2/nibabel, which are absent).
+
+Usage:  python tests/golden/make_golden.py [case ...]      (no args = all cases)
+"""
+import importlib.util
+import json
+import sys
+import time
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent))
+import procedural as P  # noqa: E402
+
+REF = Path("/root/reference")
+
+
+def _load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, str(path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def import_reference():
+    tv = _load_by_path("_ref_torchvision", REF / "koafusion/models/_torchvision.py")
+    fake = types.ModuleType("torchvision")
+    models = types.ModuleType("torchvision.models")
+
+    def _absent(name):
+        def f(*a, **k):
+            raise RuntimeError(f"torchvision.models.{name} is not available in this container")
+        return f
+    for n in ("squeezenet1_0", "vgg16", "densenet161", "inception_v3"):
+        setattr(models, n, _absent(n))
+    models.resnet18, models.resnet34, models.resnet50 = tv.resnet18, tv.resnet34, tv.resnet50
+    fake.models = models
+    sys.modules["torchvision"] = fake
+    sys.modules["torchvision.models"] = models
+    sys.path.insert(0, str(REF))
+    import koafusion.models as km
+    from koafusion import preproc
+    losses = _load_by_path("_ref_losses", REF / "koafusion/various/_losses.py")
+    optims = _load_by_path("_ref_optims", REF / "koafusion/various/_optimizers.py")
+    return km, tv, preproc, losses, optims
+
+
+class Cfg(dict):
+    """attr + item access, like OmegaConf's DictConfig"""
+
+    def __init__(self, d):
+        super().__init__()
+        for k, v in d.items():
+            self[k] = Cfg(v) if isinstance(v, dict) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def set_dropout_zero_train(model):
+    model.train()
+
+
+def grads_summary(model):
+    named, none = {}, []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            none.append(k)
+        else:
+            named["grad:" + k] = p.grad.detach().numpy()
+    out = P.summarize_tensors(named)
+    out["none_grad_keys"] = np.array(none)
+    return out
+
+
+def buffers_summary(model):
+    named = {}
+    for k, b in model.named_buffers():
+        named["buf:" + k] = b.detach().numpy()
+    return P.summarize_tensors(named)
+
+
+def params_summary(model):
+    return P.summarize_tensors({"param:" + k: p.detach().numpy() for k, p in model.named_parameters()})
+
+
+def run_model_case(km, losses, cfg, B, fname, eval_fwd=True, train_step=True, adam_steps=0, seed=1234):
+    t0 = time.time()
+    torch.manual_seed(0)
+    model = km.dict_models[cfg["name"]](config=Cfg(cfg), path_weights=None)
+    P.fill_state_dict(model.state_dict())
+    xs = [t(a) for a in P.model_inputs(cfg, B, seed)]
+    y = t(P.make_target("target", B, seed))
+    loss_fn = losses.FocalLoss(reduction="mean", gamma=2.0, num_classes=2)
+    out = {"B": np.int64(B), "cfg_json": np.array(json.dumps(cfg)), "seed": np.int64(seed),
+           "torch_version": np.array(torch.__version__)}
+    if eval_fwd:
+        model.eval()
+        with torch.no_grad():
+            out["eval_logits"] = model(*xs)["main"].numpy()
+    if train_step:
+        model.train()   # all dropout p = 0 in the fixture configs; BN in batch-stat mode
+        logits = model(*xs)["main"]
+        loss = loss_fn(input=logits.squeeze(1), target=y.long().squeeze(1))
+        loss.backward()
+        out["train_logits"] = logits.detach().numpy()
+        out["train_loss"] = np.float64(loss.item())
+        out.update(grads_summary(model))
+        out.update(buffers_summary(model))
+        nbt = [b.item() for k, b in model.named_buffers() if k.endswith("num_batches_tracked")]
+        out["num_batches_tracked"] = np.array(nbt, dtype=np.int64)
+    if adam_steps:
+        # continue from the state after the train step above: 3 Adam steps on the same batch
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
+        ls = []
+        for s in range(adam_steps):
+            if s > 0 or not train_step:
+                opt.zero_grad()
+                logits = model(*xs)["main"]
+                loss = loss_fn(input=logits.squeeze(1), target=y.long().squeeze(1))
+                loss.backward()
+            ls.append(loss.item())
+            opt.step()
+        out["adam_losses"] = np.array(ls, dtype=np.float64)
+        ps = params_summary(model)
+        out.update({"adam:" + k: v for k, v in ps.items()})
+    np.savez_compressed(HERE / fname, **out)
+    print(f"  wrote {fname} ({(HERE / fname).stat().st_size / 1024:.0f} KiB) in {time.time() - t0:.1f}s")
+
+
+# ------------------------------------------------------------------------------------------------
+def case_f1_attention_feat(km, **_):
+    out = {}
+    for dim, heads, n in ((64, 4, 25), (2048, 8, 12)):
+        torch.manual_seed(0)
+        att = km.Attention(dim, heads=heads, dropout=0.0)
+        P.fill_state_dict(att.state_dict())
+        x = t(P.make_input(f"att{dim}", (2, n, dim))).requires_grad_(True)
+        o, a = att(x)
+        (o * t(P.make_input(f"attg{dim}", (2, n, dim)))).sum().backward()
+        out[f"att{dim}:out"] = o.detach().numpy()
+        out[f"att{dim}:attn"] = a.detach().numpy()
+        out[f"att{dim}:dx"] = x.grad.numpy()
+        out[f"att{dim}:dwqkv_norm"] = np.float64(att.to_qkv.weight.grad.norm().item())
+    for with_cls in (True, False):
+        torch.manual_seed(0)
+        f = km.FeaT(num_patches=25, patch_dim=64, emb_dim=64, depth=2, heads=4, mlp_dim=128, num_classes=2,
+                    with_cls=with_cls)
+        P.fill_state_dict(f.state_dict())
+        f.eval()
+        x = t(P.make_input("feat", (3, 25, 64)))
+        o, s, a = f(x)
+        tag = f"feat_cls{int(with_cls)}"
+        out[tag + ":outputs"] = o.detach().numpy()
+        out[tag + ":states"] = s.detach().numpy()
+        out[tag + ":attn0"] = a[0].detach().numpy()
+    np.savez_compressed(HERE / "f1_attention_feat.npz", **out)
+    print("  wrote f1_attention_feat.npz")
+
+
+def case_f2_bottleneck(tv, **_):
+    out = {}
+    for tag, inpl, planes, stride, groups, bw in (("s1", 256, 64, 1, 1, 64), ("s2ds", 256, 128, 2, 1, 64),
+                                                  ("g32", 256, 128, 1, 32, 4), ("g32s2ds", 256, 256, 2, 32, 4)):
+        torch.manual_seed(0)
+        ds = None
+        if stride != 1 or inpl != planes * 4:
+            ds = torch.nn.Sequential(tv.conv1x1(inpl, planes * 4, stride), torch.nn.BatchNorm2d(planes * 4))
+        blk = tv.Bottleneck(inpl, planes, stride, ds, groups, bw)
+        P.fill_state_dict(blk.state_dict())
+        x = torch.relu(t(P.make_input("blk" + tag, (4, inpl, 20, 20))))
+        blk.eval()
+        with torch.no_grad():
+            ye = blk(x).numpy()
+        blk.train()
+        xr = x.clone().requires_grad_(True)
+        y = blk(xr)
+        (y * t(P.make_input("blkg" + tag, tuple(y.shape)))).sum().backward()
+        out.update({tag + ":" + k: v for k, v in P.summarize_tensors(
+            {"eval": ye, "train": y.detach().numpy(), "dx": xr.grad.numpy()}, k=512).items()})
+        out.update({tag + ":" + k: v for k, v in P.summarize_tensors(
+            {"grad:" + k: p.grad.numpy() for k, p in blk.named_parameters()}).items()})
+        out.update({tag + ":" + k: v for k, v in P.summarize_tensors(
+            {"buf:" + k: b.numpy() for k, b in blk.named_buffers()}).items()})
+    np.savez_compressed(HERE / "f2_bottleneck.npz", **out)
+    print("  wrote f2_bottleneck.npz")
+
+
+def case_f3_trunk(tv, **_):
+    out = {}
+    for arch, shape in (("resnet50", (4, 1, 160, 160)), ("resnet50", (2, 1, 96, 112)), ("resnext50_32x4d", (2, 1, 130, 130)),
+                        ("resnet18", (2, 1, 96, 96)), ("resnet34", (2, 1, 64, 96))):
+        torch.manual_seed(0)
+        net = getattr(tv, arch)(pretrained=False)
+        trunk = torch.nn.Sequential(*list(net.children())[:-1])
+        P.fill_state_dict(trunk.state_dict())
+        x = t(P.make_input("trunk", shape)).repeat(1, 3, 1, 1)
+        tag = f"{arch}_{shape[0]}x{shape[2]}x{shape[3]}"
+        trunk.eval()
+        with torch.no_grad():
+            out[tag + ":eval"] = trunk(x).numpy()
+        trunk.train()
+        y = trunk(x)
+        (y * t(P.make_input("trunkg", tuple(y.shape)))).sum().backward()
+        out[tag + ":train"] = y.detach().numpy()
+        out.update({tag + ":" + k: v for k, v in P.summarize_tensors(
+            {"grad:" + k: p.grad.numpy() for k, p in trunk.named_parameters()}).items()})
+        out.update({tag + ":" + k: v for k, v in P.summarize_tensors(
+            {"buf:" + k: b.numpy() for k, b in trunk.named_buffers()}).items()})
+    np.savez_compressed(HERE / "f3_trunk.npz", **out)
+    print("  wrote f3_trunk.npz")
+
+
+def case_f4_xr1cnn(km, losses, **_):
+    run_model_case(km, losses, P.cfg_xr1cnn(size=350), 4, "f4_xr1cnn_350.npz")
+    run_model_case(km, losses, P.cfg_xr1cnn(size=310), 4, "f4_xr1cnn_310.npz")
+    run_model_case(km, losses, P.cfg_xr1cnn(arch="resnet18", size=160), 2, "f4_xr1cnn_r18_160.npz")
+
+
+def case_f5_mr(km, losses, **_):
+    run_model_case(km, losses, P.cfg_mr1(shape=(160, 160, 64)), 1, "f5_mr1_rc_s64.npz")
+    run_model_case(km, losses, P.cfg_mr1(shape=(64, 96, 32), dims_view="cs", depth=1), 2, "f5_mr1_cs.npz")
+    run_model_case(km, losses, P.cfg_mr1(shape=(64, 96, 32), dims_view="rs", depth=1), 2, "f5_mr1_rs.npz")
+    run_model_case(km, losses, P.cfg_mr2(), 2, "f5_mr2.npz")
+    run_model_case(km, losses, P.cfg_xr1mr1(), 2, "f5_xr1mr1.npz")
+    run_model_case(km, losses, P.cfg_xr1mr2(), 2, "f5_xr1mr2.npz")
+
+
+def case_f6_full(km, losses, **_):
+    run_model_case(km, losses, P.cfg_full(), 2, "f6_full_native_b2.npz", adam_steps=3)
+
+
+def case_f7_focal(losses, **_):
+    logits = np.concatenate([P.make_input("focal", (60, 2)) * 3,
+                             np.array([[30, -30], [-30, 30], [0, 0], [50, 50]], dtype=np.float32)])
+    tgt = P.make_target("focal_t", 64)[:, 0]
+    lt = t(logits).requires_grad_(True)
+    out = {"logits": logits, "target": tgt}
+    for red in ("mean", "sum"):
+        fl = losses.FocalLoss(reduction=red, gamma=2.0)
+        lt.grad = None
+        loss = fl(input=lt, target=t(tgt))
+        loss.backward()
+        out[f"focal_{red}:loss"] = np.float64(loss.item())
+        out[f"focal_{red}:dlogits"] = lt.grad.numpy().copy()
+    ce = losses.CrossEntropyLoss(num_classes=2)
+    lt.grad = None
+    loss = ce(lt, t(tgt))
+    loss.backward()
+    out["ce:loss"] = np.float64(loss.item())
+    out["ce:dlogits"] = lt.grad.numpy().copy()
+    np.savez_compressed(HERE / "f7_focal.npz", **out)
+    print("  wrote f7_focal.npz")
+
+
+def case_f8_interp(preproc, **_):
+    out = {}
+    x = t(P.make_input("interp_xr", (2, 1, 70, 50)))
+    out["xr"] = preproc.PTInterpolate(scale_factor=(0.5, 0.5))(x).numpy()
+    v = t(P.make_input("interp_mr", (2, 1, 36, 28, 26)))
+    out["mr_half"] = preproc.PTInterpolate(scale_factor=(0.5, 0.5, 0.5))(v).numpy()
+    out["mr_keep"] = preproc.PTInterpolate(scale_factor=(0.5, 0.5, 1.0))(v).numpy()
+    np.savez_compressed(HERE / "f8_interp.npz", **out)
+    print("  wrote f8_interp.npz")
+
+
+def case_f9_sched(optims, **_):
+    p = [torch.nn.Parameter(torch.zeros(1))]
+    tab = {}
+    opt = torch.optim.Adam(p, lr=1e-4)
+    s = optims.dict_schedulers["CustomWarmupStaticDecayLR"](optimizer=opt, epochs_warmup=5, epochs_static=100,
+                                                            epochs_decay=1)
+    lrs = []
+    for e in range(121):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        s.step()
+    tab["static_decay"] = [repr(float(v)) for v in lrs]
+    opt = torch.optim.Adam(p, lr=1e-3)
+    s = optims.dict_schedulers["CustomWarmupMultiStepLR"](optimizer=opt, epochs_warmup=5, mstep_milestones=[20, 40])
+    lrs = []
+    for e in range(121):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        s.step()
+    tab["multistep"] = [repr(float(v)) for v in lrs]
+    tab["optimizer_keys"] = sorted(optims.dict_optimizers)
+    tab["scheduler_keys"] = sorted(optims.dict_schedulers)
+    (HERE / "f9_schedules.json").write_text(json.dumps(tab, indent=0))
+    print("  wrote f9_schedules.json")
+
+
+def case_f11_bookkeeping(km, losses, **_):
+    book = {"dict_models": sorted(km.dict_models), "dict_losses": sorted(losses.dict_losses)}
+    cfgs = {"XR1Cnn": P.cfg_xr1cnn(), "MR1CnnTrf": P.cfg_mr1(), "MR2CnnTrf": P.cfg_mr2((160, 160, 64), (160, 160, 32), 4),
+            "XR1MR1CnnTrf": P.cfg_xr1mr1((350, 350), (160, 160, 64), 4),
+            "XR1MR2CnnTrf": P.cfg_xr1mr2((350, 350), (160, 160, 64), (160, 160, 32), 4), "XR1MR2C1CnnTrf": P.cfg_full()}
+    for name, cfg in cfgs.items():
+        torch.manual_seed(0)
+        m = km.dict_models[name](config=Cfg(cfg), path_weights=None)
+        sd = m.state_dict()
+        book[name] = {
+            "vs": {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in getattr(m, "vs", {}).items()},
+            "state_dict": [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()],
+            "num_params": int(sum(p.numel() for p in m.parameters())),
+        }
+    # non-default config variants whose bookkeeping differs (with_gap false)
+    cfg = P.cfg_mr1(shape=(160, 160, 64), with_gap=False)
+    m = km.dict_models["MR1CnnTrf"](config=Cfg(cfg), path_weights=None)
+    book["MR1CnnTrf_nogap"] = {"vs": {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in m.vs.items()}}
+    (HERE / "f11_bookkeeping.json").write_text(json.dumps(book))
+    print("  wrote f11_bookkeeping.json")
+
+
+CASES = {
+    "f1": case_f1_attention_feat, "f2": case_f2_bottleneck, "f3": case_f3_trunk, "f4": case_f4_xr1cnn,
+    "f5": case_f5_mr, "f6": case_f6_full, "f7": case_f7_focal, "f8": case_f8_interp, "f9": case_f9_sched,
+    "f11": case_f11_bookkeeping,
+}
+
+
+def main():
+    torch.set_num_threads(8)
+    km, tv, preproc, losses, optims = import_reference()
+    which = sys.argv[1:] or list(CASES)
+    for c in which:
+        print(f"[{c}]")
+        CASES[c](km=km, tv=tv, preproc=preproc, losses=losses, optims=optims)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,333 @@
+"""Kernel-level parity: every libkoaf entry point against a plain torch fp32/fp64 CPU reference of the
+same op (tolerances written at each assert).  All calls go through the C ABI (ctypes)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def nhwc(x):  # NCHW cpu -> NHWC contiguous
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def packw(w):  # (Cout,Cin,KH,KW) -> packed (Cout,KH,KW,Cin)
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+G = torch.Generator().manual_seed(1234)
+
+
+def rnd(*shape, scale=1.0):
+    return torch.randn(*shape, generator=G) * scale
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 2048, 2048), (736, 6144, 2048), (8, 2048, 2048), (8, 2, 2048), (8, 2048, 9),
+                                   (200, 64, 100), (129, 130, 36)])
+def test_linear(dev, M, N, K):
+    from oaprogressionmmf_amd import ops
+    x, w, b, r = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N), rnd(M, N)
+    y_ref = (x.double() @ w.double().t() + b.double() + r.double())
+    y = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), M, N, K, residual=r.to(dev))
+    assert rel_err(y, y_ref) < 2e-6
+    dy = rnd(M, N)
+    dx_ref = dy.double() @ w.double()
+    dx = ops.linear_dgrad(dy.to(dev), w.to(dev), M, N, K)
+    assert rel_err(dx, dx_ref) < 2e-6
+    dw = torch.empty(N, K, device=dev)
+    db = torch.empty(N, device=dev)
+    ops.linear_wgrad(dy.to(dev), x.to(dev), dw, db, M, N, K)
+    assert rel_err(dw, dy.double().t() @ x.double()) < 2e-6
+    assert rel_err(db, dy.double().sum(0)) < 2e-6
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (3, 20, 20, 64, 64, 1, 1, 0),
+    (3, 20, 20, 64, 256, 1, 1, 0),
+    (2, 20, 20, 256, 512, 1, 2, 0),
+    (3, 20, 20, 64, 64, 3, 1, 1),
+    (2, 21, 19, 128, 128, 3, 2, 1),
+    (5, 10, 10, 256, 256, 3, 1, 1),
+    (4, 5, 5, 512, 512, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("prologue", [False, True])
+def test_conv2d(dev, case, prologue):
+    from oaprogressionmmf_amd import ops
+    N, H, W, Cin, Cout, k, s, p = case
+    x = rnd(N, Cin, H, W)
+    w = rnd(Cout, Cin, k, k, scale=(Cin * k * k) ** -0.5)
+    sc, sh = (rnd(Cin) * 0.5 + 1.0), rnd(Cin) * 0.3
+    xin = x.double()
+    if prologue:
+        xin = torch.relu(xin * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    xin.requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y_ref = F.conv2d(xin, wd, stride=s, padding=p)
+    dy = rnd(*y_ref.shape)
+    y_ref.backward(dy.double())
+    xd, wp = nhwc(x).to(dev), packw(w).to(dev)
+    scd, shd = (sc.to(dev), sh.to(dev)) if prologue else (None, None)
+    y, part = ops.conv2d_fwd(xd, wp, N, H, W, Cin, Cout, k, k, s, p, scd, shd, stats=True)
+    assert rel_err(nchw(y.cpu()), y_ref) < 2e-6
+    # epilogue statistics = column sums / sums of squares of y
+    s1 = part[:, 0].double().sum(0).cpu()
+    s2 = part[:, 1].double().sum(0).cpu()
+    yr = y_ref.detach().permute(1, 0, 2, 3).reshape(Cout, -1)
+    assert rel_err(s1, yr.sum(1)) < 1e-4
+    assert rel_err(s2, (yr * yr).sum(1)) < 1e-5
+    dyd = nhwc(dy).to(dev)
+    if not prologue:
+        res = rnd(N, H, W, Cin)
+        dx = ops.conv2d_dgrad(dyd, wp, N, H, W, Cin, Cout, k, k, s, p, residual=res.to(dev))
+        assert rel_err(nchw(dx.cpu()) - nchw(res), xin.grad) < 4e-6
+    dw = torch.empty(Cout, k, k, Cin, device=dev)
+    ops.conv2d_wgrad(dyd, xd, dw, N, H, W, Cin, Cout, k, k, s, p, scd, shd)
+    assert rel_err(dw.cpu().permute(0, 3, 1, 2), wd.grad) < 4e-6
+
+
+def test_conv2d_wgrad_large_splitk(dev):
+    from oaprogressionmmf_amd import ops
+    N, H, W, Cin, Cout = 64, 40, 40, 64, 64
+    x, w = rnd(N, Cin, H, W), rnd(Cout, Cin, 1, 1)
+    dy = rnd(N, Cout, H, W)
+    ref = torch.einsum("nohw,nchw->oc", dy.double(), x.double())
+    dw = torch.empty(Cout, 1, 1, Cin, device=dev)
+    ops.conv2d_wgrad(nhwc(dy).to(dev), nhwc(x).to(dev), dw, N, H, W, Cin, Cout, 1, 1, 1, 0)
+    assert rel_err(dw.cpu().reshape(Cout, Cin), ref) < 4e-6
+
+
+@pytest.mark.parametrize("C,groups,stride,H", [(128, 32, 1, 22), (256, 32, 2, 22), (512, 32, 1, 11), (1024, 32, 2, 11)])
+def test_gconv3x3(dev, C, groups, stride, H):
+    from oaprogressionmmf_amd import ops
+    N, W = 2, H
+    Cg = C // groups
+    x = rnd(N, C, H, W)
+    w = rnd(C, Cg, 3, 3, scale=(Cg * 9) ** -0.5)
+    sc, sh = (rnd(C) * 0.5 + 1.0), rnd(C) * 0.3
+    xin = torch.relu(x.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    xin.requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y_ref = F.conv2d(xin, wd, stride=stride, padding=1, groups=groups)
+    dy = rnd(*y_ref.shape)
+    y_ref.backward(dy.double())
+    xd, wp = nhwc(x).to(dev), packw(w).to(dev)
+    wexp = ops.gconv_expand_w(wp, C, groups)
+    y, part = ops.gconv3x3_fwd(xd, wexp, N, H, W, C, stride, sc.to(dev), sh.to(dev), stats=True)
+    assert rel_err(nchw(y.cpu()), y_ref) < 2e-6
+    yr = y_ref.detach().permute(1, 0, 2, 3).reshape(C, -1)
+    assert rel_err(part[:, 0].double().sum(0).cpu(), yr.sum(1)) < 1e-4
+    dyd = nhwc(dy).to(dev)
+    dx = ops.gconv3x3_dgrad(dyd, wexp, N, H, W, C, stride)
+    assert rel_err(nchw(dx.cpu()), xin.grad) < 4e-6
+    dwexp = ops.gconv3x3_wgrad(dyd, xd, N, H, W, C, stride, sc.to(dev), sh.to(dev))
+    dw = torch.empty(C, 3, 3, Cg, device=dev)
+    ops.gconv_compress_dw(dwexp, dw, C, groups)
+    assert rel_err(dw.cpu().permute(0, 3, 1, 2), wd.grad) < 4e-6
+
+
+@pytest.mark.parametrize("N,H,W", [(3, 40, 40), (2, 35, 31), (1, 70, 70)])
+def test_stem(dev, N, H, W):
+    from oaprogressionmmf_amd import ops
+    x = rnd(N, 1, H, W)
+    w = rnd(64, 3, 7, 7, scale=147 ** -0.5)
+    x3 = x.double().repeat(1, 3, 1, 1)
+    wd = w.double().requires_grad_(True)
+    y_ref = F.conv2d(x3, wd, stride=2, padding=3)
+    dy = rnd(*y_ref.shape)
+    y_ref.backward(dy.double())
+    wp = packw(w).to(dev)
+    w1t = ops.stem_fold_w(wp)
+    xd = x.reshape(N, H, W).contiguous().to(dev)
+    y = ops.stem_fwd(xd, w1t, N, H, W)
+    assert rel_err(nchw(y.cpu()), y_ref) < 2e-6
+    dw = torch.empty(64, 7, 7, 3, device=dev)
+    ops.stem_wgrad(nhwc(dy).to(dev), xd, dw, N, H, W)
+    # folded gradient: every one of the 3 input channels sees the same image, so dW[:,c] are identical
+    assert rel_err(dw.cpu().permute(0, 3, 1, 2), wd.grad) < 4e-6
+
+
+@pytest.mark.parametrize("rows,C", [(5000, 64), (777, 256), (300, 2048)])
+def test_batchnorm_train(dev, rows, C):
+    from oaprogressionmmf_amd import ops
+    c = rnd(rows, C) * 2.0 + rnd(C)[None, :]
+    gamma, beta = rnd(C) * 0.5 + 1.0, rnd(C) * 0.2
+    rm, rv = rnd(C) * 0.1, torch.rand(C, generator=G) + 0.5
+    cd = c.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    z = F.batch_norm(cd, rm_ref, rv_ref, gd, bd, training=True, momentum=0.1, eps=1e-5)
+    a = torch.relu(z)
+    g = rnd(rows, C)
+    a.backward(g.double())
+    cdv = c.to(dev)
+    part = ops.colstats(cdv, rows, C)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    saved = ops.bn_finalize(part, C, rows, gamma.to(dev), beta.to(dev), rmd, rvd, nbt, 0.1, 1e-5, True)
+    assert nbt.item() == 1
+    assert rel_err(rmd, rm_ref) < 1e-6 and rel_err(rvd, rv_ref) < 1e-6
+    a_k = ops.bn_add_relu(cdv, saved, rows, C)
+    assert rel_err(a_k, a) < 1e-5
+    dgm, dbt = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    dc = ops.bn_bwd(g.to(dev), cdv, saved, rows, C, rows, dgm, dbt, mask_mode=2)
+    assert rel_err(dc, cd.grad) < 2e-5
+    assert rel_err(dgm, gd.grad) < 2e-5 and rel_err(dbt, bd.grad) < 2e-5
+    # eval mode uses the running statistics
+    saved_e = ops.bn_finalize(None, C, 0, gamma.to(dev), beta.to(dev), rmd, rvd, None, 0.1, 1e-5, False)
+    z_e = F.batch_norm(c.double(), rm_ref, rv_ref, gamma.double(), beta.double(), training=False, eps=1e-5)
+    assert rel_err(ops.bn_add_relu(cdv, saved_e, rows, C), torch.relu(z_e)) < 1e-5
+
+
+def test_bottleneck_tail(dev):
+    from oaprogressionmmf_amd import ops
+    rows, C = 900, 256
+    c3, idt, cdn = rnd(rows, C), rnd(rows, C), rnd(rows, C)
+    s3 = torch.stack([rnd(C), rnd(C), rnd(C) * 0.5 + 1, rnd(C) * 0.1])
+    sd = torch.stack([rnd(C), rnd(C), rnd(C) * 0.5 + 1, rnd(C) * 0.1])
+    y = ops.bn_add_relu(c3.to(dev), s3.to(dev), rows, C, idt=idt.to(dev))
+    assert rel_err(y, torch.relu(c3 * s3[2] + s3[3] + idt)) < 1e-6
+    y = ops.bn_add_relu(c3.to(dev), s3.to(dev), rows, C, idt=cdn.to(dev), idsaved=sd.to(dev))
+    assert rel_err(y, torch.relu(c3 * s3[2] + s3[3] + cdn * sd[2] + sd[3])) < 1e-6
+
+
+@pytest.mark.parametrize("N,H,W", [(3, 40, 40), (2, 35, 31)])
+def test_maxpool_gap(dev, N, H, W):
+    from oaprogressionmmf_amd import ops
+    C = 64
+    c = rnd(N, C, H, W)
+    sc, sh = rnd(C) * 0.5 + 1.0, rnd(C) * 0.3
+    a = torch.relu(c.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).requires_grad_(True)
+    y_ref = F.max_pool2d(a, 3, 2, 1)
+    dy = rnd(*y_ref.shape)
+    y_ref.backward(dy.double())
+    saved = torch.stack([sc, sc, sc, sh]).to(dev)
+    y, am = ops.maxpool_fwd(nhwc(c).to(dev), saved, N, H, W, C)
+    assert rel_err(nchw(y.cpu()), y_ref) < 1e-6
+    da = ops.maxpool_bwd(nhwc(dy).to(dev), am, N, H, W, C)
+    assert rel_err(nchw(da.cpu()), a.grad) < 1e-6
+    yy = rnd(N, 25, 2048)
+    assert rel_err(ops.gap_fwd(yy.to(dev), N, 25, 2048), yy.mean(1)) < 1e-6
+    dd = rnd(N, 2048)
+    assert rel_err(ops.gap_bwd(dd.to(dev), N, 25, 2048), (dd / 25)[:, None, :].expand(N, 25, 2048)) < 1e-6
+
+
+def test_fold_downscale(dev):
+    from oaprogressionmmf_amd import ops
+    B, R, Cc, S = 2, 36, 28, 25
+    x = rnd(B, 1, R, Cc, S)
+    out = ops.slice_fold(x.to(dev), B, R, Cc, S)
+    ref = x[:, 0].permute(0, 3, 1, 2).reshape(B * S, R, Cc)
+    assert torch.equal(out.cpu(), ref)
+    for fs, sf in ((1, (0.5, 0.5, 1.0)), (2, (0.5, 0.5, 0.5))):
+        S2 = 26
+        x = rnd(B, 1, R, Cc, S2)
+        ref = F.interpolate(x, scale_factor=sf, recompute_scale_factor=True, align_corners=False, mode="trilinear")
+        out = ops.downscale2(x.to(dev), B, R, Cc, S2, fs)
+        assert rel_err(out.reshape(ref.shape), ref) < 1e-6
+    x = rnd(B, 1, 70, 50)
+    ref = F.interpolate(x, scale_factor=(0.5, 0.5), recompute_scale_factor=True, align_corners=False, mode="bilinear")
+    out = ops.downscale2(x.to(dev), B, 70, 50, 1, 1)
+    assert rel_err(out.reshape(ref.shape), ref) < 1e-6
+
+
+@pytest.mark.parametrize("rows,D", [(736, 2048), (37, 2048), (50, 64)])
+def test_layernorm(dev, rows, D):
+    from oaprogressionmmf_amd import ops
+    x = (rnd(rows, D) * 3 + 1).double().requires_grad_(True)
+    g, b = (rnd(D) * 0.5 + 1).double().requires_grad_(True), rnd(D).double().requires_grad_(True)
+    y_ref = F.layer_norm(x, (D,), g, b, 1e-5)
+    dy = rnd(rows, D)
+    y_ref.backward(dy.double())
+    xd, gd, bd = x.detach().float().to(dev), g.detach().float().to(dev), b.detach().float().to(dev)
+    y, mean, rstd = ops.layernorm_fwd(xd, gd, bd, rows, D, 1e-5)
+    assert rel_err(y, y_ref) < 2e-6
+    dg, db = torch.empty(D, device=dev), torch.empty(D, device=dev)
+    dx = ops.layernorm_bwd(dy.to(dev), xd, gd, mean, rstd, dg, db, rows, D)
+    assert rel_err(dx, x.grad) < 1e-5
+    assert rel_err(dg, g.grad) < 1e-5 and rel_err(db, b.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,n,h,d", [(2, 92, 8, 256), (2, 25, 8, 256), (3, 64, 8, 256), (1, 161, 4, 16)])
+def test_attention(dev, B, n, h, d):
+    from oaprogressionmmf_amd import ops
+    dim = h * d
+    scale = dim ** -0.5
+    qkv = rnd(B, n, 3 * dim).double().requires_grad_(True)
+    q, k, v = qkv.reshape(B, n, 3, h, d).permute(2, 0, 3, 1, 4)
+    dots = torch.einsum("bhid,bhjd->bhij", q, k) * scale
+    attn_ref = dots.softmax(-1)
+    out_ref = torch.einsum("bhij,bhjd->bhid", attn_ref, v).permute(0, 2, 1, 3).reshape(B, n, dim)
+    dout = rnd(B, n, dim)
+    out_ref.backward(dout.double())
+    qd = qkv.detach().float().to(dev)
+    out, attn = ops.attention_fwd(qd, B, n, h, d, scale)
+    assert rel_err(attn, attn_ref) < 2e-6
+    assert rel_err(out, out_ref) < 2e-6
+    dqkv = ops.attention_bwd(dout.to(dev), qd, attn, B, n, h, d, scale)
+    assert rel_err(dqkv, qkv.grad) < 1e-5
+
+
+def test_pointwise_loss_adam(dev):
+    from oaprogressionmmf_amd import ops
+    x = rnd(1000, 37) * 2
+    xd = x.double().requires_grad_(True)
+    y_ref = F.gelu(xd)
+    dy = rnd(1000, 37)
+    y_ref.backward(dy.double())
+    assert rel_err(ops.gelu_fwd(x.to(dev)), y_ref) < 1e-6
+    assert rel_err(ops.gelu_bwd(dy.to(dev), x.to(dev)), xd.grad) < 1e-5
+    assert rel_err(ops.relu_fwd(x.to(dev)), torch.relu(x)) == 0
+    assert rel_err(ops.add(x.to(dev), dy.to(dev)), x + dy) == 0
+    # dropout: keep fraction and scaling
+    big = torch.ones(1 << 20, device=dev)
+    d1 = ops.dropout(big, 0.1, 12345)
+    keep = (d1 != 0).float().mean().item()
+    assert abs(keep - 0.9) < 2e-3
+    assert abs(d1.max().item() - 1 / 0.9) < 1e-6
+    assert torch.equal(d1, ops.dropout(big, 0.1, 12345)) and not torch.equal(d1, ops.dropout(big, 0.1, 999))
+    # focal loss incl. extreme logits
+    logits = torch.cat([rnd(60, 2) * 3, torch.tensor([[30.0, -30.0], [-30.0, 30.0], [0.0, 0.0], [50.0, 50.0]])])
+    tgt = torch.randint(0, 2, (64,), generator=G)
+    ld = logits.double().requires_grad_(True)
+    logpt = -F.cross_entropy(ld, tgt, reduction="none")
+    pt = torch.exp(logpt)
+    loss_ref = (-((1 - pt) ** 2.0) * logpt).mean()
+    loss_ref.backward()
+    loss, dl = ops.focal_loss(logits.to(dev), tgt.to(dev), 2.0)
+    assert abs(loss.item() - loss_ref.item()) < 1e-6 * max(1, abs(loss_ref.item()))
+    assert rel_err(dl, ld.grad) < 1e-5
+    loss, dl = ops.focal_loss(logits.to(dev), tgt.to(dev), 0.0, focal=False)
+    ld.grad = None
+    ce = F.cross_entropy(ld, tgt)
+    ce.backward()
+    assert abs(loss.item() - ce.item()) < 1e-6 * max(1, ce.item()) and rel_err(dl, ld.grad) < 1e-5
+    # Adam, 3 steps against torch.optim.Adam
+    n = 10007
+    p0, g = rnd(n), [rnd(n) for _ in range(3)]
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pr], lr=1e-3, weight_decay=1e-4)
+    pd = torch.zeros(n + 5, device=dev)[:n]
+    pd.copy_(p0)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for s in range(3):
+        pr.grad = g[s].clone()
+        opt.step()
+        ops.adam_step(pd, g[s].to(dev), m, v, n, 1e-3, 0.9, 0.999, 1e-8, 1e-4, s + 1)
+    assert rel_err(pd, pr.detach()) < 1e-6

@@ -1,0 +1,167 @@
+"""CPU: the oracle (oracle/koafusion_cpu.py) against the golden vectors produced by the imported
+reference (tests/golden/make_golden.py).  This is what PINS the oracle.  Tolerances: both sides are torch
+fp32 CPU, identical weights/inputs, so agreement is at accumulation-order level (1e-5 relative; gradients
+through 50 train-mode BatchNorm layers 2e-4)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import procedural as P
+from common import GOLDEN, cfg_of, check_summary, load, rel
+from oracle import koafusion_cpu as O
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def run_oracle_case(gold, adam_steps=0):
+    cfg = cfg_of(gold)
+    B = int(gold["B"])
+    seed = int(gold["seed"])
+    m = O.OracleModel(cfg, fill=P.fill_value)
+    xs = [t(a) for a in P.model_inputs(cfg, B, seed)]
+    y = t(P.make_target("target", B, seed))
+    out = {}
+    with torch.no_grad():
+        out["eval_logits"] = m(*xs, train=False).numpy()
+    logits, loss = m.train_step(xs, y, optimize=False)
+    out["train_logits"], out["train_loss"] = logits.numpy(), float(loss)
+    named, none = {}, []
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            none.append(k)
+        else:
+            named["grad:" + k] = p.grad.numpy()
+    out.update(P.summarize_tensors(named))
+    out["none_grad_keys"] = none
+    out.update(P.summarize_tensors({"buf:" + k: b.numpy() for k, b in m.named_buffers()}))
+    if adam_steps:
+        ps = [p for _, p in m.named_parameters()]
+        losses = [float(loss)]
+        with torch.no_grad():
+            O.adam_step(ps, [p.grad for p in ps], m.opt_state)
+        for s in range(1, adam_steps):
+            _, l = m.train_step(xs, y, optimize=True)
+            losses.append(float(l))
+        out["adam_losses"] = losses
+        out.update({"adam:" + k: v for k, v in P.summarize_tensors(
+            {"param:" + k: p.detach().numpy() for k, p in m.named_parameters()}).items()})
+    return out
+
+
+def compare_case(out, gold, gtol=2e-4):
+    assert rel(out["eval_logits"], gold["eval_logits"]) < 1e-5
+    assert rel(out["train_logits"], gold["train_logits"]) < 1e-5
+    assert abs(out["train_loss"] - float(gold["train_loss"])) < 1e-5 * max(1.0, abs(float(gold["train_loss"])))
+    assert sorted(out["none_grad_keys"]) == sorted(str(k) for k in gold["none_grad_keys"])
+    check_summary(out, gold, "grad:", gtol, "param grads")
+    check_summary(out, gold, "buf:", 1e-5, "BN buffers")
+
+
+SMALL = ["f4_xr1cnn_350.npz", "f4_xr1cnn_310.npz", "f4_xr1cnn_r18_160.npz", "f5_mr1_cs.npz", "f5_mr1_rs.npz",
+         "f5_mr2.npz", "f5_xr1mr1.npz", "f5_xr1mr2.npz", "f5_mr1_rc_s64.npz"]
+
+
+@pytest.mark.parametrize("fname", SMALL)
+def test_oracle_models(fname):
+    gold = load(fname)
+    compare_case(run_oracle_case(gold), gold)
+
+
+@pytest.mark.skipif(not (GOLDEN / "f6_full_native_b2.npz").exists(), reason="fixture missing")
+def test_oracle_full_fusion():
+    gold = load("f6_full_native_b2.npz")
+    steps = 3 if os.environ.get("KOAF_SLOW") else 0
+    out = run_oracle_case(gold, adam_steps=steps)
+    compare_case(out, gold)
+    if steps:
+        assert np.allclose(out["adam_losses"], gold["adam_losses"], rtol=1e-4)
+        check_summary(out, gold, "adam:", 1e-5, "params after 3 Adam steps")
+
+
+def test_oracle_attention_feat():
+    g = load("f1_attention_feat.npz")
+    for dim, heads, n in ((64, 4, 25), (2048, 8, 12)):
+        sd = {"a.to_qkv.weight": t(P.fill_value("to_qkv.weight", (3 * dim, dim))),
+              "a.to_out.0.weight": t(P.fill_value("to_out.0.weight", (dim, dim))),
+              "a.to_out.0.bias": t(P.fill_value("to_out.0.bias", (dim,)))}
+        x = t(P.make_input(f"att{dim}", (2, n, dim))).requires_grad_(True)
+        o, a = O.attention(x, sd, "a", heads)
+        (o * t(P.make_input(f"attg{dim}", (2, n, dim)))).sum().backward()
+        assert rel(o.detach().numpy(), g[f"att{dim}:out"]) < 1e-5
+        assert rel(a.detach().numpy(), g[f"att{dim}:attn"]) < 1e-5
+        assert rel(x.grad.numpy(), g[f"att{dim}:dx"]) < 1e-5
+    for with_cls in (True, False):
+        spec = O.feat_spec("f", 25, 64, 2, 128, 2, with_cls)
+        sd = {k: t(P.fill_value(k[2:], s, dt == torch.int64)) for k, s, dt in spec}
+        x = t(P.make_input("feat", (3, 25, 64)))
+        o, s, a = O.feat(x, sd, "f", 2, 4, with_cls)
+        tag = f"feat_cls{int(with_cls)}"
+        assert rel(o.numpy(), g[tag + ":outputs"]) < 1e-5
+        assert rel(s.numpy(), g[tag + ":states"]) < 1e-5
+        assert rel(a[0].numpy(), g[tag + ":attn0"]) < 1e-5
+
+
+def test_oracle_trunks():
+    g = load("f3_trunk.npz")
+    for arch, shape in (("resnet50", (4, 1, 160, 160)), ("resnet50", (2, 1, 96, 112)),
+                        ("resnext50_32x4d", (2, 1, 130, 130)), ("resnet18", (2, 1, 96, 96)),
+                        ("resnet34", (2, 1, 64, 96))):
+        tag = f"{arch}_{shape[0]}x{shape[2]}x{shape[3]}"
+        spec = O.trunk_spec("t", arch)
+        sd = {k: t(P.fill_value(k[2:], s, dt == torch.int64)).reshape(s) for k, s, dt in spec}
+        x = t(P.make_input("trunk", shape))
+        with torch.no_grad():
+            ye = O.trunk(x, sd, "t", arch, False)
+        assert rel(ye.numpy(), g[tag + ":eval"]) < 1e-5
+        for k in sd:
+            if O.is_param(k):
+                sd[k].requires_grad_(True)
+        y = O.trunk(x, sd, "t", arch, True)
+        (y * t(P.make_input("trunkg", tuple(y.shape)))).sum().backward()
+        assert rel(y.detach().numpy(), g[tag + ":train"]) < 1e-5
+        got = P.summarize_tensors({"grad:" + k[2:]: v.grad.numpy() for k, v in sd.items() if O.is_param(k)})
+        got.update(P.summarize_tensors({"buf:" + k[2:]: v.numpy() for k, v in sd.items() if not O.is_param(k)}))
+        got = {tag + ":" + k: v for k, v in got.items()}
+        check_summary(got, g, tag + ":grad:", 2e-4, tag)
+        check_summary(got, g, tag + ":buf:", 1e-5, tag)
+
+
+def test_oracle_focal_interp_sched():
+    g = load("f7_focal.npz")
+    lt = t(g["logits"]).requires_grad_(True)
+    for red in ("mean", "sum"):
+        lt.grad = None
+        loss = O.focal_loss(lt, t(g["target"]), 2.0, red)
+        loss.backward()
+        assert abs(loss.item() - float(g[f"focal_{red}:loss"])) < 1e-6 * max(1, abs(float(g[f"focal_{red}:loss"])))
+        assert rel(lt.grad.numpy(), g[f"focal_{red}:dlogits"]) < 1e-6
+    g = load("f8_interp.npz")
+    assert rel(O.interpolate(t(P.make_input("interp_xr", (2, 1, 70, 50))), (0.5, 0.5)).numpy(), g["xr"]) < 1e-7
+    v = t(P.make_input("interp_mr", (2, 1, 36, 28, 26)))
+    assert rel(O.interpolate(v, (0.5, 0.5, 0.5)).numpy(), g["mr_half"]) < 1e-7
+    assert rel(O.interpolate(v, (0.5, 0.5, 1.0)).numpy(), g["mr_keep"]) < 1e-7
+    tab = json.loads((GOLDEN / "f9_schedules.json").read_text())
+    # bit-exact schedule bookkeeping: lr = base_lr * lambda(epoch), compared through repr()
+    assert [repr(1e-4 * O.lr_factor_static_decay(e, 5, 100)) for e in range(121)] == tab["static_decay"]
+    assert [repr(1e-3 * O.lr_factor_multistep(e, 5, [20, 40])) for e in range(121)] == tab["multistep"]
+
+
+def test_oracle_bookkeeping():
+    book = json.loads((GOLDEN / "f11_bookkeeping.json").read_text())
+    cfgs = {"XR1Cnn": P.cfg_xr1cnn(), "MR1CnnTrf": P.cfg_mr1(),
+            "MR2CnnTrf": P.cfg_mr2((160, 160, 64), (160, 160, 32), 4),
+            "XR1MR1CnnTrf": P.cfg_xr1mr1((350, 350), (160, 160, 64), 4),
+            "XR1MR2CnnTrf": P.cfg_xr1mr2((350, 350), (160, 160, 64), (160, 160, 32), 4),
+            "XR1MR2C1CnnTrf": P.cfg_full()}
+    for name, cfg in cfgs.items():
+        spec, vs = O.model_spec(cfg)
+        ref = book[name]
+        assert [[k, list(s), str(dt)] for k, s, dt in spec] == ref["state_dict"], name
+        assert {k: (list(v) if isinstance(v, tuple) else v) for k, v in vs.items()} == ref["vs"], name
+    _, vs = O.model_spec(P.cfg_mr1(shape=(160, 160, 64), with_gap=False))
+    assert {k: (list(v) if isinstance(v, tuple) else v) for k, v in vs.items()} == book["MR1CnnTrf_nogap"]["vs"]
