@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- knees/sec of the full XR + MRI + clinical fusion train step (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload native|syn|xr1cnn|mr1] [--batch B]
+  (N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is one iteration of the reference's step body (koafusion/run/train_prog_fus.py:132-168) on one
+synthetic batch already resident in HBM: zero_grad -> forward (dropout 0.1 as in the recipe, runner.sh:352) ->
+FocalLoss -> loss.item() (the reference's per-step host sync) -> backward -> gradient all-reduce over RCCL
+(N>1) -> fused Adam.  Weak scaling: the per-GPU batch is fixed, `value` = global samples / max-over-ranks time.
+
+Workloads:
+  native (default)  XR1MR2C1CnnTrf exactly as runner.sh:341-363 (the reference's biggest registered model, the
+                    oracle-pinned mapping of BASELINE config 4): XR 1x350x350 (ResNeXt-50), SAG-3D-DESS 160x160x64 and
+                    SAG-T2-MAP 160x160x25 (ResNet-50 slice-wise), 9 clinical variables, 3 x FeaT(depth 4, 8 heads,
+                    width 2048); per-GPU batch 8.
+  xr1cnn / mr1      BASELINE configs 1 / 3 analogues (XR1Cnn B=4 @350^2; MR1CnnTrf B=4 @160x160x64).
+The JSON line carries `roofline` for the dominant kernel (the fp32 MFMA GEMM, timed live with events on the
+launch stream over one extra instrumented step) and `cpu_baseline` (the oracle = CPU port of the same step,
+timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level table)
+
+
+def workload_cfg(name):
+    import procedural as P
+    if name == "native":
+        return P.cfg_full(dropout=0.1), 8
+    if name == "xr1cnn":
+        return P.cfg_xr1cnn(size=350, dropout=0.5), 4
+    if name == "mr1":
+        return P.cfg_mr1(shape=(160, 160, 64), dropout=0.1), 4
+    raise SystemExit(f"unknown workload {name}")
+
+
+def algorithmic_train_gflop_per_sample(name):
+    # measured with torch.utils.flop_counter on the imported reference
+    return {"native": 1280.0, "xr1cnn": 62.1, "mr1": 3 * (64 * 4.1705 + 65 * 0.2097)}[name]
+
+
+def cpu_baseline(cfg, workload):
+    """The oracle (CPU port of the same train step) on this box's host cores; bounded sample."""
+    import procedural as P
+    from oracle import koafusion_cpu as O
+    B = 1
+    n = torch.get_num_threads()
+    om = O.OracleModel(cfg, fill=None)
+    g = torch.Generator().manual_seed(0)
+    for k, v in om.sd.items():      # cheap random init (values do not matter for timing)
+        if v.dtype.is_floating_point:
+            with torch.no_grad():
+                if k.endswith("running_var") or (v.dim() == 1 and k.endswith("weight")):
+                    v.fill_(1.0)
+                elif v.dim() >= 2:
+                    v.copy_(torch.randn(v.shape, generator=g) * (1.0 / max(1, v[0].numel())) ** 0.5)
+    xs = [torch.from_numpy(a) for a in P.model_inputs(cfg, B)]
+    y = torch.from_numpy(P.make_target("target", B))
+    om.train_step(xs, y)                     # warm-up
+    steps = 2 if workload == "native" else 3
+    t0 = time.time()
+    for _ in range(steps):
+        om.train_step(xs, y)
+    dt = time.time() - t0
+    return {"value": round(B * steps / dt, 4), "unit": "knees/s", "cores": n, "kind": "port",
+            "sample": f"{steps} full train steps (fwd+focal loss+bwd+Adam) of the same model/shapes at batch {B} "
+                      f"on the host CPU ({n} torch threads), after 1 warm-up step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="native")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = workload default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import procedural as P
+    from oaprogressionmmf_amd import ops
+    from oaprogressionmmf_amd.config import ConfigDict
+    from oaprogressionmmf_amd.models import dict_models
+    from oaprogressionmmf_amd.parallel import DataParallelRCCL
+    from oaprogressionmmf_amd.various import dict_losses, dict_optimizers, set_ultimate_seed
+
+    set_ultimate_seed()
+    cfg, bdef = workload_cfg(args.workload)
+    B = args.batch or bdef
+    model = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None).to(dev)
+    ddp = DataParallelRCCL(model)
+    loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
+    opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4)
+    xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(cfg, B, seed=1234 + rank)]
+    y = torch.from_numpy(P.make_target("target", B, seed=1234 + rank)).to(dev)
+    model.train()
+
+    def step():
+        opt.zero_grad()
+        logits = ddp(*xs)["main"]
+        loss = loss_fn(input=logits.squeeze(1), target=y.long().squeeze(1))
+        lv = loss.item()                      # the reference logs loss.item() every step (:159-163)
+        ddp.scale_loss(loss).backward()
+        ddp.reduce_gradients()
+        opt.step()
+        return lv
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lv = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # one extra instrumented step: live event timing of every MFMA-GEMM launch on its launch stream
+    ops.PROFILE = []
+    step()
+    torch.cuda.synchronize()
+    gemm_ms = sum(e0.elapsed_time(e1) for f, fl, e0, e1 in ops.PROFILE if f == "gemm")
+    gemm_flop = sum(fl for f, fl, e0, e1 in ops.PROFILE if f == "gemm")
+    n_launch = sum(1 for f, *_ in ops.PROFILE if f == "gemm")
+    ops.PROFILE = None
+    achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        out = {
+            "metric": "knees/sec full XR+MRI+clin fusion train step",
+            "value": round(value, 3), "unit": "knees/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {cfg['name']} train step (fwd+FocalLoss+bwd+Adam), "
+                                   f"per-GPU batch {B}, global batch {world * B}, "
+                                   + ("XR 1x350x350 + DESS 160x160x64 + T2 160x160x25 + 9 clinical; random-init weights"
+                                      if args.workload == "native" else "random-init weights"),
+                       "parallelism": f"dp{world}", "last_loss": round(lv, 6)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "koaf_gemm_kernel (fp32 MFMA implicit GEMM: conv fwd/dgrad/wgrad, linear, attention)",
+                         "launches_per_step": n_launch, "kernel_ms_per_step": round(gemm_ms, 2),
+                         "algorithmic_gflop_per_step": round(gemm_flop / 1e9, 1),
+                         "step_gflop_per_sample_survey": algorithmic_train_gflop_per_sample(args.workload)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.workload)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,9 +91,8 @@ def _bn_bwd(bn, g, c, saved, rows, mask_mode, ymask=None, dz_out=None, dc_out=No
 
 class EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, trunk, anchor):
+    def forward(ctx, x, trunk, anchor, keep):
         st = trunk._koaf_layout()
-        keep = torch.is_grad_enabled() and anchor.requires_grad
         if x.dim() == 4:
             if x.shape[1] != 1:
                 raise ValueError("KoafTrunk takes the single-channel image (the 1->3 repeat is folded into conv1)")
@@ -206,7 +205,7 @@ class EncoderFn(torch.autograd.Function):
         gw, acc = grad_target(conv1.weight)
         ops.stem_wgrad(dc0, S["x"], gw, N, H, W)
         deliver_grad(conv1.weight, gw, acc)
-        return None, None, None
+        return None, None, None, None
 
 
 class KoafTrunk(nn.Sequential):
@@ -242,4 +241,7 @@ class KoafTrunk(nn.Sequential):
 
     def forward(self, x):
         lay = self._koaf_layout()
-        return EncoderFn.apply(x, self, lay["conv1"].weight)
+        anchor = lay["conv1"].weight
+        # autograd runs Function.forward with grad mode off, so decide here whether backward can happen
+        keep = torch.is_grad_enabled() and anchor.requires_grad
+        return EncoderFn.apply(x, self, anchor, keep)

@@ -13,6 +13,27 @@ from ._lib import KoafGemm, KoafError, check, lib
 
 _i32 = ctypes.c_int32
 
+# Optional live profiler (bench.py): when a list is installed here every MFMA-GEMM based call is bracketed
+# by two events recorded on the stream the kernel is launched on (torch's current stream) and logged as
+# (family, algorithmic_flops, start_event, end_event).
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, family, flops):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.append((family, flops, e0, e1))
+
 
 def _ptr(t):
     if t is None:
@@ -49,8 +70,10 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     if stats:
         nrows = L.koaf_conv2d_stats_rows(N * OH * OW, Cout)
         part = _empty((nrows, 2, Cout), x)
+    e0 = _prof_begin()
     check(L.koaf_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
                             _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _stream()), "conv2d_fwd")
+    _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin)
     if stats:
         assert rows.value == part.shape[0], (rows.value, part.shape)
     return y, part
@@ -59,8 +82,10 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
 def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None):
     L = lib()
     dx = _empty((N, H, W, Cin), dy)
+    e0 = _prof_begin()
     check(L.koaf_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(residual),
                               _stream()), "conv2d_dgrad")
+    _prof_end(e0, "gemm", 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin)
     return dx
 
 
@@ -69,8 +94,10 @@ def conv2d_wgrad(dy, x, dw, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None,
     L = lib()
     ws = L.koaf_conv2d_wgrad_ws(N, H, W, Cin, Cout, KH, KW, stride, pad)
     slabs = _empty((ws,), dy) if ws > 0 else None
+    e0 = _prof_begin()
     check(L.koaf_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
                               _ptr(in_sh), _ptr(slabs), _stream()), "conv2d_wgrad")
+    _prof_end(e0, "gemm", 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin)
     return dw
 
 
@@ -92,14 +119,18 @@ def gconv3x3_fwd(x, wexp, N, H, W, C, stride, in_sc=None, in_sh=None, stats=Fals
     part, rows = None, _i32(0)
     if stats:
         part = _empty(((N * OH * OW + 127) // 128, 2, C), x)
+    e0 = _prof_begin()
     check(L.koaf_gconv3x3_fwd(_ptr(x), _ptr(wexp), _ptr(y), N, H, W, C, stride, _ptr(in_sc), _ptr(in_sh), _ptr(part),
                               ctypes.addressof(rows), _stream()), "gconv3x3_fwd")
+    _prof_end(e0, "gemm", 2.0 * N * OH * OW * C * 9 * (C // 32))   # algorithmic (32 groups), not the slab flops
     return y, part
 
 
 def gconv3x3_dgrad(dy, wexp, N, H, W, C, stride):
     dx = _empty((N, H, W, C), dy)
+    e0 = _prof_begin()
     check(lib().koaf_gconv3x3_dgrad(_ptr(dy), _ptr(wexp), _ptr(dx), N, H, W, C, stride, _stream()), "gconv3x3_dgrad")
+    _prof_end(e0, "gemm", 2.0 * N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C * 9 * (C // 32))
     return dx
 
 
@@ -108,8 +139,10 @@ def gconv3x3_wgrad(dy, x, N, H, W, C, stride, in_sc=None, in_sh=None):
     ws = L.koaf_gconv3x3_wgrad_ws(N, H, W, C, stride)
     slabs = _empty((ws,), dy)
     dwexp = _empty((C // 64, 64, 9, 64), dy)
+    e0 = _prof_begin()
     check(L.koaf_gconv3x3_wgrad(_ptr(dy), _ptr(x), _ptr(dwexp), N, H, W, C, stride, _ptr(in_sc), _ptr(in_sh),
                                 _ptr(slabs), _stream()), "gconv3x3_wgrad")
+    _prof_end(e0, "gemm", 2.0 * N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C * 9 * (C // 32))
     return dwexp
 
 
@@ -233,13 +266,17 @@ def downscale2(x, B, R, Cc, S, fs):
 # ------------------------------------------------------------------------------------------------
 def linear_fwd(x, w, b, M, N, K, residual=None):
     y = _empty((M, N), x)
+    e0 = _prof_begin()
     check(lib().koaf_linear_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(residual), _ptr(y), M, N, K, _stream()), "linear_fwd")
+    _prof_end(e0, "gemm", 2.0 * M * N * K)
     return y
 
 
 def linear_dgrad(dy, w, M, N, K, residual=None):
     dx = _empty((M, K), dy)
+    e0 = _prof_begin()
     check(lib().koaf_linear_dgrad(_ptr(dy), _ptr(w), _ptr(residual), _ptr(dx), M, N, K, _stream()), "linear_dgrad")
+    _prof_end(e0, "gemm", 2.0 * M * N * K)
     return dx
 
 
@@ -249,7 +286,9 @@ def linear_wgrad(dy, x, dw, db, M, N, K):
     if db is not None:
         n = L.koaf_colsum_ws(M, N)
         ws = _empty((n,), dy) if n > 0 else None
+    e0 = _prof_begin()
     check(L.koaf_linear_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(ws), M, N, K, _stream()), "linear_wgrad")
+    _prof_end(e0, "gemm", 2.0 * M * N * K)
 
 
 def layernorm_fwd(x, gamma, beta, rows, D, eps):
@@ -273,15 +312,19 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, rows, D):
 def attention_fwd(qkv, B, n, h, d, scale):
     attn = _empty((B, h, n, n), qkv)
     out = _empty((B, n, h * d), qkv)
+    e0 = _prof_begin()
     check(lib().koaf_attention_fwd(_ptr(qkv), _ptr(attn), _ptr(out), B, n, h, d, scale, _stream()), "attention_fwd")
+    _prof_end(e0, "gemm", 4.0 * B * h * n * n * d)
     return out, attn
 
 
 def attention_bwd(dout, qkv, attn, B, n, h, d, scale):
     dqkv = torch.empty_like(qkv)
     ws = torch.empty_like(attn)
+    e0 = _prof_begin()
     check(lib().koaf_attention_bwd(_ptr(dout), _ptr(qkv), _ptr(attn), _ptr(dqkv), _ptr(ws), B, n, h, d, scale,
                                    _stream()), "attention_bwd")
+    _prof_end(e0, "gemm", 8.0 * B * h * n * n * d)
     return dqkv
 
 

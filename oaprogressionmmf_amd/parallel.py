@@ -1,0 +1,130 @@
+"""Process-per-GPU data parallelism for the koafusion train step (replaces the reference's single-process
+`nn.DataParallel`, koafusion/run/train_prog_fus.py:84).
+
+One exchange step per iteration: an all-reduce (RCCL over xGMI; `backend="nccl"` IS RCCL on ROCm) of the flat
+gradient arena.  Buckets are plain [lo, hi) slices of `arena.G` -- no flatten/unflatten copies -- and are
+launched `async_op=True` the moment the last gradient of a bucket has been written by the backward kernels,
+so the exchange of the transformer/late-stage gradients runs under the remaining encoder backward.
+Parameters that never receive a gradient (the mlp_head0 of the cls-less aggregators) are learnt
+on the first step and never waited for.
+
+Semantics vs nn.DataParallel: equal shards + mean-reduction loss => mean of per-rank means is
+the global mean (call `scale_loss` or divide the loss by world size); BatchNorm statistics stay per replica
+exactly as under DataParallel; `broadcast_buffers()` copies rank 0's running stats (DataParallel keeps
+replica 0's).
+"""
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .arena import _round_up, get_arena
+
+BUCKET_ELEMS = 32 * 1024 * 1024   # 128 MB of fp32 per all-reduce (xGMI ring is per-link bound; few, large)
+
+
+class DataParallelRCCL(nn.Module):
+    def __init__(self, module: nn.Module, process_group=None, bucket_elems=BUCKET_ELEMS, overlap=True):
+        super().__init__()
+        self.module = module
+        self.pg = process_group
+        self.bucket_elems = bucket_elems
+        self.overlap = overlap
+        self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
+        self._arena = None
+        self._plan = None          # list of buckets: dict(lo, hi, need=set(param ids))
+        self._pending = None
+        self._handles = []
+        self._seen = []
+
+    # -- setup -------------------------------------------------------------------------------------
+    def arena(self):
+        a = get_arena(self.module)
+        if a is not self._arena:
+            self._arena = a
+            self._plan = None
+            a.ready_hook = self._on_ready
+            if self.world > 1:
+                self.broadcast_parameters()
+        return a
+
+    def broadcast_parameters(self):
+        a = self._arena
+        dist.broadcast(a.P, src=0, group=self.pg)
+        self.broadcast_buffers()
+
+    def broadcast_buffers(self):
+        a = self._arena
+        if a.B.numel() > 1:
+            dist.broadcast(a.B, src=0, group=self.pg)
+
+    def scale_loss(self, loss):
+        return loss / self.world if self.world > 1 else loss
+
+    # -- forward / gradient exchange -------------------------------------------------------------------
+    def forward(self, *inputs, **kw):
+        self.arena()
+        self._begin_step()
+        return self.module(*inputs, **kw)
+
+    def _begin_step(self):
+        self._handles = []
+        self._seen = []
+        if self._plan is not None:
+            self._pending = [set(b["need"]) for b in self._plan]
+
+    def _on_ready(self, p):
+        self._seen.append(p)
+        if self.world == 1 or self._plan is None or not self.overlap:
+            return
+        pid = id(p)
+        bi = self._where.get(pid)
+        if bi is None:
+            return
+        pend = self._pending[bi]
+        pend.discard(pid)
+        if not pend:
+            b = self._plan[bi]
+            self._handles.append(dist.all_reduce(self._arena.G[b["lo"]:b["hi"]], group=self.pg, async_op=True))
+
+    def _build_plan(self, params):
+        a = self._arena
+        spans = sorted((a.slot(p)[0], a.slot(p)[1], id(p)) for p in params)
+        plan, cur = [], None
+        for o, n, pid in spans:
+            hi = o + _round_up(n)
+            if cur is not None and cur["hi"] == o and (hi - cur["lo"]) <= self.bucket_elems:
+                cur["hi"] = hi
+                cur["need"].add(pid)
+            else:
+                cur = dict(lo=o, hi=hi, need={pid})
+                plan.append(cur)
+        self._plan = plan
+        self._where = {pid: i for i, b in enumerate(plan) for pid in b["need"]}
+
+    def reduce_gradients(self):
+        """Call after backward(): finishes (or, on the first step, performs) the gradient all-reduce."""
+        if self.world == 1:
+            return
+        a = self._arena
+        if self._plan is None or not self.overlap:
+            # first step: learn which parameters receive gradients, reduce everything now
+            params = [p for p in a.params if p.grad is not None]
+            self._build_plan(params)
+            for b in self._plan:
+                self._handles.append(dist.all_reduce(a.G[b["lo"]:b["hi"]], group=self.pg, async_op=True))
+        else:
+            # anything not launched from the hook (a parameter skipped this step) goes now
+            for bi, pend in enumerate(self._pending):
+                if pend:
+                    b = self._plan[bi]
+                    self._handles.append(dist.all_reduce(a.G[b["lo"]:b["hi"]], group=self.pg, async_op=True))
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+
+    # module protocol pass-throughs used by the train driver / checkpoint handler
+    def state_dict(self, *a, **k):
+        return self.module.state_dict(*a, **k)
+
+    def load_state_dict(self, *a, **k):
+        return self.module.load_state_dict(*a, **k)

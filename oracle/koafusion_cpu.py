@@ -196,11 +196,13 @@ def model_spec(cfg):
     return spec, vs
 
 
-def new_state(cfg, fill=None):
-    """Allocate the model state {key: tensor}; `fill(key, shape, is_int) -> ndarray` sets the values."""
+def new_state(cfg, fill=None, dtype=torch.float32):
+    """Allocate the model state {key: tensor}; `fill(key, shape, is_int) -> ndarray` sets the values.
+    dtype=float64 gives the high-precision twin the parity tests use as ground truth."""
     spec, vs = model_spec(cfg)
     sd = OrderedDict()
     for k, shape, dt in spec:
+        dt = dt if dt == torch.int64 else dtype
         if fill is not None:
             sd[k] = torch.from_numpy(fill(k, shape, dt == torch.int64)).to(dt).reshape(shape).clone()
         else:
@@ -426,9 +428,10 @@ def adam_step(params, grads, state, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weigh
 class OracleModel:
     """Convenience holder: parameters are leaf tensors with requires_grad, buffers plain tensors."""
 
-    def __init__(self, cfg, fill=None):
+    def __init__(self, cfg, fill=None, dtype=torch.float32):
         self.cfg = cfg
-        self.sd, self.vs = new_state(cfg, fill)
+        self.dtype = dtype
+        self.sd, self.vs = new_state(cfg, fill, dtype)
         for k, v in self.sd.items():
             if is_param(k):
                 v.requires_grad_(True)
@@ -441,7 +444,7 @@ class OracleModel:
         return [(k, v) for k, v in self.sd.items() if not is_param(k)]
 
     def __call__(self, *inputs, train=False):
-        return forward(self.cfg, self.sd, list(inputs), train)
+        return forward(self.cfg, self.sd, [x.to(self.dtype) for x in inputs], train)
 
     def zero_grad(self):
         for _, p in self.named_parameters():

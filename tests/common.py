@@ -42,3 +42,25 @@ def check_summary(got, gold, prefix, tol, what=""):
 
 def cfg_of(gold):
     return json.loads(str(gold["cfg_json"]))
+
+
+def e32_table(gold, prefix=""):
+    """{param key: relative L2 error of the reference's own fp32 gradient vs its fp64 run}"""
+    keys = [str(k) for k in gold[prefix + "e32_keys"]]
+    return dict(zip(keys, np.asarray(gold[prefix + "e32_vals"], dtype=np.float64)))
+
+
+def check_grads_vs_truth(mine, truth, e32, what, med_factor=2.0, max_factor=10.0, floor=1e-4):
+    """Gradient parity bar.  truth = float64 run of the same computation; e32[k] = how far the REFERENCE's own
+    fp32 gradient of parameter k is from that truth (recorded in the fixture).  Through ~50 train-mode
+    BatchNorm layers with random weights that noise is 1e-4 ... 2e-2 and heavy-tailed per tensor, so the
+    requirement is statistical: the typical (median) ratio  err_k / (e32_k + floor)  must be <= med_factor and
+    no single tensor may exceed max_factor."""
+    ratios = {}
+    for k, tr in truth.items():
+        ratios[k] = rel(mine[k], tr) / (e32[k] + floor)
+    r = np.array(list(ratios.values()))
+    worst = max(ratios, key=ratios.get)
+    assert np.median(r) <= med_factor, f"{what}: median error ratio {np.median(r):.2f} > {med_factor}"
+    assert r.max() <= max_factor, f"{what}: {worst} is {ratios[worst]:.1f}x the reference fp32 noise ({e32[worst]:.2e})"
+    return float(np.median(r)), float(r.max())

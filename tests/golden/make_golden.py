@@ -104,11 +104,35 @@ def params_summary(model):
     return P.summarize_tensors({"param:" + k: p.detach().numpy() for k, p in model.named_parameters()})
 
 
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def fp64_twin(build, run, grads32, logits32):
+    """Run the same reference computation in float64 and record, per parameter, how far the reference's OWN
+    fp32 gradients are from it (`e32`).  Through ~50 train-mode BatchNorm layers fp32 rounding (ReLU-mask
+    flips, small-batch statistics) moves gradients by up to a few 1e-3 relative, so parity of a different
+    fp32 implementation is stated against this noise floor, not against bit patterns."""
+    m64 = build().double()
+    logits64, grads64 = run(m64, torch.float64)
+    keys = [k for k in grads32 if k in grads64]
+    out = {"e32_keys": np.array(keys), "e32_vals": np.array([_rel(grads32[k], grads64[k]) for k in keys]),
+           "e32_logits": np.float64(_rel(logits32, logits64)), "train_logits64": logits64.numpy()}
+    out.update(P.summarize_tensors({"g64:" + k: grads64[k].numpy() for k in keys}))
+    return out
+
+
 def run_model_case(km, losses, cfg, B, fname, eval_fwd=True, train_step=True, adam_steps=0, seed=1234):
     t0 = time.time()
-    torch.manual_seed(0)
-    model = km.dict_models[cfg["name"]](config=Cfg(cfg), path_weights=None)
-    P.fill_state_dict(model.state_dict())
+
+    def build():
+        torch.manual_seed(0)
+        m = km.dict_models[cfg["name"]](config=Cfg(cfg), path_weights=None)
+        P.fill_state_dict(m.state_dict())
+        return m
+
+    model = build()
     xs = [t(a) for a in P.model_inputs(cfg, B, seed)]
     y = t(P.make_target("target", B, seed))
     loss_fn = losses.FocalLoss(reduction="mean", gamma=2.0, num_classes=2)
@@ -129,6 +153,15 @@ def run_model_case(km, losses, cfg, B, fname, eval_fwd=True, train_step=True, ad
         out.update(buffers_summary(model))
         nbt = [b.item() for k, b in model.named_buffers() if k.endswith("num_batches_tracked")]
         out["num_batches_tracked"] = np.array(nbt, dtype=np.int64)
+
+        def run64(m64, dt):
+            m64.train()
+            lg = m64(*[x.to(dt) for x in xs])["main"]
+            ls = loss_fn(input=lg.squeeze(1), target=y.long().squeeze(1))
+            ls.backward()
+            return lg.detach(), {k: p.grad.detach() for k, p in m64.named_parameters() if p.grad is not None}
+        g32 = {k: p.grad.detach() for k, p in model.named_parameters() if p.grad is not None}
+        out.update(fp64_twin(build, run64, g32, logits.detach()))
     if adam_steps:
         # continue from the state after the train step above: 3 Adam steps on the same batch
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
@@ -161,7 +194,7 @@ def case_f1_attention_feat(km, **_):
         out[f"att{dim}:out"] = o.detach().numpy()
         out[f"att{dim}:attn"] = a.detach().numpy()
         out[f"att{dim}:dx"] = x.grad.numpy()
-        out[f"att{dim}:dwqkv_norm"] = np.float64(att.to_qkv.weight.grad.norm().item())
+        out[f"att{dim}:dwqkv_norm"] = np.float64(att.to_qkv.weight.grad.double().norm().item())
     for with_cls in (True, False):
         torch.manual_seed(0)
         f = km.FeaT(num_patches=25, patch_dim=64, emb_dim=64, depth=2, heads=4, mlp_dim=128, num_classes=2,
@@ -210,23 +243,31 @@ def case_f3_trunk(tv, **_):
     out = {}
     for arch, shape in (("resnet50", (4, 1, 160, 160)), ("resnet50", (2, 1, 96, 112)), ("resnext50_32x4d", (2, 1, 130, 130)),
                         ("resnet18", (2, 1, 96, 96)), ("resnet34", (2, 1, 64, 96))):
-        torch.manual_seed(0)
-        net = getattr(tv, arch)(pretrained=False)
-        trunk = torch.nn.Sequential(*list(net.children())[:-1])
-        P.fill_state_dict(trunk.state_dict())
+        def build():
+            torch.manual_seed(0)
+            net = getattr(tv, arch)(pretrained=False)
+            tr = torch.nn.Sequential(*list(net.children())[:-1])
+            P.fill_state_dict(tr.state_dict())
+            return tr
+        trunk = build()
         x = t(P.make_input("trunk", shape)).repeat(1, 3, 1, 1)
         tag = f"{arch}_{shape[0]}x{shape[2]}x{shape[3]}"
         trunk.eval()
         with torch.no_grad():
             out[tag + ":eval"] = trunk(x).numpy()
-        trunk.train()
-        y = trunk(x)
-        (y * t(P.make_input("trunkg", tuple(y.shape)))).sum().backward()
-        out[tag + ":train"] = y.detach().numpy()
+
+        def run(m, dt):
+            m.train()
+            yy = m(x.to(dt))
+            (yy * t(P.make_input("trunkg", tuple(yy.shape))).to(dt)).sum().backward()
+            return yy.detach(), {k: p.grad.detach() for k, p in m.named_parameters()}
+        y, g32 = run(trunk, torch.float32)
+        out[tag + ":train"] = y.numpy()
         out.update({tag + ":" + k: v for k, v in P.summarize_tensors(
-            {"grad:" + k: p.grad.numpy() for k, p in trunk.named_parameters()}).items()})
+            {"grad:" + k: v.numpy() for k, v in g32.items()}).items()})
         out.update({tag + ":" + k: v for k, v in P.summarize_tensors(
             {"buf:" + k: b.numpy() for k, b in trunk.named_buffers()}).items()})
+        out.update({tag + ":" + k: v for k, v in fp64_twin(build, run, g32, y).items()})
     np.savez_compressed(HERE / "f3_trunk.npz", **out)
     print("  wrote f3_trunk.npz")
 

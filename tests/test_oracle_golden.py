@@ -53,6 +53,19 @@ def run_oracle_case(gold, adam_steps=0):
     return out
 
 
+def check_fp64_twin(gold):
+    """the oracle in float64 against the reference in float64: validates the ground-truth generator the
+    GPU parity tests use"""
+    cfg, B, seed = cfg_of(gold), int(gold["B"]), int(gold["seed"])
+    m = O.OracleModel(cfg, fill=P.fill_value, dtype=torch.float64)
+    xs = [t(a) for a in P.model_inputs(cfg, B, seed)]
+    y = t(P.make_target("target", B, seed))
+    logits, _ = m.train_step(xs, y, optimize=False)
+    assert rel(logits.numpy(), gold["train_logits64"]) < 1e-10
+    got = P.summarize_tensors({"g64:" + k: p.grad.numpy() for k, p in m.named_parameters() if p.grad is not None})
+    check_summary(got, gold, "g64:", 1e-8, "fp64 gradients")
+
+
 def compare_case(out, gold, gtol=2e-4):
     assert rel(out["eval_logits"], gold["eval_logits"]) < 1e-5
     assert rel(out["train_logits"], gold["train_logits"]) < 1e-5
@@ -70,6 +83,8 @@ SMALL = ["f4_xr1cnn_350.npz", "f4_xr1cnn_310.npz", "f4_xr1cnn_r18_160.npz", "f5_
 def test_oracle_models(fname):
     gold = load(fname)
     compare_case(run_oracle_case(gold), gold)
+    if fname in ("f4_xr1cnn_r18_160.npz", "f5_mr1_cs.npz", "f5_xr1mr2.npz"):
+        check_fp64_twin(gold)
 
 
 @pytest.mark.skipif(not (GOLDEN / "f6_full_native_b2.npz").exists(), reason="fixture missing")
