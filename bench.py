@@ -56,7 +56,8 @@ def cpu_baseline(cfg, workload):
     import procedural as P
     from oracle import koafusion_cpu as O
     B = 1
-    n = torch.get_num_threads()
+    n = min(len(os.sched_getaffinity(0)), 64)
+    torch.set_num_threads(n)
     om = O.OracleModel(cfg, fill=None)
     g = torch.Generator().manual_seed(0)
     for k, v in om.sd.items():      # cheap random init (values do not matter for timing)
@@ -87,6 +88,7 @@ def main():
     ap.add_argument("--workload", default="native")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", default="", help="write a per-shape table of the instrumented step to this file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,10 +155,21 @@ def main():
     ops.PROFILE = []
     step()
     torch.cuda.synchronize()
-    gemm_ms = sum(e0.elapsed_time(e1) for f, fl, e0, e1 in ops.PROFILE if f == "gemm")
-    gemm_flop = sum(fl for f, fl, e0, e1 in ops.PROFILE if f == "gemm")
-    n_launch = sum(1 for f, *_ in ops.PROFILE if f == "gemm")
+    prof = [(f, fl, e0.elapsed_time(e1), tag) for f, fl, e0, e1, tag in ops.PROFILE]
     ops.PROFILE = None
+    gemm_ms = sum(ms for f, fl, ms, tag in prof if f == "gemm")
+    gemm_flop = sum(fl for f, fl, ms, tag in prof if f == "gemm")
+    n_launch = sum(1 for f, *_ in prof if f == "gemm")
+    if args.breakdown and rank == 0:
+        agg = {}
+        for f, fl, ms, tag in prof:
+            a = agg.setdefault(tag, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += fl; a[2] += ms
+        with open(args.breakdown, "w") as fh:
+            fh.write(f"# per-shape GEMM-family calls of one train step ({args.workload}, batch {B}); ms from events on the launch stream\n")
+            fh.write(f"{'call':48s} {'n':>4s} {'ms':>9s} {'GFLOP':>10s} {'TFLOP/s':>8s}\n")
+            for tag, (n, fl, ms) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+                fh.write(f"{tag:48s} {n:4d} {ms:9.3f} {fl / 1e9:10.1f} {fl / ms / 1e9 if ms > 0 else 0:8.1f}\n")
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
 
     if rank == 0:

@@ -50,6 +50,7 @@ typedef struct KoafOperand {
     int32_t PH, PW;   /* pixel grid the GEMM rows (KC) or the k index (KM) enumerate: (n,py,px) */
     int32_t KH, KW, stride, pad;
     int32_t tf;       /* 0 none; 1 relu(sc[c]*x + sh[c]) on load (c = source channel) */
+    int32_t tf_bs;    /* channel offset of sc/sh per batch index z1 (grouped-conv slabs) */
     const float* sc;
     const float* sh;
 } KoafOperand;

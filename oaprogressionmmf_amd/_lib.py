@@ -34,6 +34,7 @@ class KoafOperand(ctypes.Structure):
         ("stride", ctypes.c_int32),
         ("pad", ctypes.c_int32),
         ("tf", ctypes.c_int32),
+        ("tf_bs", ctypes.c_int32),
         ("sc", ctypes.c_void_p),
         ("sh", ctypes.c_void_p),
     ]

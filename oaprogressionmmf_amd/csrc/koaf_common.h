@@ -7,6 +7,8 @@
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef long long v4l __attribute__((ext_vector_type(4)));
 
 void koaf_set_error(const char* fmt, ...);
 

@@ -358,22 +358,7 @@ extern "C" int koaf_gconv3x3_fwd(const float* x, const float* wexp, float* y, in
     g.stats = stats; g.stats_ld = C; g.stats_bs = 64;
     g.bn = 64; g.bm = 128;
     if (stats_rows) *stats_rows = (int)cdiv64(M, g.bm);
-    // per-slab transform pointers: the kernel indexes sc/sh by the slab-local channel, so shift via batch
-    // is not available -> handled by passing absolute channel pointers through A.sc + 64*z (see below)
-    if (in_sc) {
-        // launch one slab at a time (few slabs; keeps the operand descriptor simple)
-        for (int z = 0; z < C / 64; ++z) {
-            KoafGemm s = g;
-            s.nb1 = 1;
-            s.A.ptr = x + 64 * z; s.A.sc = in_sc + 64 * z; s.A.sh = in_sh + 64 * z;
-            s.B.ptr = wexp + (int64_t)z * 64 * 576;
-            s.C = y + 64 * z;
-            s.stats = stats ? stats + 64 * z : nullptr; s.stats_bs = 0;
-            int rc = koaf_gemm(&s, stream);
-            if (rc != KOAF_OK) return rc;
-        }
-        return KOAF_OK;
-    }
+    g.A.tf_bs = 64;
     return koaf_gemm(&g, stream);
 }
 

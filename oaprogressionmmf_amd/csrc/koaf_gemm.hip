@@ -24,32 +24,38 @@ template <int ROWS, int KIND, bool VEC>
 struct TileLoader {
     static constexpr int NU = ROWS / 32;
     v4f r[NU];
-    // KC state
-    const float* base[NU];
-    int iy0[NU], ix0[NU];
-    bool rv[NU];
+    unsigned vm;       // validity bits of the tile in flight: VEC 1 bit / unit, else 4 bits / unit
+    v4f ts4, th4;      // transform coefficients of the tile in flight (KC) / of this thread's columns (KM)
+    // KC state (ext-vector values, not arrays: arrays of per-unit state were left in scratch by hipcc and
+    // every scratch reload drained the in-flight global loads through the in-order vmcnt)
+    v4l base;          // element offset of each unit's row / image from the operand pointer
+    v4i iy0, ix0;
+    unsigned rvm;      // row-valid bits
     // KM state
     int col, cc, kh_, kw_;
-    bool cv[4];
-    v4f sc4, sh4;
+    unsigned cvm;      // column-valid bits
 
-    __device__ __forceinline__ void init(const KoafOperand& op, const float* ptr, int r0, int R) {
+    __device__ __forceinline__ void init(const KoafOperand& op, const float* ptr, int r0, int R, int z1) {
         const int t = threadIdx.x;
+        vm = 0;
+        ts4 = th4 = (v4f){0.f, 0.f, 0.f, 0.f};
         if constexpr (KIND == 0) {
+            rvm = 0;
+            base = (v4l){0, 0, 0, 0};
+            iy0 = ix0 = (v4i){0, 0, 0, 0};
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 int row = r0 + (t >> 3) + 32 * i;
-                rv[i] = row < R;
+                rvm |= (row < R ? 1u : 0u) << i;
                 if (op.gather == 0) {
-                    base[i] = ptr + (int64_t)row * op.ld;
-                    iy0[i] = ix0[i] = 0;
+                    base[i] = (int64_t)row * op.ld;
                 } else {
                     int ppi = op.PH * op.PW;
                     int n = row / ppi;
                     int rem = row - n * ppi;
                     int py = rem / op.PW;
                     int px = rem - py * op.PW;
-                    base[i] = ptr + (int64_t)n * op.H * op.W * op.CS;
+                    base[i] = (int64_t)n * op.H * op.W * op.CS;
                     if (op.gather == 1) {
                         iy0[i] = py * op.stride - op.pad;
                         ix0[i] = px * op.stride - op.pad;
@@ -62,8 +68,9 @@ struct TileLoader {
         } else {
             constexpr int CV = ROWS / 4;
             col = r0 + 4 * (t % CV);
+            cvm = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) cv[j] = (col + j) < R;
+            for (int j = 0; j < 4; ++j) cvm |= ((col + j) < R ? 1u : 0u) << j;
             cc = col;
             kh_ = kw_ = 0;
             if (op.gather == 1) {
@@ -73,71 +80,71 @@ struct TileLoader {
                 kw_ = tap - kh_ * op.KW;
             }
             if (op.tf) {
+                const float* sc = op.sc + z1 * op.tf_bs;
+                const float* sh = op.sh + z1 * op.tf_bs;
                 if (VEC) {
-                    sc4 = cv[0] ? *(const v4f*)(op.sc + cc) : (v4f){0.f, 0.f, 0.f, 0.f};
-                    sh4 = cv[0] ? *(const v4f*)(op.sh + cc) : (v4f){0.f, 0.f, 0.f, 0.f};
+                    if (cvm & 1u) { ts4 = *(const v4f*)(sc + cc); th4 = *(const v4f*)(sh + cc); }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        sc4[j] = cv[j] ? op.sc[cc + j] : 0.f;
-                        sh4[j] = cv[j] ? op.sh[cc + j] : 0.f;
-                    }
+                    for (int j = 0; j < 4; ++j)
+                        if ((cvm >> j) & 1u) { ts4[j] = sc[cc + j]; th4[j] = sh[cc + j]; }
                 }
             }
         }
     }
 
-    __device__ __forceinline__ void load(const KoafOperand& op, const float* ptr, int k0, int kend) {
+    // Issue the global loads of the k-tile [k0, k0+32) -- nothing here consumes a loaded value, so the
+    // s_waitcnt lands in finish(), i.e. after the MFMAs of the tile currently in LDS.
+    __device__ __forceinline__ void issue(const KoafOperand& op, const float* ptr, int k0, int kend, int z1) {
         const int t = threadIdx.x;
-        const v4f zero = {0.f, 0.f, 0.f, 0.f};
+        vm = 0;
         if constexpr (KIND == 0) {
             const int kv = t & 7;
             const int kk = k0 + 4 * kv;
-            if (op.gather == 0) {
-                v4f s4 = zero, h4 = zero;
-                if (op.tf) {
-                    if (VEC) {
-                        if (kk < kend) { s4 = *(const v4f*)(op.sc + kk); h4 = *(const v4f*)(op.sh + kk); }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (kk + j < kend) { s4[j] = op.sc[kk + j]; h4[j] = op.sh[kk + j]; }
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    v4f v = zero;
-                    if (VEC) {
-                        bool ok = rv[i] && kk < kend;
-                        if (ok) v = *(const v4f*)(base[i] + kk);
-                        if (op.tf) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = ok ? fmaxf(v[j] * s4[j] + h4[j], 0.f) : 0.f;
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            bool ok = rv[i] && (kk + j) < kend;
-                            float x = ok ? base[i][kk + j] : 0.f;
-                            if (op.tf) x = ok ? fmaxf(x * s4[j] + h4[j], 0.f) : 0.f;
-                            v[j] = x;
-                        }
-                    }
-                    r[i] = v;
-                }
-            } else {
+            int ch = kk;
+            int kh = 0, kw = 0;
+            if (op.gather != 0) {
                 // conv gather: a 32-wide k chunk lies inside one filter tap (C % 32 == 0)
                 const int tap = k0 / op.C;
                 const int c0 = k0 - tap * op.C;
-                const int kh = tap / op.KW;
-                const int kw = tap - kh * op.KW;
-                const int ch = c0 + 4 * kv;
-                v4f s4 = zero, h4 = zero;
-                if (op.tf) { s4 = *(const v4f*)(op.sc + ch); h4 = *(const v4f*)(op.sh + ch); }
+                kh = tap / op.KW;
+                kw = tap - kh * op.KW;
+                ch = c0 + 4 * kv;
+            }
+            if (op.tf) {
+                const float* sc = op.sc + z1 * op.tf_bs;
+                const float* sh = op.sh + z1 * op.tf_bs;
+                if (VEC) {
+                    const int c = (kk < kend) ? ch : 0;
+                    ts4 = *(const v4f*)(sc + c);
+                    th4 = *(const v4f*)(sh + c);
+                } else {
 #pragma unroll
-                for (int i = 0; i < NU; ++i) {
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = (kk + j < kend) ? ch + j : 0;
+                        ts4[j] = sc[c];
+                        th4[j] = sh[c];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                if (op.gather == 0) {
+                    if (VEC) {
+                        const bool ok = ((rvm >> i) & 1u) && kk < kend;
+                        r[i] = *(const v4f*)(ok ? ptr + base[i] + kk : ptr);
+                        vm |= (ok ? 1u : 0u) << i;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool ok = ((rvm >> i) & 1u) && (kk + j) < kend;
+                            r[i][j] = *(ok ? ptr + base[i] + kk + j : ptr);
+                            vm |= (ok ? 1u : 0u) << (4 * i + j);
+                        }
+                    }
+                } else {
                     int sy, sx;
-                    bool ok = rv[i] && kk < kend;
+                    bool ok = ((rvm >> i) & 1u) && kk < kend;
                     if (op.gather == 1) {
                         sy = iy0[i] + kh;
                         sx = ix0[i] + kw;
@@ -149,13 +156,8 @@ struct TileLoader {
                         ok = ok && (sy * op.stride == ny) && (sx * op.stride == nx);
                     }
                     ok = ok && (unsigned)sy < (unsigned)op.H && (unsigned)sx < (unsigned)op.W;
-                    v4f v = zero;
-                    if (ok) v = *(const v4f*)(base[i] + ((int64_t)(sy * op.W + sx) * op.CS + ch));
-                    if (op.tf) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = ok ? fmaxf(v[j] * s4[j] + h4[j], 0.f) : 0.f;
-                    }
-                    r[i] = v;
+                    r[i] = *(const v4f*)(ok ? ptr + base[i] + ((int64_t)(sy * op.W + sx) * op.CS + ch) : ptr);
+                    vm |= (ok ? 1u : 0u) << i;
                 }
             }
         } else {
@@ -185,24 +187,32 @@ struct TileLoader {
                     ok = ok && (unsigned)sy < (unsigned)op.H && (unsigned)sx < (unsigned)op.W;
                     src = ptr + ((int64_t)(n * op.H + sy) * op.W + sx) * op.CS + cc;
                 }
-                v4f v = zero;
                 if (VEC) {
-                    ok = ok && cv[0];
-                    if (ok) v = *(const v4f*)src;
-                    if (op.tf) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = ok ? fmaxf(v[j] * sc4[j] + sh4[j], 0.f) : 0.f;
-                    }
+                    ok = ok && (cvm & 1u);
+                    r[i] = *(const v4f*)(ok ? src : ptr);
+                    vm |= (ok ? 1u : 0u) << i;
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        bool okj = ok && cv[j];
-                        float x = okj ? src[j] : 0.f;
-                        if (op.tf) x = okj ? fmaxf(x * sc4[j] + sh4[j], 0.f) : 0.f;
-                        v[j] = x;
+                        const bool okj = ok && ((cvm >> j) & 1u);
+                        r[i][j] = *(okj ? src + j : ptr);
+                        vm |= (okj ? 1u : 0u) << (4 * i + j);
                     }
                 }
-                r[i] = v;
+            }
+        }
+    }
+
+    // transform + zero-fill of the tile issued by issue(); first consumer of the loaded registers
+    __device__ __forceinline__ void finish(const KoafOperand& op) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = VEC ? ((vm >> i) & 1u) : ((vm >> (4 * i + j)) & 1u);
+                float x = r[i][j];
+                if (op.tf) x = fmaxf(x * ts4[j] + th4[j], 0.f);
+                r[i][j] = ok ? x : 0.f;
             }
         }
     }
@@ -246,8 +256,8 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
 
     TileLoader<BM, AK, VEC> la;
     TileLoader<BN, BKD, VEC> lb;
-    la.init(p.A, Ap, m0, p.M);
-    lb.init(p.B, Bp, n0, p.N);
+    la.init(p.A, Ap, m0, p.M, z1);
+    lb.init(p.B, Bp, n0, p.N, z1);
 
     v16f acc[TM][TN];
 #pragma unroll
@@ -263,8 +273,10 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     const int r = lane & 31, h = lane >> 5;
 
     if (kbeg < kend) {
-        la.load(p.A, Ap, kbeg, kend);
-        lb.load(p.B, Bp, kbeg, kend);
+        la.issue(p.A, Ap, kbeg, kend, z1);
+        lb.issue(p.B, Bp, kbeg, kend, z1);
+        la.finish(p.A);
+        lb.finish(p.B);
         la.store(As);
         lb.store(Bs);
     }
@@ -272,8 +284,8 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = (k0 + BK) < kend;
         if (more) {
-            la.load(p.A, Ap, k0 + BK, kend);
-            lb.load(p.B, Bp, k0 + BK, kend);
+            la.issue(p.A, Ap, k0 + BK, kend, z1);
+            lb.issue(p.B, Bp, k0 + BK, kend, z1);
         }
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
@@ -306,6 +318,8 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         }
         __syncthreads();
         if (more) {
+            la.finish(p.A);
+            lb.finish(p.B);
             la.store(As);
             lb.store(Bs);
             __syncthreads();

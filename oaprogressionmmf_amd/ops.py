@@ -27,12 +27,12 @@ def _prof_begin():
     return e
 
 
-def _prof_end(e0, family, flops):
+def _prof_end(e0, family, flops, tag=""):
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    PROFILE.append((family, flops, e0, e1))
+    PROFILE.append((family, flops, e0, e1, tag))
 
 
 def _ptr(t):
@@ -73,7 +73,7 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     e0 = _prof_begin()
     check(L.koaf_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
                             _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _stream()), "conv2d_fwd")
-    _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin)
+    _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin, f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}")
     if stats:
         assert rows.value == part.shape[0], (rows.value, part.shape)
     return y, part
@@ -85,7 +85,8 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None):
     e0 = _prof_begin()
     check(L.koaf_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(residual),
                               _stream()), "conv2d_dgrad")
-    _prof_end(e0, "gemm", 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin)
+    _prof_end(e0, "gemm", 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin,
+              f"conv_dgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}")
     return dx
 
 
@@ -97,7 +98,8 @@ def conv2d_wgrad(dy, x, dw, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None,
     e0 = _prof_begin()
     check(L.koaf_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
                               _ptr(in_sh), _ptr(slabs), _stream()), "conv2d_wgrad")
-    _prof_end(e0, "gemm", 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin)
+    _prof_end(e0, "gemm", 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin,
+              f"conv_wgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}")
     return dw
 
 
@@ -122,7 +124,7 @@ def gconv3x3_fwd(x, wexp, N, H, W, C, stride, in_sc=None, in_sh=None, stats=Fals
     e0 = _prof_begin()
     check(L.koaf_gconv3x3_fwd(_ptr(x), _ptr(wexp), _ptr(y), N, H, W, C, stride, _ptr(in_sc), _ptr(in_sh), _ptr(part),
                               ctypes.addressof(rows), _stream()), "gconv3x3_fwd")
-    _prof_end(e0, "gemm", 2.0 * N * OH * OW * C * 9 * (C // 32))   # algorithmic (32 groups), not the slab flops
+    _prof_end(e0, "gemm", 2.0 * N * OH * OW * C * 9 * (C // 32), f"gconv_fwd s{stride} C{C} px{N*OH*OW}")   # algorithmic (32 groups)
     return y, part
 
 
@@ -130,7 +132,8 @@ def gconv3x3_dgrad(dy, wexp, N, H, W, C, stride):
     dx = _empty((N, H, W, C), dy)
     e0 = _prof_begin()
     check(lib().koaf_gconv3x3_dgrad(_ptr(dy), _ptr(wexp), _ptr(dx), N, H, W, C, stride, _stream()), "gconv3x3_dgrad")
-    _prof_end(e0, "gemm", 2.0 * N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C * 9 * (C // 32))
+    _prof_end(e0, "gemm", 2.0 * N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C * 9 * (C // 32),
+              f"gconv_dgrad s{stride} C{C} px{N*H*W}")
     return dx
 
 
@@ -142,7 +145,8 @@ def gconv3x3_wgrad(dy, x, N, H, W, C, stride, in_sc=None, in_sh=None):
     e0 = _prof_begin()
     check(L.koaf_gconv3x3_wgrad(_ptr(dy), _ptr(x), _ptr(dwexp), N, H, W, C, stride, _ptr(in_sc), _ptr(in_sh),
                                 _ptr(slabs), _stream()), "gconv3x3_wgrad")
-    _prof_end(e0, "gemm", 2.0 * N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C * 9 * (C // 32))
+    _prof_end(e0, "gemm", 2.0 * N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C * 9 * (C // 32),
+              f"gconv_wgrad s{stride} C{C} px{N*H*W}")
     return dwexp
 
 
@@ -268,7 +272,7 @@ def linear_fwd(x, w, b, M, N, K, residual=None):
     y = _empty((M, N), x)
     e0 = _prof_begin()
     check(lib().koaf_linear_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(residual), _ptr(y), M, N, K, _stream()), "linear_fwd")
-    _prof_end(e0, "gemm", 2.0 * M * N * K)
+    _prof_end(e0, "gemm", 2.0 * M * N * K, f"linear_fwd M{M} N{N} K{K}")
     return y
 
 
@@ -276,7 +280,7 @@ def linear_dgrad(dy, w, M, N, K, residual=None):
     dx = _empty((M, K), dy)
     e0 = _prof_begin()
     check(lib().koaf_linear_dgrad(_ptr(dy), _ptr(w), _ptr(residual), _ptr(dx), M, N, K, _stream()), "linear_dgrad")
-    _prof_end(e0, "gemm", 2.0 * M * N * K)
+    _prof_end(e0, "gemm", 2.0 * M * N * K, f"linear_dgrad M{M} N{N} K{K}")
     return dx
 
 
@@ -288,7 +292,7 @@ def linear_wgrad(dy, x, dw, db, M, N, K):
         ws = _empty((n,), dy) if n > 0 else None
     e0 = _prof_begin()
     check(L.koaf_linear_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(ws), M, N, K, _stream()), "linear_wgrad")
-    _prof_end(e0, "gemm", 2.0 * M * N * K)
+    _prof_end(e0, "gemm", 2.0 * M * N * K, f"linear_wgrad M{M} N{N} K{K}")
 
 
 def layernorm_fwd(x, gamma, beta, rows, D, eps):
@@ -314,7 +318,7 @@ def attention_fwd(qkv, B, n, h, d, scale):
     out = _empty((B, n, h * d), qkv)
     e0 = _prof_begin()
     check(lib().koaf_attention_fwd(_ptr(qkv), _ptr(attn), _ptr(out), B, n, h, d, scale, _stream()), "attention_fwd")
-    _prof_end(e0, "gemm", 4.0 * B * h * n * n * d)
+    _prof_end(e0, "gemm", 4.0 * B * h * n * n * d, f"attn_fwd B{B} n{n}")
     return out, attn
 
 
@@ -324,7 +328,7 @@ def attention_bwd(dout, qkv, attn, B, n, h, d, scale):
     e0 = _prof_begin()
     check(lib().koaf_attention_bwd(_ptr(dout), _ptr(qkv), _ptr(attn), _ptr(dqkv), _ptr(ws), B, n, h, d, scale,
                                    _stream()), "attention_bwd")
-    _prof_end(e0, "gemm", 8.0 * B * h * n * n * d)
+    _prof_end(e0, "gemm", 8.0 * B * h * n * n * d, f"attn_bwd B{B} n{n}")
     return dqkv
 
 
