@@ -20,9 +20,21 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
 
-template <int ROWS, int KIND, bool VEC>
+// operand access modes (compile-time: the loaders are straight-line code, so hipcc can schedule their
+// address arithmetic into the shadows of the 64-cycle fp32 MFMAs)
+enum { M_KC = 0,     // K-contiguous rows, dense
+       M_KC_G1 = 1,  // K-contiguous, conv forward gather (NHWC source)
+       M_KC_G2 = 2,  // K-contiguous, transposed-conv (dgrad) gather
+       M_KM = 3,     // K-major, dense
+       M_KM_G1 = 4,  // K-major, conv gather on the k index (wgrad activations)
+       M_KM_G3 = 5   // K-major, tapped weights (dgrad)
+};
+__host__ __device__ constexpr bool mode_is_kc(int m) { return m < 3; }
+
+template <int ROWS, int MODE, bool TF, bool VEC>
 struct TileLoader {
     static constexpr int NU = ROWS / 32;
+    static constexpr bool KC = mode_is_kc(MODE);
     v4f r[NU];
     unsigned vm;       // validity bits of the tile in flight: VEC 1 bit / unit, else 4 bits / unit
     v4f ts4, th4;      // transform coefficients of the tile in flight (KC) / of this thread's columns (KM)
@@ -35,28 +47,29 @@ struct TileLoader {
     int col, cc, kh_, kw_;
     unsigned cvm;      // column-valid bits
 
-    __device__ __forceinline__ void init(const KoafOperand& op, const float* ptr, int r0, int R, int z1) {
+    __device__ __forceinline__ void init(const KoafOperand& op, int r0, int R, int z1) {
         const int t = threadIdx.x;
         vm = 0;
         ts4 = th4 = (v4f){0.f, 0.f, 0.f, 0.f};
-        if constexpr (KIND == 0) {
-            rvm = 0;
-            base = (v4l){0, 0, 0, 0};
-            iy0 = ix0 = (v4i){0, 0, 0, 0};
+        rvm = cvm = 0;
+        base = (v4l){0, 0, 0, 0};
+        iy0 = ix0 = (v4i){0, 0, 0, 0};
+        col = cc = kh_ = kw_ = 0;
+        if constexpr (KC) {
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
-                int row = r0 + (t >> 3) + 32 * i;
+                const int row = r0 + (t >> 3) + 32 * i;
                 rvm |= (row < R ? 1u : 0u) << i;
-                if (op.gather == 0) {
-                    base[i] = (int64_t)row * op.ld;
+                if constexpr (MODE == M_KC) {
+                    base[i] = (int64_t)row * op.ld + 4 * (t & 7);
                 } else {
-                    int ppi = op.PH * op.PW;
-                    int n = row / ppi;
-                    int rem = row - n * ppi;
-                    int py = rem / op.PW;
-                    int px = rem - py * op.PW;
-                    base[i] = (int64_t)n * op.H * op.W * op.CS;
-                    if (op.gather == 1) {
+                    const int ppi = op.PH * op.PW;
+                    const int n = row / ppi;
+                    const int rem = row - n * ppi;
+                    const int py = rem / op.PW;
+                    const int px = rem - py * op.PW;
+                    base[i] = (int64_t)n * op.H * op.W * op.CS + 4 * (t & 7);
+                    if constexpr (MODE == M_KC_G1) {
                         iy0[i] = py * op.stride - op.pad;
                         ix0[i] = px * op.stride - op.pad;
                     } else {
@@ -68,18 +81,16 @@ struct TileLoader {
         } else {
             constexpr int CV = ROWS / 4;
             col = r0 + 4 * (t % CV);
-            cvm = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) cvm |= ((col + j) < R ? 1u : 0u) << j;
             cc = col;
-            kh_ = kw_ = 0;
-            if (op.gather == 1) {
-                int tap = r0 / op.C;
+            if constexpr (MODE == M_KM_G1) {
+                const int tap = r0 / op.C;
                 cc = col - tap * op.C;
                 kh_ = tap / op.KW;
                 kw_ = tap - kh_ * op.KW;
             }
-            if (op.tf) {
+            if constexpr (TF) {
                 const float* sc = op.sc + z1 * op.tf_bs;
                 const float* sh = op.sh + z1 * op.tf_bs;
                 if (VEC) {
@@ -93,29 +104,28 @@ struct TileLoader {
         }
     }
 
-    // Issue the global loads of the k-tile [k0, k0+32) -- nothing here consumes a loaded value, so the
-    // s_waitcnt lands in finish(), i.e. after the MFMAs of the tile currently in LDS.
+    // Issue the global loads of the k-tile [k0, k0+32): nothing here consumes a loaded value, so the
+    // s_waitcnt lands in finish(), after the MFMAs of the tile currently in LDS.
     __device__ __forceinline__ void issue(const KoafOperand& op, const float* ptr, int k0, int kend, int z1) {
         const int t = threadIdx.x;
         vm = 0;
-        if constexpr (KIND == 0) {
-            const int kv = t & 7;
-            const int kk = k0 + 4 * kv;
-            int ch = kk;
-            int kh = 0, kw = 0;
-            if (op.gather != 0) {
-                // conv gather: a 32-wide k chunk lies inside one filter tap (C % 32 == 0)
+        if constexpr (KC) {
+            const int kk = k0 + 4 * (t & 7);
+            const bool kok = kk < kend;
+            int ch = kk, kh = 0, kw = 0, coff = k0;
+            if constexpr (MODE != M_KC) {
+                // a 32-wide k chunk lies inside one filter tap (C % 32 == 0)
                 const int tap = k0 / op.C;
-                const int c0 = k0 - tap * op.C;
+                coff = k0 - tap * op.C;
                 kh = tap / op.KW;
                 kw = tap - kh * op.KW;
-                ch = c0 + 4 * kv;
+                ch = coff + 4 * (t & 7);
             }
-            if (op.tf) {
+            if constexpr (TF) {
                 const float* sc = op.sc + z1 * op.tf_bs;
                 const float* sh = op.sh + z1 * op.tf_bs;
                 if (VEC) {
-                    const int c = (kk < kend) ? ch : 0;
+                    const int c = kok ? ch : 0;
                     ts4 = *(const v4f*)(sc + c);
                     th4 = *(const v4f*)(sh + c);
                 } else {
@@ -129,34 +139,45 @@ struct TileLoader {
             }
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
-                if (op.gather == 0) {
+                const bool rok = (rvm >> i) & 1u;
+                if constexpr (MODE == M_KC) {
                     if (VEC) {
-                        const bool ok = ((rvm >> i) & 1u) && kk < kend;
-                        r[i] = *(const v4f*)(ok ? ptr + base[i] + kk : ptr);
+                        const bool ok = rok && kok;
+                        r[i] = *(const v4f*)(ptr + (ok ? base[i] + k0 : 0));
                         vm |= (ok ? 1u : 0u) << i;
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const bool ok = ((rvm >> i) & 1u) && (kk + j) < kend;
-                            r[i][j] = *(ok ? ptr + base[i] + kk + j : ptr);
+                            const bool ok = rok && (kk + j) < kend;
+                            r[i][j] = ptr[ok ? base[i] + k0 + j : 0];
                             vm |= (ok ? 1u : 0u) << (4 * i + j);
                         }
                     }
                 } else {
                     int sy, sx;
-                    bool ok = ((rvm >> i) & 1u) && kk < kend;
-                    if (op.gather == 1) {
+                    bool ok = rok && kok;
+                    if constexpr (MODE == M_KC_G1) {
                         sy = iy0[i] + kh;
                         sx = ix0[i] + kw;
                     } else {
-                        int ny = iy0[i] - kh, nx = ix0[i] - kw;
+                        const int ny = iy0[i] - kh, nx = ix0[i] - kw;
                         ok = ok && ny >= 0 && nx >= 0;
-                        sy = ny / op.stride;
-                        sx = nx / op.stride;
-                        ok = ok && (sy * op.stride == ny) && (sx * op.stride == nx);
+                        if (op.stride == 1) {
+                            sy = ny;
+                            sx = nx;
+                        } else if (op.stride == 2) {
+                            sy = ny >> 1;
+                            sx = nx >> 1;
+                            ok = ok && (((ny | nx) & 1) == 0);
+                        } else {
+                            sy = ny / op.stride;
+                            sx = nx / op.stride;
+                            ok = ok && (sy * op.stride == ny) && (sx * op.stride == nx);
+                        }
                     }
                     ok = ok && (unsigned)sy < (unsigned)op.H && (unsigned)sx < (unsigned)op.W;
-                    r[i] = *(const v4f*)(ok ? ptr + base[i] + ((int64_t)(sy * op.W + sx) * op.CS + ch) : ptr);
+                    const int off = (sy * op.W + sx) * op.CS + coff;   // per-image offset fits 32 bits
+                    r[i] = *(const v4f*)(ptr + (ok ? base[i] + off : 0));
                     vm |= (ok ? 1u : 0u) << i;
                 }
             }
@@ -165,37 +186,37 @@ struct TileLoader {
             constexpr int RP = 256 / CV;
             const int kr0 = t / CV;
             int tap3 = 0, c03 = 0;
-            if (op.gather == 3) { tap3 = k0 / op.C; c03 = k0 - tap3 * op.C; }
+            if constexpr (MODE == M_KM_G3) { tap3 = k0 / op.C; c03 = k0 - tap3 * op.C; }
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 const int k = k0 + kr0 + RP * i;
                 bool ok = k < kend;
-                const float* src;
-                if (op.gather == 0) {
-                    src = ptr + (int64_t)k * op.ld + col;
-                } else if (op.gather == 3) {
+                int64_t off;
+                if constexpr (MODE == M_KM) {
+                    off = (int64_t)k * op.ld + col;
+                } else if constexpr (MODE == M_KM_G3) {
                     // tapped weights: k = (tap, ck); element at ck*ld + tap*tap_stride + col
-                    src = ptr + (int64_t)(c03 + kr0 + RP * i) * op.ld + (int64_t)tap3 * op.tap_stride + col;
+                    off = (int64_t)(c03 + kr0 + RP * i) * op.ld + (int64_t)tap3 * op.tap_stride + col;
                 } else {
-                    int ppi = op.PH * op.PW;
-                    int n = k / ppi;
-                    int rem = k - n * ppi;
-                    int py = rem / op.PW;
-                    int px = rem - py * op.PW;
-                    int sy = py * op.stride - op.pad + kh_;
-                    int sx = px * op.stride - op.pad + kw_;
+                    const int ppi = op.PH * op.PW;
+                    const int n = k / ppi;
+                    const int rem = k - n * ppi;
+                    const int py = rem / op.PW;
+                    const int px = rem - py * op.PW;
+                    const int sy = py * op.stride - op.pad + kh_;
+                    const int sx = px * op.stride - op.pad + kw_;
                     ok = ok && (unsigned)sy < (unsigned)op.H && (unsigned)sx < (unsigned)op.W;
-                    src = ptr + ((int64_t)(n * op.H + sy) * op.W + sx) * op.CS + cc;
+                    off = ((int64_t)(n * op.H + sy) * op.W + sx) * op.CS + cc;
                 }
                 if (VEC) {
                     ok = ok && (cvm & 1u);
-                    r[i] = *(const v4f*)(ok ? src : ptr);
+                    r[i] = *(const v4f*)(ptr + (ok ? off : 0));
                     vm |= (ok ? 1u : 0u) << i;
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const bool okj = ok && ((cvm >> j) & 1u);
-                        r[i][j] = *(okj ? src + j : ptr);
+                        r[i][j] = ptr[okj ? off + j : 0];
                         vm |= (okj ? 1u : 0u) << (4 * i + j);
                     }
                 }
@@ -204,14 +225,14 @@ struct TileLoader {
     }
 
     // transform + zero-fill of the tile issued by issue(); first consumer of the loaded registers
-    __device__ __forceinline__ void finish(const KoafOperand& op) {
+    __device__ __forceinline__ void finish() {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool ok = VEC ? ((vm >> i) & 1u) : ((vm >> (4 * i + j)) & 1u);
                 float x = r[i][j];
-                if (op.tf) x = fmaxf(x * ts4[j] + th4[j], 0.f);
+                if constexpr (TF) x = fmaxf(x * ts4[j] + th4[j], 0.f);
                 r[i][j] = ok ? x : 0.f;
             }
         }
@@ -219,7 +240,7 @@ struct TileLoader {
 
     __device__ __forceinline__ void store(float* S) const {
         const int t = threadIdx.x;
-        if constexpr (KIND == 0) {
+        if constexpr (KC) {
             const int kv = t & 7;
 #pragma unroll
             for (int i = 0; i < NU; ++i) *(v4f*)&S[((t >> 3) + 32 * i) * LDK + 4 * kv] = r[i];
@@ -232,14 +253,17 @@ struct TileLoader {
     }
 };
 
-template <int BM, int BN, int AK, int BKD, bool VEC>
+template <int BM, int BN, int AM, int BMD, bool TFA, bool TFB, bool VEC>
 __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int A_ELEMS = (AK == 0) ? BM * LDK : BK * BM;
-    constexpr int B_ELEMS = (BKD == 0) ? BN * LDK : BK * BN;
-    __shared__ __attribute__((aligned(16))) float smem[A_ELEMS + B_ELEMS];
-    float* As = smem;
-    float* Bs = smem + A_ELEMS;
+    constexpr bool AKC = mode_is_kc(AM), BKC = mode_is_kc(BMD);
+    constexpr int A_ELEMS = AKC ? BM * LDK : BK * BM;
+    constexpr int B_ELEMS = BKC ? BN * LDK : BK * BN;
+    constexpr int STAGE = A_ELEMS + B_ELEMS;
+    constexpr int LDC_S = BN + 4;                                    // epilogue staging row (floats)
+    constexpr int C_ELEMS = VEC ? BM * LDC_S : 0;
+    constexpr int SMEM = (2 * STAGE > C_ELEMS) ? 2 * STAGE : C_ELEMS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];        // double-buffered operand tiles
 
     const int ntn = (p.N + BN - 1) / BN;
     const int tn = blockIdx.x % ntn;
@@ -254,10 +278,10 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     const float* Ap = p.A.ptr + z0 * p.A.bs0 + z1 * p.A.bs1;
     const float* Bp = p.B.ptr + z0 * p.B.bs0 + z1 * p.B.bs1;
 
-    TileLoader<BM, AK, VEC> la;
-    TileLoader<BN, BKD, VEC> lb;
-    la.init(p.A, Ap, m0, p.M, z1);
-    lb.init(p.B, Bp, n0, p.N, z1);
+    TileLoader<BM, AM, TFA, VEC> la;
+    TileLoader<BN, BMD, TFB, VEC> lb;
+    la.init(p.A, m0, p.M, z1);
+    lb.init(p.B, n0, p.N, z1);
 
     v16f acc[TM][TN];
 #pragma unroll
@@ -275,24 +299,23 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     if (kbeg < kend) {
         la.issue(p.A, Ap, kbeg, kend, z1);
         lb.issue(p.B, Bp, kbeg, kend, z1);
-        la.finish(p.A);
-        lb.finish(p.B);
-        la.store(As);
-        lb.store(Bs);
+        la.finish();
+        lb.finish();
+        la.store(smem);
+        lb.store(smem + A_ELEMS);
     }
     __syncthreads();
+    int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = (k0 + BK) < kend;
-        if (more) {
-            la.issue(p.A, Ap, k0 + BK, kend, z1);
-            lb.issue(p.B, Bp, k0 + BK, kend, z1);
-        }
+        const float* As = smem + cur * STAGE;
+        const float* Bs = As + A_ELEMS;
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
             v4f a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if constexpr (AK == 0) {
+                if constexpr (AKC) {
                     a[i] = *(const v4f*)&As[(wm * WM + 32 * i + r) * LDK + 8 * kg + 4 * h];
                 } else {
 #pragma unroll
@@ -301,7 +324,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
             }
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
-                if constexpr (BKD == 0) {
+                if constexpr (BKC) {
                     b[i] = *(const v4f*)&Bs[(wn * WN + 32 * i + r) * LDK + 8 * kg + 4 * h];
                 } else {
 #pragma unroll
@@ -315,15 +338,20 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
 #pragma unroll
                     for (int jn = 0; jn < TN; ++jn)
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[jn][j], acc[i][jn], 0, 0, 0);
+            // the next tile's global loads go out between the MFMA groups (their address VALU work
+            // executes in the shadow of the MFMAs just issued)
+            if (kg == 0 && more) la.issue(p.A, Ap, k0 + BK, kend, z1);
+            if (kg == 1 && more) lb.issue(p.B, Bp, k0 + BK, kend, z1);
+        }
+        if (more) {
+            float* An = smem + (cur ^ 1) * STAGE;
+            la.finish();
+            lb.finish();
+            la.store(An);
+            lb.store(An + A_ELEMS);
         }
         __syncthreads();
-        if (more) {
-            la.finish(p.A);
-            lb.finish(p.B);
-            la.store(As);
-            lb.store(Bs);
-            __syncthreads();
-        }
+        cur ^= 1;
     }
 
     // ---- epilogue ----
@@ -344,6 +372,41 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) s1[jn] = s2[jn] = 0.f;
 
+    if constexpr (VEC) {
+        // stage the accumulator tile through LDS so global stores (and residual / bias loads) are
+        // 16 B per lane on full 512-B row segments instead of 4 B per lane
+        float* Cs = smem;   // all waves passed the k-loop's last barrier: operand tiles are dead
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = p.alpha * acc[i][jn][e];
+                    s1[jn] += v;
+                    s2[jn] += v * v;
+                    Cs[(wm * WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC_S + wn * WN + 32 * jn + r] = v;
+                }
+        __syncthreads();
+        constexpr int C4 = BN / 4;
+        constexpr int RPP = 256 / C4;          // rows per pass
+        const int c4 = t % C4, rr = t / C4;
+        const int col = n0 + 4 * c4;
+        if (col < p.N) {                         // N % 4 == 0 on this path
+            v4f bv = {0.f, 0.f, 0.f, 0.f};
+            if (bias) bv = *(const v4f*)(bias + col);
+#pragma unroll 4
+            for (int row = rr; row < BM; row += RPP) {
+                const int grow = m0 + row;
+                if (grow < p.M) {
+                    v4f v = *(const v4f*)&Cs[row * LDC_S + 4 * c4] + bv;
+                    if (Rp) v += *(const v4f*)(Rp + (int64_t)grow * p.ldr + col);
+                    *(v4f*)(Cp + (int64_t)grow * ldc + col) = v;
+                }
+            }
+        }
+        if (do_stats) __syncthreads();           // Cs is about to be reused by the statistics reduction
+    } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -364,6 +427,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
                 }
             }
         }
+    }
     }
     if (do_stats) {
         // column sums over this block's BM rows: lanes (r,0)+(r,1), then the two M-waves via LDS
@@ -420,14 +484,31 @@ bool operand_vec_ok(const KoafOperand& o, int R, int K) {
     return true;
 }
 
+int operand_mode(const KoafOperand& o) {
+    if (o.kind == 0) return o.gather == 0 ? M_KC : (o.gather == 1 ? M_KC_G1 : M_KC_G2);
+    return o.gather == 0 ? M_KM : (o.gather == 1 ? M_KM_G1 : M_KM_G3);
+}
+
+#define KOAF_LAUNCH(AMODE, BMODE, TA, TB)                                                                        \
+    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC>), grid, dim3(256), 0, s, g);         \
+    return koaf_check_launch("koaf_gemm")
+
+// the operand-mode pairs the library uses: conv fwd (KC|KC_G1 x KC), dgrad (KC x KM | KC_G2 x KM_G3),
+// wgrad (KM x KM|KM_G1), linear / attention (dense pairs).  tf only where a BatchNorm prologue exists.
 template <int BM, int BN, bool VEC>
-int launch_kinds(const KoafGemm& g, dim3 grid, hipStream_t s) {
-    const int ak = g.A.kind, bk = g.B.kind;
-    if (ak == 0 && bk == 0) hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, 0, 0, VEC>), grid, dim3(256), 0, s, g);
-    else if (ak == 0 && bk == 1) hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, 0, 1, VEC>), grid, dim3(256), 0, s, g);
-    else if (ak == 1 && bk == 0) hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, 1, 0, VEC>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, 1, 1, VEC>), grid, dim3(256), 0, s, g);
-    return koaf_check_launch("koaf_gemm");
+int launch_modes(const KoafGemm& g, dim3 grid, hipStream_t s) {
+    const int am = operand_mode(g.A), bm = operand_mode(g.B);
+    const bool ta = g.A.tf != 0, tb = g.B.tf != 0;
+    if (am == M_KC && bm == M_KC && !tb) { if (ta) { KOAF_LAUNCH(M_KC, M_KC, true, false); } else { KOAF_LAUNCH(M_KC, M_KC, false, false); } }
+    if (am == M_KC && bm == M_KM && !ta && !tb) { KOAF_LAUNCH(M_KC, M_KM, false, false); }
+    if (am == M_KM && bm == M_KM && !ta) { if (tb) { KOAF_LAUNCH(M_KM, M_KM, false, true); } else { KOAF_LAUNCH(M_KM, M_KM, false, false); } }
+    if constexpr (VEC) {
+        if (am == M_KC_G1 && bm == M_KC && !tb) { if (ta) { KOAF_LAUNCH(M_KC_G1, M_KC, true, false); } else { KOAF_LAUNCH(M_KC_G1, M_KC, false, false); } }
+        if (am == M_KC_G2 && bm == M_KM_G3 && !ta && !tb) { KOAF_LAUNCH(M_KC_G2, M_KM_G3, false, false); }
+        if (am == M_KM && bm == M_KM_G1 && !ta) { if (tb) { KOAF_LAUNCH(M_KM, M_KM_G1, false, true); } else { KOAF_LAUNCH(M_KM, M_KM_G1, false, false); } }
+    }
+    koaf_set_error("koaf_gemm: operand mode pair (%d,%d) tf=(%d,%d) is not instantiated", am, bm, (int)ta, (int)tb);
+    return KOAF_EINVAL;
 }
 
 }  // namespace
@@ -473,6 +554,10 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     koaf_gemm_pick_tile(&g, &bm, &bn);
     KOAF_REQUIRE((bm == 64 || bm == 128) && (bn == 64 || bn == 128), "koaf_gemm: tile must be 64|128");
     bool vec = operand_vec_ok(g.A, g.M, g.K) && operand_vec_ok(g.B, g.N, g.K);
+    // vector epilogue: 16-B aligned rows of C / residual / bias
+    if ((g.N & 3) || !aligned16(g.C) || (g.ldc & 3) || (g.cbs0 & 3) || (g.cbs1 & 3)) vec = false;
+    if (g.residual && (!aligned16(g.residual) || (g.ldr & 3) || (g.rbs0 & 3) || (g.rbs1 & 3))) vec = false;
+    if (g.bias && !aligned16(g.bias)) vec = false;
     if (g.A.gather || g.B.gather) KOAF_REQUIRE(vec, "koaf_gemm: gathered operands need aligned, C%%32==0 tensors");
     if (g.B.kind == 1 && g.B.gather == 1)
         KOAF_REQUIRE(g.B.C % bn == 0, "koaf_gemm: wgrad tile (%d) must divide channels per tap (%d)", bn, g.B.C);
@@ -483,11 +568,11 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     KOAF_REQUIRE(tiles < (1ll << 31), "koaf_gemm: grid too large");
     dim3 grid((unsigned)tiles, (unsigned)g.splitk, (unsigned)(g.nb0 * g.nb1));
     hipStream_t s = (hipStream_t)stream;
-    if (!vec) return launch_kinds<64, 64, false>(g, grid, s);
-    if (bm == 128 && bn == 128) return launch_kinds<128, 128, true>(g, grid, s);
-    if (bm == 128 && bn == 64) return launch_kinds<128, 64, true>(g, grid, s);
-    if (bm == 64 && bn == 128) return launch_kinds<64, 128, true>(g, grid, s);
-    return launch_kinds<64, 64, true>(g, grid, s);
+    if (!vec) return launch_modes<64, 64, false>(g, grid, s);
+    if (bm == 128 && bn == 128) return launch_modes<128, 128, true>(g, grid, s);
+    if (bm == 128 && bn == 64) return launch_modes<128, 64, true>(g, grid, s);
+    if (bm == 64 && bn == 128) return launch_modes<64, 128, true>(g, grid, s);
+    return launch_modes<64, 64, true>(g, grid, s);
 }
 
 extern "C" int koaf_slab_reduce(const float* slabs, int32_t nslab, int64_t n, float* out, void* stream) {
