@@ -41,14 +41,17 @@ typedef struct KoafOperand {
     const float* ptr;
     int64_t ld;       /* KC: stride between rows; KM: stride between k-rows */
     int64_t bs0, bs1; /* batch strides (elements) for batch index z = z0*nb1 + z1 */
-    int64_t tap_stride; /* gather 3 (K-major weights [C][taps][rows]): offset between filter taps */
+    int64_t tap_stride;   /* gather 3 (K-major weights [C][taps][rows]): offset between taps in a tap row */
+    int64_t tap_stride_h; /* gather 3: offset between tap rows; tap index = th*KW + tw */
     int32_t kind;     /* 0 = KC, 1 = KM */
     int32_t gather;   /* 0 none; 1 conv forward gather; 2 transposed-conv (dgrad) gather;
                          3 (KM only) tapped weights: k = (tap, c), element at c*ld + tap*tap_stride + r */
     int32_t H, W, C;  /* source NHWC tensor dims for a gathered operand (C = channels per tap) */
     int32_t CS;       /* channels per source pixel (0 = C); > C when the GEMM sees a channel slab */
     int32_t PH, PW;   /* pixel grid the GEMM rows (KC) or the k index (KM) enumerate: (n,py,px) */
-    int32_t KH, KW, stride, pad;
+    int32_t KH, KW, stride, pad; /* pad = row (y) padding */
+    int32_t pad_w;               /* column (x) padding (set = pad for square padding) */
+    int32_t _pad1;
     int32_t tf;       /* 0 none; 1 relu(sc[c]*x + sh[c]) on load (c = source channel) */
     int32_t tf_bs;    /* channel offset of sc/sh per batch index z1 (grouped-conv slabs) */
     const float* sc;
@@ -71,6 +74,9 @@ typedef struct KoafGemm {
     float* stats;          /* [ceil(M/bm)][2][stats_ld] per-M-tile column sum / sum of squares, or NULL */
     int64_t stats_ld;      /* 0 = N */
     int64_t stats_bs;      /* column offset per batch index (grouped conv slabs) */
+    /* output row map (stride-2 dgrad parity classes): GEMM row (n, y', x') over a cm_PH x cm_PW grid is
+       written to pixel row (n*cm_H + 2y'+cm_py)*cm_W + 2x'+cm_px of C / residual.  cmap = 0: identity. */
+    int32_t cmap, cm_PH, cm_PW, cm_H, cm_W, cm_py, cm_px, _pad2;
 } KoafGemm;
 
 int koaf_gemm(const KoafGemm* g, void* stream);

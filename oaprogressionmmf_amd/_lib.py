@@ -21,6 +21,7 @@ class KoafOperand(ctypes.Structure):
         ("bs0", ctypes.c_int64),
         ("bs1", ctypes.c_int64),
         ("tap_stride", ctypes.c_int64),
+        ("tap_stride_h", ctypes.c_int64),
         ("kind", ctypes.c_int32),
         ("gather", ctypes.c_int32),
         ("H", ctypes.c_int32),
@@ -33,6 +34,8 @@ class KoafOperand(ctypes.Structure):
         ("KW", ctypes.c_int32),
         ("stride", ctypes.c_int32),
         ("pad", ctypes.c_int32),
+        ("pad_w", ctypes.c_int32),
+        ("_pad1", ctypes.c_int32),
         ("tf", ctypes.c_int32),
         ("tf_bs", ctypes.c_int32),
         ("sc", ctypes.c_void_p),
@@ -66,6 +69,14 @@ class KoafGemm(ctypes.Structure):
         ("stats", ctypes.c_void_p),
         ("stats_ld", ctypes.c_int64),
         ("stats_bs", ctypes.c_int64),
+        ("cmap", ctypes.c_int32),
+        ("cm_PH", ctypes.c_int32),
+        ("cm_PW", ctypes.c_int32),
+        ("cm_H", ctypes.c_int32),
+        ("cm_W", ctypes.c_int32),
+        ("cm_py", ctypes.c_int32),
+        ("cm_px", ctypes.c_int32),
+        ("_pad2", ctypes.c_int32),
     ]
 
 

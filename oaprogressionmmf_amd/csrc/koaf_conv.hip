@@ -225,7 +225,7 @@ extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t
         g.A.gather = 1;
         g.A.H = H; g.A.W = W; g.A.C = Cin; g.A.CS = Cin;
         g.A.PH = OH; g.A.PW = OW;
-        g.A.KH = KH; g.A.KW = KW; g.A.stride = stride; g.A.pad = pad;
+        g.A.KH = KH; g.A.KW = KW; g.A.stride = stride; g.A.pad = pad; g.A.pad_w = pad;
     }
     if (in_sc) { g.A.tf = 1; g.A.sc = in_sc; g.A.sh = in_sh; }
     g.B.ptr = w;
@@ -255,6 +255,35 @@ extern "C" int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int
     const int64_t M = (int64_t)N * H * W;
     KOAF_REQUIRE(M < (1ll << 31), "koaf_conv2d_dgrad: too many pixels");
     KoafGemm g;
+    if (stride == 2) {
+        // Parity decomposition: input pixel (y, x) only sees taps kh = (y+pad) mod 2 (+2, +4, ...), so the four
+        // classes (y%2, x%2) are four stride-1 transposed gathers over their own tap subsets -- 4x less MFMA work
+        // than multiplying the structural zeros of the plain gather.  Each class scatters its rows straight from
+        // the epilogue (row map); a class with no tap (1x1 kernels) just writes residual / zero.
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                const int Hc = (H - py + 1) / 2, Wc = (W - px + 1) / 2;
+                if (Hc <= 0 || Wc <= 0) continue;
+                const int khs = (py + pad) & 1, kws = (px + pad) & 1;
+                const int nkh = khs < KH ? (KH - khs + 1) / 2 : 0, nkw = kws < KW ? (KW - kws + 1) / 2 : 0;
+                const int offy = (py + pad - khs) / 2, offx = (px + pad - kws) / 2;
+                zero_gemm(&g);
+                g.A.ptr = dy; g.A.kind = 0; g.A.gather = 2;
+                g.A.H = OH; g.A.W = OW; g.A.C = Cout; g.A.CS = Cout;
+                g.A.PH = Hc; g.A.PW = Wc;
+                g.A.KH = nkh > 0 ? nkh : 1; g.A.KW = nkw > 0 ? nkw : 1; g.A.stride = 1; g.A.pad = offy; g.A.pad_w = offx;
+                g.B.ptr = w + ((int64_t)khs * KW + kws) * Cin; g.B.kind = 1; g.B.gather = 3;
+                g.B.C = Cout; g.B.ld = (int64_t)KH * KW * Cin;
+                g.B.KW = g.A.KW; g.B.tap_stride = 2ll * Cin; g.B.tap_stride_h = 2ll * KW * Cin;
+                g.M = N * Hc * Wc; g.N = Cin; g.K = nkh * nkw * Cout;
+                g.C = dx; g.ldc = Cin;
+                g.residual = residual; g.ldr = Cin;
+                g.cmap = 1; g.cm_PH = Hc; g.cm_PW = Wc; g.cm_H = H; g.cm_W = W; g.cm_py = py; g.cm_px = px;
+                int rc = koaf_gemm(&g, stream);
+                if (rc != KOAF_OK) return rc;
+            }
+        return KOAF_OK;
+    }
     zero_gemm(&g);
     g.A.ptr = dy;
     g.A.kind = 0;
@@ -269,11 +298,13 @@ extern "C" int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int
         g.A.gather = 2;
         g.A.H = OH; g.A.W = OW; g.A.C = Cout; g.A.CS = Cout;
         g.A.PH = H; g.A.PW = W;
-        g.A.KH = KH; g.A.KW = KW; g.A.stride = stride; g.A.pad = pad;
+        g.A.KH = KH; g.A.KW = KW; g.A.stride = stride; g.A.pad = pad; g.A.pad_w = pad;
         g.B.gather = 3;
         g.B.C = Cout;
         g.B.ld = (int64_t)KH * KW * Cin;
+        g.B.KW = KW;
         g.B.tap_stride = Cin;
+        g.B.tap_stride_h = (int64_t)KW * Cin;
     }
     g.M = (int)M; g.N = Cin; g.K = KH * KW * Cout;
     g.C = dx; g.ldc = Cin;
@@ -310,7 +341,7 @@ extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int
         g.B.gather = 1;
         g.B.H = H; g.B.W = W; g.B.C = Cin; g.B.CS = Cin;
         g.B.PH = OH; g.B.PW = OW;
-        g.B.KH = KH; g.B.KW = KW; g.B.stride = stride; g.B.pad = pad;
+        g.B.KH = KH; g.B.KW = KW; g.B.stride = stride; g.B.pad = pad; g.B.pad_w = pad;
     }
     if (in_sc) { g.B.tf = 1; g.B.sc = in_sc; g.B.sh = in_sh; }
     g.M = Cout; g.N = Ntot; g.K = (int)P;
@@ -350,7 +381,7 @@ extern "C" int koaf_gconv3x3_fwd(const float* x, const float* wexp, float* y, in
     g.nb1 = C / 64;
     g.A.ptr = x; g.A.kind = 0; g.A.gather = 1; g.A.bs1 = 64;
     g.A.H = H; g.A.W = W; g.A.C = 64; g.A.CS = C; g.A.PH = OH; g.A.PW = OW;
-    g.A.KH = 3; g.A.KW = 3; g.A.stride = stride; g.A.pad = 1;
+    g.A.KH = 3; g.A.KW = 3; g.A.stride = stride; g.A.pad = 1; g.A.pad_w = 1;
     if (in_sc) { g.A.tf = 1; g.A.sc = in_sc; g.A.sh = in_sh; }
     g.B.ptr = wexp; g.B.kind = 0; g.B.ld = 576; g.B.bs1 = 64 * 576;
     g.M = (int)M; g.N = 64; g.K = 576;
@@ -373,8 +404,9 @@ extern "C" int koaf_gconv3x3_dgrad(const float* dy, const float* wexp, float* dx
     g.nb1 = C / 64;
     g.A.ptr = dy; g.A.kind = 0; g.A.gather = 2; g.A.bs1 = 64;
     g.A.H = OH; g.A.W = OW; g.A.C = 64; g.A.CS = C; g.A.PH = H; g.A.PW = W;
-    g.A.KH = 3; g.A.KW = 3; g.A.stride = stride; g.A.pad = 1;
+    g.A.KH = 3; g.A.KW = 3; g.A.stride = stride; g.A.pad = 1; g.A.pad_w = 1;
     g.B.ptr = wexp; g.B.kind = 1; g.B.gather = 3; g.B.C = 64; g.B.ld = 576; g.B.tap_stride = 64;
+    g.B.tap_stride_h = 3 * 64; g.B.KW = 3;
     g.B.bs1 = 64 * 576;
     g.M = (int)M; g.N = 64; g.K = 576;
     g.C = dx; g.ldc = C; g.cbs1 = 64;
@@ -404,7 +436,7 @@ extern "C" int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp
         g.A.ptr = dy + 64 * z; g.A.kind = 1; g.A.ld = C;
         g.B.ptr = x + 64 * z; g.B.kind = 1; g.B.gather = 1;
         g.B.H = H; g.B.W = W; g.B.C = 64; g.B.CS = C; g.B.PH = OH; g.B.PW = OW;
-        g.B.KH = 3; g.B.KW = 3; g.B.stride = stride; g.B.pad = 1;
+        g.B.KH = 3; g.B.KW = 3; g.B.stride = stride; g.B.pad = 1; g.B.pad_w = 1;
         if (in_sc) { g.B.tf = 1; g.B.sc = in_sc + 64 * z; g.B.sh = in_sh + 64 * z; }
         g.M = 64; g.N = 576; g.K = (int)P;
         g.bm = 64; g.bn = 64; g.splitk = p.splitk;

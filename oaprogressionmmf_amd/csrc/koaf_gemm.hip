@@ -71,10 +71,10 @@ struct TileLoader {
                     base[i] = (int64_t)n * op.H * op.W * op.CS + 4 * (t & 7);
                     if constexpr (MODE == M_KC_G1) {
                         iy0[i] = py * op.stride - op.pad;
-                        ix0[i] = px * op.stride - op.pad;
+                        ix0[i] = px * op.stride - op.pad_w;
                     } else {
                         iy0[i] = py + op.pad;
-                        ix0[i] = px + op.pad;
+                        ix0[i] = px + op.pad_w;
                     }
                 }
             }
@@ -195,8 +195,9 @@ struct TileLoader {
                 if constexpr (MODE == M_KM) {
                     off = (int64_t)k * op.ld + col;
                 } else if constexpr (MODE == M_KM_G3) {
-                    // tapped weights: k = (tap, ck); element at ck*ld + tap*tap_stride + col
-                    off = (int64_t)(c03 + kr0 + RP * i) * op.ld + (int64_t)tap3 * op.tap_stride + col;
+                    // tapped weights: k = (tap, ck), tap = th*KW + tw; element at ck*ld + th*tap_stride_h + tw*tap_stride + col
+                    const int th3 = tap3 / op.KW, tw3 = tap3 - th3 * op.KW;
+                    off = (int64_t)(c03 + kr0 + RP * i) * op.ld + th3 * op.tap_stride_h + tw3 * op.tap_stride + col;
                 } else {
                     const int ppi = op.PH * op.PW;
                     const int n = k / ppi;
@@ -204,7 +205,7 @@ struct TileLoader {
                     const int py = rem / op.PW;
                     const int px = rem - py * op.PW;
                     const int sy = py * op.stride - op.pad + kh_;
-                    const int sx = px * op.stride - op.pad + kw_;
+                    const int sx = px * op.stride - op.pad_w + kw_;
                     ok = ok && (unsigned)sy < (unsigned)op.H && (unsigned)sx < (unsigned)op.W;
                     off = ((int64_t)(n * op.H + sy) * op.W + sx) * op.CS + cc;
                 }
@@ -399,9 +400,18 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
             for (int row = rr; row < BM; row += RPP) {
                 const int grow = m0 + row;
                 if (grow < p.M) {
+                    int64_t orow = grow;
+                    if (p.cmap) {
+                        const int ppi = p.cm_PH * p.cm_PW;
+                        const int n = grow / ppi;
+                        const int rem = grow - n * ppi;
+                        const int yy = rem / p.cm_PW;
+                        const int xx = rem - yy * p.cm_PW;
+                        orow = ((int64_t)n * p.cm_H + 2 * yy + p.cm_py) * p.cm_W + 2 * xx + p.cm_px;
+                    }
                     v4f v = *(const v4f*)&Cs[row * LDC_S + 4 * c4] + bv;
-                    if (Rp) v += *(const v4f*)(Rp + (int64_t)grow * p.ldr + col);
-                    *(v4f*)(Cp + (int64_t)grow * ldc + col) = v;
+                    if (Rp) v += *(const v4f*)(Rp + orow * p.ldr + col);
+                    *(v4f*)(Cp + orow * ldc + col) = v;
                 }
             }
         }
@@ -477,7 +487,7 @@ bool operand_vec_ok(const KoafOperand& o, int R, int K) {
         if (o.gather && ((o.C & 31) || (o.CS & 3))) return false;
     } else {
         if (R & 3) return false;
-        if (o.gather == 3 && ((o.C & 31) || (o.tap_stride & 3))) return false;
+        if (o.gather == 3 && ((o.C & 31) || (o.tap_stride & 3) || (o.tap_stride_h & 3))) return false;
         if (o.gather == 1 && ((o.C & 3) || (o.CS & 3))) return false;
     }
     if (o.tf && (!aligned16(o.sc) || !aligned16(o.sh))) return false;
@@ -543,6 +553,7 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     if (g.A.CS == 0) g.A.CS = g.A.C;
     if (g.B.CS == 0) g.B.CS = g.B.C;
     if (g.stats_ld == 0) g.stats_ld = g.N;
+    KOAF_REQUIRE(!g.cmap || (g.splitk == 1 && !g.stats), "koaf_gemm: row map excludes split-K / stats");
     KOAF_REQUIRE(g.splitk == 1 || (!g.bias && !g.residual && !g.stats),
                  "koaf_gemm: split-K writes raw slabs (no epilogue)");
     KOAF_REQUIRE((int64_t)g.nb0 * g.nb1 <= 65535 && g.splitk <= 65535, "koaf_gemm: batch/splitk too large");
@@ -558,6 +569,7 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     if ((g.N & 3) || !aligned16(g.C) || (g.ldc & 3) || (g.cbs0 & 3) || (g.cbs1 & 3)) vec = false;
     if (g.residual && (!aligned16(g.residual) || (g.ldr & 3) || (g.rbs0 & 3) || (g.rbs1 & 3))) vec = false;
     if (g.bias && !aligned16(g.bias)) vec = false;
+    KOAF_REQUIRE(!g.cmap || vec, "koaf_gemm: row map needs the vector epilogue");
     if (g.A.gather || g.B.gather) KOAF_REQUIRE(vec, "koaf_gemm: gathered operands need aligned, C%%32==0 tensors");
     if (g.B.kind == 1 && g.B.gather == 1)
         KOAF_REQUIRE(g.B.C % bn == 0, "koaf_gemm: wgrad tile (%d) must divide channels per tap (%d)", bn, g.B.C);
