@@ -19,6 +19,9 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
+#ifndef KOAF_ISSUE_AT
+#define KOAF_ISSUE_AT 0   // 0: next tile's loads go out at the top of the k-step (longest flight time);
+#endif                    // 1: between the MFMA groups
 
 // operand access modes (compile-time: the loaders are straight-line code, so hipcc can schedule their
 // address arithmetic into the shadows of the 64-cycle fp32 MFMAs)
@@ -311,6 +314,10 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         const bool more = (k0 + BK) < kend;
         const float* As = smem + cur * STAGE;
         const float* Bs = As + A_ELEMS;
+        if (KOAF_ISSUE_AT == 0 && more) {
+            la.issue(p.A, Ap, k0 + BK, kend, z1);
+            lb.issue(p.B, Bp, k0 + BK, kend, z1);
+        }
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
             v4f a[TM], b[TN];
@@ -341,8 +348,10 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[jn][j], acc[i][jn], 0, 0, 0);
             // the next tile's global loads go out between the MFMA groups (their address VALU work
             // executes in the shadow of the MFMAs just issued)
-            if (kg == 0 && more) la.issue(p.A, Ap, k0 + BK, kend, z1);
-            if (kg == 1 && more) lb.issue(p.B, Bp, k0 + BK, kend, z1);
+            if (KOAF_ISSUE_AT == 1) {
+                if (kg == 0 && more) la.issue(p.A, Ap, k0 + BK, kend, z1);
+                if (kg == 1 && more) lb.issue(p.B, Bp, k0 + BK, kend, z1);
+            }
         }
         if (more) {
             float* An = smem + (cur ^ 1) * STAGE;
