@@ -94,11 +94,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # KOAF_DIST_BACKEND=gloo + KOAF_ONE_DEVICE=1: rehearsal of the N>1 path with all ranks on one GPU (the
+    # 1-GPU development box has no second device for RCCL); the driver's real runs use nccl (= RCCL).
+    backend = os.environ.get("KOAF_DIST_BACKEND", "nccl")
+    if os.environ.get("KOAF_ONE_DEVICE"):
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)

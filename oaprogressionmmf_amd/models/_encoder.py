@@ -25,6 +25,11 @@ from ..arena import deliver_grad, grad_target, packed_weight
 from ._core_fes import BasicBlock, Bottleneck
 
 
+import os
+
+USE_SIDE_STREAM = os.environ.get("KOAF_SIDE_STREAM", "1") != "0"
+
+
 class _Rec:
     __slots__ = ("kind", "blk", "yin", "c1", "s1", "c2", "s2", "c3", "s3", "cd", "sd", "y", "dims", "wexp")
 
@@ -58,19 +63,56 @@ def _bn_fin(bn, part, count):
                            bn.eps, train)
 
 
-def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True):
+class _SideStream:
+    """Second HIP stream for the weight gradients.  In backward every wgrad GEMM is off the critical path
+    (dgrad -> BatchNorm backward -> next dgrad), so they run here: MFMA-bound wgrad blocks fill the CUs while the
+    main stream runs HBM-bound BatchNorm kernels or the tail of a dgrad.  Gradients are delivered (p.grad /
+    data-parallel hook) only after the main stream has joined this one."""
+    _streams = {}
+
+    def __init__(self, device):
+        key = (device.type, device.index)
+        if key not in _SideStream._streams:
+            _SideStream._streams[key] = torch.cuda.Stream(device=device)
+        self.stream = _SideStream._streams[key]
+        self.pending = []
+
+    def run(self, inputs, fn, param, buf, acc):
+        main = torch.cuda.current_stream()
+        self.stream.wait_stream(main)
+        with torch.cuda.stream(self.stream):
+            fn()
+        for t in inputs:
+            if t is not None:
+                t.record_stream(self.stream)     # the caching allocator must not recycle them under the side stream
+        self.pending.append((param, buf, acc))
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        for param, buf, acc in self.pending:
+            deliver_grad(param, buf, acc)
+        self.pending = []
+
+
+def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True, side=None):
     """weight gradient (x transformed on load by in_saved) and data gradient of one conv."""
     w = packed_weight(conv.weight)
     cin, cout = conv.in_channels, conv.out_channels
     k, s, p, g = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.groups
     sc, sh = (in_saved[2], in_saved[3]) if in_saved is not None else (None, None)
     gw, acc = grad_target(conv.weight)
-    if g == 1:
-        ops.conv2d_wgrad(dc, x, gw, N, H, W, cin, cout, k, k, s, p, sc, sh)
+
+    def wgrad():
+        if g == 1:
+            ops.conv2d_wgrad(dc, x, gw, N, H, W, cin, cout, k, k, s, p, sc, sh)
+        else:
+            dwexp = ops.gconv3x3_wgrad(dc, x, N, H, W, cin, s, sc, sh)
+            ops.gconv_compress_dw(dwexp, gw, cin, g)
+    if side is not None:
+        side.run((dc, x, in_saved), wgrad, conv.weight, gw, acc)
     else:
-        dwexp = ops.gconv3x3_wgrad(dc, x, N, H, W, cin, s, sc, sh)
-        ops.gconv_compress_dw(dwexp, gw, cin, g)
-    deliver_grad(conv.weight, gw, acc)
+        wgrad()
+        deliver_grad(conv.weight, gw, acc)
     if not need_dx:
         return None
     if g == 1:
@@ -167,6 +209,7 @@ class EncoderFn(torch.autograd.Function):
             if dy.data_ptr() == gout.data_ptr():
                 dy = dy.clone()  # masked in place below
         recs = S["recs"]
+        side = _SideStream(gout.device) if USE_SIDE_STREAM else None
         while recs:
             r = recs.pop()
             blk = r.blk
@@ -176,27 +219,27 @@ class EncoderFn(torch.autograd.Function):
                 # tail: dz = dy*[y>0] (in place), BN3
                 dc3 = _bn_bwd(blk.bn3, dy, r.c3, r.s3, rows_o, 1, ymask=r.y, dz_out=dy)
                 dz = dy
-                da2 = _conv_bwd(blk.conv3, dc3, r.c2, N, OH, OW, r.s2, None)
+                da2 = _conv_bwd(blk.conv3, dc3, r.c2, N, OH, OW, r.s2, None, side=side)
                 del dc3
                 dc2 = _bn_bwd(blk.bn2, da2, r.c2, r.s2, rows_o, 2, dc_out=da2)
-                da1 = _conv_bwd(blk.conv2, dc2, r.c1, N, Hi, Wi, r.s1, r.wexp)
+                da1 = _conv_bwd(blk.conv2, dc2, r.c1, N, Hi, Wi, r.s1, r.wexp, side=side)
                 del dc2, da2
                 dc1 = _bn_bwd(blk.bn1, da1, r.c1, r.s1, rows_i, 2, dc_out=da1)
                 first = blk.conv1
             else:
                 dc2 = _bn_bwd(blk.bn2, dy, r.c2, r.s2, rows_o, 1, ymask=r.y, dz_out=dy)
                 dz = dy
-                da1 = _conv_bwd(blk.conv2, dc2, r.c1, N, OH, OW, r.s1, None)
+                da1 = _conv_bwd(blk.conv2, dc2, r.c1, N, OH, OW, r.s1, None, side=side)
                 del dc2
                 dc1 = _bn_bwd(blk.bn1, da1, r.c1, r.s1, rows_o, 2, dc_out=da1)
                 first = blk.conv1
             if blk.downsample is not None:
                 dcd = _bn_bwd(blk.downsample[1], dz, r.cd, r.sd, rows_o, 0, dc_out=dz)
-                t = _conv_bwd(blk.downsample[0], dcd, r.yin, N, Hi, Wi, None, None)
-                dy = _conv_bwd(first, dc1, r.yin, N, Hi, Wi, None, None, residual=t)
+                t = _conv_bwd(blk.downsample[0], dcd, r.yin, N, Hi, Wi, None, None, side=side)
+                dy = _conv_bwd(first, dc1, r.yin, N, Hi, Wi, None, None, residual=t, side=side)
                 del t, dcd
             else:
-                dy = _conv_bwd(first, dc1, r.yin, N, Hi, Wi, None, None, residual=dz)
+                dy = _conv_bwd(first, dc1, r.yin, N, Hi, Wi, None, None, residual=dz, side=side)
             del dc1, da1, dz, r
         # stem: max-pool, BN0, conv1 weight gradient (no data gradient: the input is a leaf)
         conv1, bn1 = st["conv1"], st["bn1"]
@@ -205,6 +248,8 @@ class EncoderFn(torch.autograd.Function):
         gw, acc = grad_target(conv1.weight)
         ops.stem_wgrad(dc0, S["x"], gw, N, H, W)
         deliver_grad(conv1.weight, gw, acc)
+        if side is not None:
+            side.join()
         return None, None, None, None
 
 
