@@ -135,11 +135,12 @@ def main():
         opt.zero_grad()
         logits = ddp(*xs)["main"]
         loss = loss_fn(input=logits.squeeze(1), target=y.long().squeeze(1))
-        lv = loss.item()                      # the reference logs loss.item() every step (:159-163)
         ddp.scale_loss(loss).backward()
         ddp.reduce_gradients()
         opt.step()
-        return lv
+        # the reference logs loss.item() every step (:159-163): same value, read after the backward/optimizer
+        # kernels are enqueued so the host sync does not drain the GPU between forward and backward
+        return loss.item()
 
     def barrier():
         if world > 1:
@@ -160,6 +161,8 @@ def main():
         dt = float(tt.item())
 
     # one extra instrumented step: live event timing of every MFMA-GEMM launch on its launch stream
+    from oaprogressionmmf_amd.models import _encoder
+    _encoder.USE_SIDE_STREAM = False      # serialise: per-kernel durations are not inflated by co-running kernels
     ops.PROFILE = []
     step()
     torch.cuda.synchronize()

@@ -82,7 +82,8 @@ typedef struct KoafGemm {
 int koaf_gemm(const KoafGemm* g, void* stream);
 /* rows of `stats` koaf_gemm will write for (M, bm) -- callers size the buffer with this */
 int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn);
-/* out[i] = sum_s slabs[s][i], i < n  (deterministic split-K combine) */
+/* out[i] = sum_s slabs[s][i], i < n, n % 4 == 0 (deterministic split-K combine).  The slab workspace must
+ * hold (nslab + 16) * n floats: large counts are folded in two levels through the 16 trailing slabs. */
 int koaf_slab_reduce(const float* slabs, int32_t nslab, int64_t n, float* out, void* stream);
 
 /* ---- Convolution (nn.Conv2d, bias-free; _torchvision.py:23-31) as implicit GEMM on NHWC -------

@@ -316,7 +316,7 @@ extern "C" int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t
                                         int32_t KW, int32_t stride, int32_t pad) {
     const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
     WgradPlan p = wgrad_plan(Cout, KH * KW * Cin, (int64_t)N * OH * OW, Cin, 1);
-    return p.splitk > 1 ? (int64_t)p.splitk * Cout * KH * KW * Cin : 0;
+    return p.splitk > 1 ? (int64_t)(p.splitk + 16) * Cout * KH * KW * Cin : 0;   // +16: koaf_slab_reduce level-1 partials
 }
 
 extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int32_t N, int32_t H, int32_t W,
@@ -469,7 +469,7 @@ static inline int stem_wgrad_blocks(int N, int H, int W) {
     return (int)(tiles < 1024 ? tiles : 1024);
 }
 extern "C" int64_t koaf_stem_wgrad_ws(int32_t N, int32_t H, int32_t W) {
-    return (int64_t)stem_wgrad_blocks(N, H, W) * 49 * 64;
+    return (int64_t)(stem_wgrad_blocks(N, H, W) + 16) * 49 * 64;
 }
 extern "C" int koaf_stem_wgrad(const float* dy, const float* x, float* dw1t, int32_t N, int32_t H, int32_t W,
                                float* slabs, void* stream) {

@@ -469,20 +469,24 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     }
 }
 
+// out[i] = sum_s slabs[s][i]: block = 64 float4-columns x 4 slab groups (LDS tree), so small outputs (a 64x64
+// weight gradient split 1024 ways) still spread over many waves instead of 4 blocks doing 1024 serial loads
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int nslab,
                                                           int64_t n, float* __restrict__ out) {
-    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= n) return;
-    if (i + 3 < n && (n & 3) == 0) {
-        v4f a = *(const v4f*)(slabs + i);
-        for (int s = 1; s < nslab; ++s) a += *(const v4f*)(slabs + (int64_t)s * n + i);
-        *(v4f*)(out + i) = a;
-    } else {
-        for (int j = 0; j < 4 && i + j < n; ++j) {
-            float a = slabs[i + j];
-            for (int s = 1; s < nslab; ++s) a += slabs[(int64_t)s * n + i + j];
-            out[i + j] = a;
-        }
+    __shared__ v4f red[4][64];
+    const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
+    const int64_t i = ((int64_t)blockIdx.x * 64 + cx) * 4;
+    const int s_per = (nslab + gridDim.y - 1) / gridDim.y;
+    const int s0 = blockIdx.y * s_per, s1 = min(nslab, s0 + s_per);
+    v4f a = {0.f, 0.f, 0.f, 0.f};
+    if (i < n)
+        for (int s = s0 + gy; s < s1; s += 4) a += *(const v4f*)(slabs + (int64_t)s * n + i);
+    red[gy][cx] = a;
+    __syncthreads();
+    if (gy == 0 && i < n) {
+        a = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+        if (gridDim.y == 1) *(v4f*)(out + i) = a;
+        else *(v4f*)(out + (int64_t)blockIdx.y * n + i) = a;   // second-level slabs
     }
 }
 
@@ -597,10 +601,20 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
 }
 
 extern "C" int koaf_slab_reduce(const float* slabs, int32_t nslab, int64_t n, float* out, void* stream) {
-    KOAF_REQUIRE(slabs && out && nslab >= 1 && n > 0, "koaf_slab_reduce: bad args");
+    KOAF_REQUIRE(slabs && out && nslab >= 1 && n > 0 && (n & 3) == 0, "koaf_slab_reduce: bad args (n %% 4 == 0)");
     KOAF_REQUIRE((((uintptr_t)slabs | (uintptr_t)out) & 15) == 0, "koaf_slab_reduce: unaligned");
-    int64_t blocks = cdiv64(cdiv64(n, 4), 256);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, slabs,
-                       nslab, n, out);
+    const unsigned bx = (unsigned)cdiv64(n / 4, 64);
+    // two-level when one level would leave the chip idle: nslab -> 16 partial slabs written BEHIND the input
+    // slabs (the workspace holds (nslab + 16) * n floats), then 16 -> out
+    hipStream_t s = (hipStream_t)stream;
+    if (nslab >= 64 && bx < 256) {
+        float* part = const_cast<float*>(slabs) + (int64_t)nslab * n;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(bx, 16), dim3(256), 0, s, slabs, nslab, n, part);
+        int rc = koaf_check_launch("koaf_slab_reduce/1");
+        if (rc != KOAF_OK) return rc;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(bx, 1), dim3(256), 0, s, part, 16, n, out);
+        return koaf_check_launch("koaf_slab_reduce/2");
+    }
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(bx, 1), dim3(256), 0, s, slabs, nslab, n, out);
     return koaf_check_launch("koaf_slab_reduce");
 }
