@@ -6,7 +6,7 @@ from .. import functional as KF
 from .. import ops
 from ..arena import get_arena
 from ._core_fes import dict_fes
-from ._encoder import KoafTrunk
+from ._encoder import KoafTrunk, lane_streams
 
 
 def build_trunk(arch, pretrained, with_gap):
@@ -88,3 +88,36 @@ def maybe_restore(model, config, path_weights):
 
 MAPPING_CH = {"resnet18": 512, "resnet34": 512, "resnet50": 2048, "resnext50_32x4d": 2048}
 MAPPING_SPAT = {320: 10, 160: 5, 128: 4, 96: 3, 64: 2, 32: 1, 350: 11, 25: 1}
+
+
+import os
+
+USE_LANES = os.environ.get("KOAF_ENCODER_LANES", "1") != "0"
+
+
+def run_trunks(jobs):
+    """Run independent encoders concurrently, one HIP stream pair ("lane") each.
+    jobs: [(trunk, input, dims_view or None)] -- dims_view None = 2-D radiograph, else the MRI slice fold.
+    The encoders share nothing but read-only inputs, so their ~160 kernels each interleave on the 256 CUs: one
+    lane's HBM-bound BatchNorm kernels and GEMM tails are filled by the other lanes' MFMA blocks.  The caller's
+    stream waits for all lanes before the tokens are consumed; in backward each encoder replays on its lane."""
+    def one(trunk, x, view, lane):
+        xin = fold_slices(x, view) if view is not None else x
+        return trunk(xin, lane=lane)
+    if not USE_LANES or len(jobs) < 2:
+        return [one(t, x, v, None) for t, x, v in jobs]
+    main = torch.cuda.current_stream()
+    ev = main.record_event()
+    outs = []
+    dev = jobs[0][1].device
+    for lane, (trunk, x, view) in enumerate(jobs):
+        s, _ = lane_streams(dev, lane)
+        s.wait_event(ev)
+        with torch.cuda.stream(s):
+            out = one(trunk, x, view, lane)
+        x.record_stream(s)
+        out.record_stream(main)
+        outs.append(out)
+    for lane in range(len(jobs)):
+        main.wait_stream(lane_streams(dev, lane)[0])
+    return outs

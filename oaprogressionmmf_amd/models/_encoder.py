@@ -63,6 +63,37 @@ def _bn_fin(bn, part, count):
                            bn.eps, train)
 
 
+_LANES = {}
+
+
+def lane_streams(device, lane):
+    """(main, side) HIP streams of encoder lane `lane` on `device` (created once)."""
+    key = (device.index, lane)
+    if key not in _LANES:
+        _LANES[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _LANES[key]
+
+
+_JOIN = {"queued": False, "streams": []}
+
+
+def _final_join():
+    """End of the backward pass: the caller's stream waits for every encoder lane that ran."""
+    cur = torch.cuda.current_stream()
+    for st in _JOIN["streams"]:
+        cur.wait_stream(st)
+    _JOIN["streams"] = []
+    _JOIN["queued"] = False
+
+
+def _register_join(stream):
+    _JOIN["streams"].append(stream)
+    if not _JOIN["queued"]:
+        _JOIN["queued"] = True
+        from torch.autograd import Variable
+        Variable._execution_engine.queue_callback(_final_join)
+
+
 class _SideStream:
     """Second HIP stream for the weight gradients.  In backward every wgrad GEMM is off the critical path
     (dgrad -> BatchNorm backward -> next dgrad), so they run here: MFMA-bound wgrad blocks fill the CUs while the
@@ -70,11 +101,13 @@ class _SideStream:
     data-parallel hook) only after the main stream has joined this one."""
     _streams = {}
 
-    def __init__(self, device):
-        key = (device.type, device.index)
-        if key not in _SideStream._streams:
-            _SideStream._streams[key] = torch.cuda.Stream(device=device)
-        self.stream = _SideStream._streams[key]
+    def __init__(self, device, stream=None):
+        if stream is None:
+            key = (device.type, device.index)
+            if key not in _SideStream._streams:
+                _SideStream._streams[key] = torch.cuda.Stream(device=device)
+            stream = _SideStream._streams[key]
+        self.stream = stream
         self.pending = []
 
     def run(self, inputs, fn, param, buf, acc):
@@ -133,7 +166,7 @@ def _bn_bwd(bn, g, c, saved, rows, mask_mode, ymask=None, dz_out=None, dc_out=No
 
 class EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, trunk, anchor, keep):
+    def forward(ctx, x, trunk, anchor, keep, lane):
         st = trunk._koaf_layout()
         if x.dim() == 4:
             if x.shape[1] != 1:
@@ -192,13 +225,30 @@ class EncoderFn(torch.autograd.Function):
             out = y.permute(0, 3, 1, 2)  # (N,C,h,w) view of the NHWC buffer
         if keep:
             ctx.state = dict(x=x, c0=c0, s0=s0, am=am, recs=recs, dims=(N, H, W, H1, W1), last=(Hc, Wc, C),
-                             st=st)
+                             st=st, lane=lane)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         S = ctx.state
         ctx.state = None
+        lane = S["lane"]
+        if lane is None:
+            return EncoderFn._backward_body(S, gout, None)
+        # multi-stream: this encoder's backward runs on its own lane (autograd already switched to the forward
+        # stream and ordered it after the producer of gout); the caller's stream joins at the end of backward()
+        main_s, side_s = lane_streams(gout.device, lane)
+        cur = torch.cuda.current_stream()
+        if cur != main_s:
+            main_s.wait_stream(cur)
+            gout.record_stream(main_s)
+        with torch.cuda.stream(main_s):
+            out = EncoderFn._backward_body(S, gout, side_s)
+        _register_join(main_s)
+        return out
+
+    @staticmethod
+    def _backward_body(S, gout, side_stream):
         st = S["st"]
         N, H, W, H1, W1 = S["dims"]
         Hc, Wc, C = S["last"]
@@ -209,7 +259,7 @@ class EncoderFn(torch.autograd.Function):
             if dy.data_ptr() == gout.data_ptr():
                 dy = dy.clone()  # masked in place below
         recs = S["recs"]
-        side = _SideStream(gout.device) if USE_SIDE_STREAM else None
+        side = _SideStream(gout.device, side_stream) if USE_SIDE_STREAM else None
         while recs:
             r = recs.pop()
             blk = r.blk
@@ -250,7 +300,7 @@ class EncoderFn(torch.autograd.Function):
         deliver_grad(conv1.weight, gw, acc)
         if side is not None:
             side.join()
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 class KoafTrunk(nn.Sequential):
@@ -284,9 +334,9 @@ class KoafTrunk(nn.Sequential):
         self.__dict__["_koaf_lay"] = lay
         return lay
 
-    def forward(self, x):
+    def forward(self, x, lane=None):
         lay = self._koaf_layout()
         anchor = lay["conv1"].weight
         # autograd runs Function.forward with grad mode off, so decide here whether backward can happen
         keep = torch.is_grad_enabled() and anchor.requires_grad
-        return EncoderFn.apply(x, self, anchor, keep)
+        return EncoderFn.apply(x, self, anchor, keep, lane)

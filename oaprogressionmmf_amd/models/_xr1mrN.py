@@ -60,8 +60,9 @@ class XR1MR1CnnTrf(nn.Module):
         """input0 : (B,1,R,C); input1 : (B,1,R,C,S)"""
         C.adopt(self, input0, input1)
         B = input0.shape[0]
-        t_fe0 = C.tokens(self._fe0_drop(self._fe0(input0)), B)
-        t_fe1 = C.tokens(self._fe1_drop(self._fe1(C.fold_slices(input1))), B)
+        f1, f0 = C.run_trunks([(self._fe1, input1, "rc"), (self._fe0, input0, None)])
+        t_fe0 = C.tokens(self._fe0_drop(f0), B)
+        t_fe1 = C.tokens(self._fe1_drop(f1), B)
         res_agg, _, _ = self._agg(torch.cat([t_fe0, t_fe1], dim=1))
         return C.finish(self.config, res_agg.reshape(B, -1))
 
@@ -113,9 +114,10 @@ class XR1MR2CnnTrf(nn.Module):
     def forward(self, input0, input1, input2):
         C.adopt(self, input0, input1, input2)
         B = input0.shape[0]
-        t_fe0 = C.tokens(self._fe0_drop(self._fe0(input0)), B)
-        t_fe1 = C.tokens(self._fe1_drop(self._fe1(C.fold_slices(input1))), B)
-        t_fe2 = C.tokens(self._fe2_drop(self._fe2(C.fold_slices(input2))), B)
+        f1, f2, f0 = C.run_trunks([(self._fe1, input1, "rc"), (self._fe2, input2, "rc"), (self._fe0, input0, None)])
+        t_fe0 = C.tokens(self._fe0_drop(f0), B)
+        t_fe1 = C.tokens(self._fe1_drop(f1), B)
+        t_fe2 = C.tokens(self._fe2_drop(f2), B)
         # Q4: the reference runs mlp_head0 of the cls-less aggregators and discards it
         _, res_agg1, _ = self._agg_1(t_fe1)
         _, res_agg2, _ = self._agg_2(t_fe2)

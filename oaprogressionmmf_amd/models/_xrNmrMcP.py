@@ -81,9 +81,11 @@ class XR1MR2C1CnnTrf(nn.Module):
         """input0 (B,1,R,C) radiograph; input1, input2 (B,1,R,C,S) MRI volumes; input3 (B,1,F) clinical"""
         C.adopt(self, input0, input1, input2, input3)
         B = input0.shape[0]
-        t_fe0 = C.tokens(self._fe0_drop(self._fe0(input0)), B)
-        t_fe1 = C.tokens(self._fe1_drop(self._fe1(C.fold_slices(input1))), B)
-        t_fe2 = C.tokens(self._fe2_drop(self._fe2(C.fold_slices(input2))), B)
+        # largest encoder first so the short ones fill its tails
+        f1, f2, f0 = C.run_trunks([(self._fe1, input1, "rc"), (self._fe2, input2, "rc"), (self._fe0, input0, None)])
+        t_fe0 = C.tokens(self._fe0_drop(f0), B)
+        t_fe1 = C.tokens(self._fe1_drop(f1), B)
+        t_fe2 = C.tokens(self._fe2_drop(f2), B)
         t_fe3 = self._fe3_drop(self._fe3(input3))
         _, res_agg1, _ = self._agg_1(t_fe1)
         _, res_agg2, _ = self._agg_2(t_fe2)
