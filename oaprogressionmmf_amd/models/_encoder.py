@@ -70,8 +70,22 @@ def lane_streams(device, lane):
     """(main, side) HIP streams of encoder lane `lane` on `device` (created once)."""
     key = (device.index, lane)
     if key not in _LANES:
-        _LANES[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        # critical path (forward chain, dgrad -> BatchNorm backward) on a HIGH priority stream, the weight
+        # gradients on a LOW priority one: wgrad blocks are dispatched only into what the critical path leaves
+        # free, so they trail behind and fill the HBM-bound BatchNorm phases and GEMM tails
+        hi, lo = _priorities()
+        _LANES[key] = (torch.cuda.Stream(device=device, priority=hi), torch.cuda.Stream(device=device, priority=lo))
     return _LANES[key]
+
+
+def _priorities():
+    try:
+        lo, hi = torch.cuda.Stream.priority_range()   # (least, greatest); numerically lower = higher priority
+    except Exception:  # noqa: BLE001
+        lo, hi = 0, -1
+    if os.environ.get("KOAF_STREAM_PRIORITY", "0") == "0":   # measured: 2 levels only; prioritising hurts (163 vs 145 ms)
+        return 0, 0
+    return hi, lo
 
 
 _JOIN = {"queued": False, "streams": []}
@@ -105,7 +119,7 @@ class _SideStream:
         if stream is None:
             key = (device.type, device.index)
             if key not in _SideStream._streams:
-                _SideStream._streams[key] = torch.cuda.Stream(device=device)
+                _SideStream._streams[key] = torch.cuda.Stream(device=device, priority=_priorities()[1])
             stream = _SideStream._streams[key]
         self.stream = stream
         self.pending = []
@@ -141,17 +155,21 @@ def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True,
         else:
             dwexp = ops.gconv3x3_wgrad(dc, x, N, H, W, cin, s, sc, sh)
             ops.gconv_compress_dw(dwexp, gw, cin, g)
-    if side is not None:
-        side.run((dc, x, in_saved), wgrad, conv.weight, gw, acc)
-    else:
+    if side is None:
         wgrad()
         deliver_grad(conv.weight, gw, acc)
-    if not need_dx:
-        return None
-    if g == 1:
-        return ops.conv2d_dgrad(dc, w, N, H, W, cin, cout, k, k, s, p, residual=residual)
-    assert residual is None
-    return ops.gconv3x3_dgrad(dc, wexp, N, H, W, cin, s)
+    dx = None
+    if need_dx:
+        if g == 1:
+            dx = ops.conv2d_dgrad(dc, w, N, H, W, cin, cout, k, k, s, p, residual=residual)
+        else:
+            assert residual is None
+            dx = ops.gconv3x3_dgrad(dc, wexp, N, H, W, cin, s)
+    if side is not None:
+        # enqueued BEHIND the sibling dgrad: the side stream starts this wgrad when the dgrad is done, so it
+        # overlaps the HBM-bound BatchNorm backward of the next layer instead of fighting the dgrad for MFMAs
+        side.run((dc, x, in_saved), wgrad, conv.weight, gw, acc)
+    return dx
 
 
 def _bn_bwd(bn, g, c, saved, rows, mask_mode, ymask=None, dz_out=None, dc_out=None):

@@ -1,0 +1,33 @@
+"""how long does the host need to ENQUEUE one train step (vs the GPU time of the step)?"""
+import sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import torch
+import procedural as P
+from oaprogressionmmf_amd.config import ConfigDict
+from oaprogressionmmf_amd.models import dict_models
+from oaprogressionmmf_amd.various import dict_losses, dict_optimizers
+dev = torch.device("cuda:0")
+cfg = P.cfg_full(dropout=0.1); B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+model = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None).to(dev).train()
+loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
+opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4)
+xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(cfg, B)]
+y = torch.from_numpy(P.make_target("target", B)).to(dev)
+def step():
+    t0 = time.perf_counter()
+    opt.zero_grad()
+    logits = model(*xs)["main"]
+    loss = loss_fn(input=logits.squeeze(1), target=y.long().squeeze(1))
+    t1 = time.perf_counter()
+    loss.backward()
+    t2 = time.perf_counter()
+    opt.step()
+    t3 = time.perf_counter()
+    torch.cuda.synchronize()
+    t4 = time.perf_counter()
+    return t1 - t0, t2 - t1, t3 - t2, t4 - t0
+for i in range(6):
+    f, b, o, tot = step()
+    print(f"B={B} host enqueue: fwd {f*1e3:6.1f} ms  bwd {b*1e3:6.1f} ms  opt {o*1e3:5.1f} ms | step wall {tot*1e3:6.1f} ms")
