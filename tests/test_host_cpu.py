@@ -1,0 +1,156 @@
+"""CPU: host logic of the product and the C-ABI surface (no compute calls: there is no GPU here).
+ * libkoaf.so loads and exports every symbol include/koaf.h declares; ctypes struct layout == the C layout
+ * registries have the reference's keys; bookkeeping (`vs` dicts, state-dict keys/shapes/dtypes, parameter
+   counts) of all six models is bit-exact against fixture F11 taken from the imported reference
+ * LR schedules are bit-exact (repr) against fixture F9
+ * the product fails loudly on CPU tensors (no silent fallback) and never imports the oracle
+"""
+import ctypes
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+import procedural as P
+from common import GOLDEN
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    from oaprogressionmmf_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 55
+    handle = ctypes.CDLL(str(_lib.LIB_PATH))
+    missing = [n for n in protos if not hasattr(handle, n)]
+    assert not missing, missing
+    L = _lib.lib()
+    assert L.koaf_version() >= 100
+    # an argument error comes back as a status + message, not a crash
+    assert L.koaf_slab_reduce(None, 0, 0, None, None) != 0
+    assert b"koaf_slab_reduce" in L.koaf_last_error()
+
+
+def test_struct_layout_matches_c(tmp_path):
+    from oaprogressionmmf_amd import _lib
+    src = tmp_path / "sz.c"
+    src.write_text('#include "koaf.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(KoafGemm),sizeof(KoafOperand),offsetof(KoafGemm,C),offsetof(KoafGemm,stats),'
+                   'offsetof(KoafGemm,cmap),offsetof(KoafOperand,sc));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    c = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    py = [ctypes.sizeof(_lib.KoafGemm), ctypes.sizeof(_lib.KoafOperand), _lib.KoafGemm.C.offset,
+          _lib.KoafGemm.stats.offset, _lib.KoafGemm.cmap.offset, _lib.KoafOperand.sc.offset]
+    assert c == py
+
+
+def _cfgs():
+    return {"XR1Cnn": P.cfg_xr1cnn(), "MR1CnnTrf": P.cfg_mr1(),
+            "MR2CnnTrf": P.cfg_mr2((160, 160, 64), (160, 160, 32), 4),
+            "XR1MR1CnnTrf": P.cfg_xr1mr1((350, 350), (160, 160, 64), 4),
+            "XR1MR2CnnTrf": P.cfg_xr1mr2((350, 350), (160, 160, 64), (160, 160, 32), 4),
+            "XR1MR2C1CnnTrf": P.cfg_full()}
+
+
+def test_registries_and_bookkeeping_match_reference():
+    from oaprogressionmmf_amd.config import ConfigDict
+    from oaprogressionmmf_amd.models import dict_fes, dict_models
+    from oaprogressionmmf_amd.various import dict_losses, dict_optimizers, dict_schedulers
+    book = json.loads((GOLDEN / "f11_bookkeeping.json").read_text())
+    sched = json.loads((GOLDEN / "f9_schedules.json").read_text())
+    assert sorted(dict_models) == book["dict_models"]
+    assert sorted(dict_losses) == book["dict_losses"]
+    assert sorted(dict_optimizers) == sched["optimizer_keys"]
+    assert sorted(dict_schedulers) == sched["scheduler_keys"]
+    assert sorted(dict_fes) == sorted(["squeezenet1_0", "vgg16", "densenet161", "inception_v3", "resnet18",
+                                       "resnet34", "resnet50", "resnext50_32x4d"])
+    for name, cfg in _cfgs().items():
+        m = dict_models[name](config=ConfigDict(cfg), path_weights=None)
+        ref = book[name]
+        assert [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()] == ref["state_dict"], name
+        assert sum(p.numel() for p in m.parameters()) == ref["num_params"], name
+        vs = {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in getattr(m, "vs", {}).items()}
+        assert vs == ref["vs"], name
+    m = dict_models["MR1CnnTrf"](config=ConfigDict(P.cfg_mr1(shape=(160, 160, 64), with_gap=False)), path_weights=None)
+    assert {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in m.vs.items()} == book["MR1CnnTrf_nogap"]["vs"]
+
+
+def test_config_errors_like_reference():
+    from oaprogressionmmf_amd.config import ConfigDict
+    from oaprogressionmmf_amd.models import dict_models
+    bad = P.cfg_full(xr=(310, 310))          # 310 is not in the reference's size table (_xrNmrMcP.py:104-106)
+    with pytest.raises(AssertionError):
+        dict_models["XR1MR2C1CnnTrf"](config=ConfigDict(bad), path_weights=None)
+    with pytest.raises(ValueError):
+        dict_models["MR1CnnTrf"](config=ConfigDict(P.cfg_mr1(dims_view="xy")), path_weights=None)
+    with pytest.raises(ValueError):
+        dict_models["MR1CnnTrf"](config=ConfigDict(P.cfg_mr1(arch="resnext50_32x4d")), path_weights=None)
+    with pytest.raises(KeyError):
+        dict_models["NoSuchModel"]
+    cfg = ConfigDict(P.cfg_xr1cnn())
+    assert cfg["fe"]["arch"] == cfg.fe.arch
+
+
+def test_schedules_bit_exact():
+    from oaprogressionmmf_amd.various import dict_optimizers, dict_schedulers
+    tab = json.loads((GOLDEN / "f9_schedules.json").read_text())
+    p = [torch.nn.Parameter(torch.zeros(1))]
+    opt = torch.optim.SGD(p, lr=1e-4)
+    s = dict_schedulers["CustomWarmupStaticDecayLR"](optimizer=opt, epochs_warmup=5, epochs_static=100, epochs_decay=1)
+    lrs = []
+    for _ in range(121):
+        lrs.append(repr(float(opt.param_groups[0]["lr"])))
+        opt.step()
+        s.step()
+    assert lrs == tab["static_decay"]
+    opt = torch.optim.SGD(p, lr=1e-3)
+    s = dict_schedulers["CustomWarmupMultiStepLR"](optimizer=opt, epochs_warmup=5, mstep_milestones=[20, 40])
+    lrs = []
+    for _ in range(121):
+        lrs.append(repr(float(opt.param_groups[0]["lr"])))
+        opt.step()
+        s.step()
+    assert lrs == tab["multistep"]
+    assert dict_optimizers["Adam"].__module__.startswith("oaprogressionmmf_amd")
+
+
+def test_no_cpu_fallback_and_no_oracle_in_product():
+    from oaprogressionmmf_amd import ops
+    from oaprogressionmmf_amd._lib import KoafError
+    from oaprogressionmmf_amd.config import ConfigDict
+    from oaprogressionmmf_amd.models import dict_models
+    from oaprogressionmmf_amd.various import dict_losses
+    with pytest.raises(KoafError):
+        ops.gelu_fwd(torch.zeros(8))
+    m = dict_models["XR1Cnn"](config=ConfigDict(P.cfg_xr1cnn(arch="resnet18", size=64)), path_weights=None)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 1, 64, 64))
+    with pytest.raises(KoafError):
+        dict_losses["FocalLoss"]()(torch.zeros(2, 2), torch.zeros(2, dtype=torch.int64))
+    # the product package never references the oracle
+    for f in (ROOT / "oaprogressionmmf_amd").rglob("*.py"):
+        txt = f.read_text()
+        assert "import oracle" not in txt and "from oracle" not in txt and "koafusion_cpu" not in txt, f
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from oaprogressionmmf_amd.config import ConfigDict
+    from oaprogressionmmf_amd.models import dict_models
+    from oaprogressionmmf_amd.various import CheckpointHandler
+    cfg = P.cfg_xr1cnn(arch="resnet18", size=64)
+    m = dict_models["XR1Cnn"](config=ConfigDict(cfg), path_weights=None)
+    h = CheckpointHandler(tmp_path)
+    h.save_new_ckpt(model=m, model_name="XR1Cnn", fold_idx=0, epoch_idx=3)
+    h.save_new_ckpt(model=m, model_name="XR1Cnn", fold_idx=0, epoch_idx=7)
+    files = sorted(p.name for p in tmp_path.glob("*.pth"))
+    assert files == ["XR1Cnn__fold_0__epoch_007.pth"]            # num_saved = 1, reference file-name pattern
+    cfg2 = dict(cfg, restore_weights=True)
+    m2 = dict_models["XR1Cnn"](config=ConfigDict(cfg2), path_weights=h.get_last_ckpt())
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    sd = torch.load(h.get_last_ckpt())
+    assert all(v.is_contiguous() for v in sd.values())           # plain tensors: loadable by the reference
