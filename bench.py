@@ -161,8 +161,9 @@ def main():
         dt = float(tt.item())
 
     # one extra instrumented step: live event timing of every MFMA-GEMM launch on its launch stream
-    from oaprogressionmmf_amd.models import _encoder
+    from oaprogressionmmf_amd.models import _common, _encoder
     _encoder.USE_SIDE_STREAM = False      # serialise: per-kernel durations are not inflated by co-running kernels
+    _common.USE_LANES = False
     ops.PROFILE = []
     step()
     torch.cuda.synchronize()

@@ -85,6 +85,9 @@ int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn);
 /* out[i] = sum_s slabs[s][i], i < n, n % 4 == 0 (deterministic split-K combine).  The slab workspace must
  * hold (nslab + 16) * n floats: large counts are folded in two levels through the 16 trailing slabs. */
 int koaf_slab_reduce(const float* slabs, int32_t nslab, int64_t n, float* out, void* stream);
+/* out[m][c] = sum_s slabs[s][m][c] + bias[c] + residual[m][c]  (split-K combine with the linear epilogue) */
+int koaf_slab_reduce_epilogue(const float* slabs, int32_t nslab, int32_t M, int32_t N, const float* bias,
+                              const float* residual, int64_t ldr, float* out, int64_t ldo, void* stream);
 
 /* ---- Convolution (nn.Conv2d, bias-free; _torchvision.py:23-31) as implicit GEMM on NHWC -------
  * x [N,H,W,Cin], w packed [Cout,KH,KW,Cin] (the memory of a channels_last (Cout,Cin,KH,KW)
@@ -194,11 +197,13 @@ int koaf_downscale2(const float* x, float* out, int32_t B, int32_t R, int32_t Cc
                     int32_t fs, void* stream);
 
 /* ---- Transformer pieces (_core_trf.py) ------------------------------------------------------- */
-/* nn.Linear: y[M,N] = x[M,K] w[N,K]^T + b (+residual) */
+/* nn.Linear: y[M,N] = x[M,K] w[N,K]^T + b (+residual).  Small grids (few tokens) run split-K: ws = workspace
+ * of koaf_linear_ws(M, N, K) floats (0 = not needed; NULL ws falls back to the unsplit kernel). */
+int64_t koaf_linear_ws(int32_t M, int32_t N, int32_t K);
 int koaf_linear_fwd(const float* x, const float* w, const float* b, const float* residual,
-                    float* y, int32_t M, int32_t N, int32_t K, void* stream);
-/* dx[M,K] = dy[M,N] w[N,K]  (w read K-major, no re-pack) (+residual) */
-int koaf_linear_dgrad(const float* dy, const float* w, const float* residual, float* dx,
+                    float* y, float* ws, int32_t M, int32_t N, int32_t K, void* stream);
+/* dx[M,K] = dy[M,N] w[N,K]  (w read K-major, no re-pack) (+residual); ws: koaf_linear_ws(M, K, N) floats */
+int koaf_linear_dgrad(const float* dy, const float* w, const float* residual, float* dx, float* ws,
                       int32_t M, int32_t N, int32_t K, void* stream);
 /* dw[N,K] = dy^T x ; db[N] = column sums of dy (db nullable; ws: koaf_colsum_ws(M,N) floats) */
 int koaf_linear_wgrad(const float* dy, const float* x, float* dw, float* db, float* ws, int32_t M,

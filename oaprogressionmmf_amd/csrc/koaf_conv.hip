@@ -495,27 +495,59 @@ extern "C" int koaf_stem_unfold_dw(const float* dw1t, float* dw, void* stream) {
 // ================================================================================================
 // nn.Linear
 // ================================================================================================
+// split-K plan for a linear layer with few rows: the 64x64-tile grid of M x N is only a few hundred blocks with
+// K/32 serial k-steps each (latency-bound at ~1 block per CU); splitting K 2-8 ways fills the chip.
+static int linear_splitk(int M, int N, int K) {
+    if ((N & 3) || K < 512) return 1;
+    const int64_t tiles = cdiv64(M, 64) * cdiv64(N, 64);
+    if (tiles >= 1024) return 1;
+    int sk = (int)(1024 / tiles);
+    if (sk > 8) sk = 8;
+    while (sk > 1 && K / sk < 256) --sk;
+    return sk;
+}
+extern "C" int64_t koaf_linear_ws(int32_t M, int32_t N, int32_t K) {
+    const int sk = linear_splitk(M, N, K);
+    return sk > 1 ? (int64_t)sk * M * N : 0;
+}
+
 extern "C" int koaf_linear_fwd(const float* x, const float* w, const float* b, const float* residual, float* y,
-                               int32_t M, int32_t N, int32_t K, void* stream) {
+                               float* ws, int32_t M, int32_t N, int32_t K, void* stream) {
     KOAF_REQUIRE(x && w && y && M > 0 && N > 0 && K > 0, "koaf_linear_fwd: bad args");
     KoafGemm g;
     zero_gemm(&g);
     g.A.ptr = x; g.A.kind = 0; g.A.ld = K;
     g.B.ptr = w; g.B.kind = 0; g.B.ld = K;
     g.M = M; g.N = N; g.K = K;
+    const int sk = ws ? linear_splitk(M, N, K) : 1;
+    if (sk > 1) {
+        g.splitk = sk; g.bm = 64; g.bn = 64;
+        g.C = ws; g.ldc = N;
+        int rc = koaf_gemm(&g, stream);
+        if (rc != KOAF_OK) return rc;
+        return koaf_slab_reduce_epilogue(ws, sk, M, N, b, residual, N, y, N, stream);
+    }
     g.C = y; g.ldc = N;
     g.bias = b;
     g.residual = residual; g.ldr = N;
     return koaf_gemm(&g, stream);
 }
-extern "C" int koaf_linear_dgrad(const float* dy, const float* w, const float* residual, float* dx, int32_t M,
-                                 int32_t N, int32_t K, void* stream) {
+extern "C" int koaf_linear_dgrad(const float* dy, const float* w, const float* residual, float* dx, float* ws,
+                                 int32_t M, int32_t N, int32_t K, void* stream) {
     KOAF_REQUIRE(dy && w && dx && M > 0 && N > 0 && K > 0, "koaf_linear_dgrad: bad args");
     KoafGemm g;
     zero_gemm(&g);
     g.A.ptr = dy; g.A.kind = 0; g.A.ld = N;
     g.B.ptr = w; g.B.kind = 1; g.B.ld = K;  // element (r = k_in, kk = n_out) at w + n_out*K + k_in
     g.M = M; g.N = K; g.K = N;
+    const int sk = ws ? linear_splitk(M, K, N) : 1;
+    if (sk > 1) {
+        g.splitk = sk; g.bm = 64; g.bn = 64;
+        g.C = ws; g.ldc = K;
+        int rc = koaf_gemm(&g, stream);
+        if (rc != KOAF_OK) return rc;
+        return koaf_slab_reduce_epilogue(ws, sk, M, K, nullptr, residual, K, dx, K, stream);
+    }
     g.C = dx; g.ldc = K;
     g.residual = residual; g.ldr = K;
     return koaf_gemm(&g, stream);

@@ -19,6 +19,9 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
+#ifndef KOAF_DB_ALL
+#define KOAF_DB_ALL 0
+#endif
 #ifndef KOAF_ISSUE_AT
 #define KOAF_ISSUE_AT 0   // 0: next tile's loads go out at the top of the k-step (longest flight time);
 #endif                    // 1: between the MFMA groups
@@ -264,9 +267,14 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     constexpr int A_ELEMS = AKC ? BM * LDK : BK * BM;
     constexpr int B_ELEMS = BKC ? BN * LDK : BK * BN;
     constexpr int STAGE = A_ELEMS + B_ELEMS;
+    // LDS double buffering (one barrier per k-step) only where it does not cost a resident block: the 128x128
+    // tile is register-limited to 2 blocks/CU either way; the rectangular tiles fit 3 blocks single-buffered
+    // (27 KB) but only 2 double-buffered (55 KB), and the third block hides more than the saved barrier.
+    constexpr bool DB = KOAF_DB_ALL ? true : (BM == BN);
+    constexpr int NSTAGE = DB ? 2 : 1;
     constexpr int LDC_S = BN + 4;                                    // epilogue staging row (floats)
     constexpr int C_ELEMS = VEC ? BM * LDC_S : 0;
-    constexpr int SMEM = (2 * STAGE > C_ELEMS) ? 2 * STAGE : C_ELEMS;
+    constexpr int SMEM = (NSTAGE * STAGE > C_ELEMS) ? NSTAGE * STAGE : C_ELEMS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];        // double-buffered operand tiles
 
     const int ntn = (p.N + BN - 1) / BN;
@@ -353,15 +361,26 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
                 if (kg == 1 && more) lb.issue(p.B, Bp, k0 + BK, kend, z1);
             }
         }
-        if (more) {
-            float* An = smem + (cur ^ 1) * STAGE;
-            la.finish();
-            lb.finish();
-            la.store(An);
-            lb.store(An + A_ELEMS);
+        if constexpr (DB) {
+            if (more) {
+                float* An = smem + (cur ^ 1) * STAGE;
+                la.finish();
+                lb.finish();
+                la.store(An);
+                lb.store(An + A_ELEMS);
+            }
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();
+            if (more) {
+                la.finish();
+                lb.finish();
+                la.store(smem);
+                lb.store(smem + A_ELEMS);
+                __syncthreads();
+            }
         }
-        __syncthreads();
-        cur ^= 1;
     }
 
     // ---- epilogue ----
@@ -471,6 +490,24 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
 
 // out[i] = sum_s slabs[s][i]: block = 64 float4-columns x 4 slab groups (LDS tree), so small outputs (a 64x64
 // weight gradient split 1024 ways) still spread over many waves instead of 4 blocks doing 1024 serial loads
+// out[m][c] = sum_s slabs[s][m][c] + bias[c] + residual[m][c]   (split-K combine of a small-grid linear layer)
+__global__ void __launch_bounds__(256) slab_reduce_epi_kernel(const float* __restrict__ slabs, int nslab, int M, int N,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ residual, int64_t ldr,
+                                                              float* __restrict__ out, int64_t ldo) {
+    const int N4 = N / 4;
+    const int64_t total = (int64_t)M * N4;
+    const int64_t n = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / N4), c = (int)(i - (int64_t)m * N4) * 4;
+        v4f a = *(const v4f*)(slabs + (int64_t)m * N + c);
+        for (int s = 1; s < nslab; ++s) a += *(const v4f*)(slabs + (int64_t)s * n + (int64_t)m * N + c);
+        if (bias) a += *(const v4f*)(bias + c);
+        if (residual) a += *(const v4f*)(residual + (int64_t)m * ldr + c);
+        *(v4f*)(out + (int64_t)m * ldo + c) = a;
+    }
+}
+
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int nslab,
                                                           int64_t n, float* __restrict__ out) {
     __shared__ v4f red[4][64];
@@ -617,4 +654,16 @@ extern "C" int koaf_slab_reduce(const float* slabs, int32_t nslab, int64_t n, fl
     }
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(bx, 1), dim3(256), 0, s, slabs, nslab, n, out);
     return koaf_check_launch("koaf_slab_reduce");
+}
+
+extern "C" int koaf_slab_reduce_epilogue(const float* slabs, int32_t nslab, int32_t M, int32_t N, const float* bias,
+                                         const float* residual, int64_t ldr, float* out, int64_t ldo, void* stream) {
+    KOAF_REQUIRE(slabs && out && nslab >= 1 && M > 0 && N > 0 && (N & 3) == 0 && (ldo & 3) == 0 && (ldr & 3) == 0,
+                 "koaf_slab_reduce_epilogue: bad args");
+    const int64_t total = (int64_t)M * (N / 4);
+    int64_t blocks = cdiv64(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(slab_reduce_epi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslab, M,
+                       N, bias, residual, ldr, out, ldo);
+    return koaf_check_launch("koaf_slab_reduce_epilogue");
 }

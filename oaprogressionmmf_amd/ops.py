@@ -269,17 +269,25 @@ def downscale2(x, B, R, Cc, S, fs):
 # transformer pieces
 # ------------------------------------------------------------------------------------------------
 def linear_fwd(x, w, b, M, N, K, residual=None):
+    L = lib()
     y = _empty((M, N), x)
+    n = L.koaf_linear_ws(M, N, K)
+    ws = _empty((n,), x) if n > 0 else None
     e0 = _prof_begin()
-    check(lib().koaf_linear_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(residual), _ptr(y), M, N, K, _stream()), "linear_fwd")
+    check(L.koaf_linear_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(residual), _ptr(y), _ptr(ws), M, N, K, _stream()),
+          "linear_fwd")
     _prof_end(e0, "gemm", 2.0 * M * N * K, f"linear_fwd M{M} N{N} K{K}")
     return y
 
 
 def linear_dgrad(dy, w, M, N, K, residual=None):
+    L = lib()
     dx = _empty((M, K), dy)
+    n = L.koaf_linear_ws(M, K, N)
+    ws = _empty((n,), dy) if n > 0 else None
     e0 = _prof_begin()
-    check(lib().koaf_linear_dgrad(_ptr(dy), _ptr(w), _ptr(residual), _ptr(dx), M, N, K, _stream()), "linear_dgrad")
+    check(L.koaf_linear_dgrad(_ptr(dy), _ptr(w), _ptr(residual), _ptr(dx), _ptr(ws), M, N, K, _stream()),
+          "linear_dgrad")
     _prof_end(e0, "gemm", 2.0 * M * N * K, f"linear_dgrad M{M} N{N} K{K}")
     return dx
 
