@@ -77,6 +77,22 @@ typedef struct KoafGemm {
     /* output row map (stride-2 dgrad parity classes): GEMM row (n, y', x') over a cm_PH x cm_PW grid is
        written to pixel row (n*cm_H + 2y'+cm_py)*cm_W + 2x'+cm_px of C / residual.  cmap = 0: identity. */
     int32_t cmap, cm_PH, cm_PW, cm_H, cm_W, cm_py, cm_px, _pad2;
+    /* Fused BatchNorm(+ReLU)-backward reduction (dgrad epilogue).  The GEMM output g (after bias/residual) is the
+       gradient w.r.t. relu(bn(c)); the epilogue masks it (bnb_mode 1: bnb_y > 0; 2: bnb_sc*c+bnb_sh > 0), stores
+       dz instead of g, and emits per-M-tile column sums  bnb_part[tile][k][N]:  k=0: sum dz, k=1: sum dz*xhat with
+       xhat = (c-mean)*invstd, k=2 (if bnb2_c): sum dz*xhat2 for a second BatchNorm fed by the same dz (the
+       downsample branch).  c / y / c2 are laid out like C (same ldc, same row map).  bnb_mode 0 = off. */
+    int32_t bnb_mode, _pad3;
+    const float* bnb_c;
+    const float* bnb_y;
+    const float* bnb_sc;
+    const float* bnb_sh;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    const float* bnb2_c;
+    const float* bnb2_mean;
+    const float* bnb2_invstd;
+    float* bnb_part;
 } KoafGemm;
 
 int koaf_gemm(const KoafGemm* g, void* stream);
@@ -105,6 +121,26 @@ int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout);
 int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
                       int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride,
                       int32_t pad, const float* residual, void* stream);
+/* Same, with the BatchNorm(+ReLU) backward reduction of the layer that PRODUCED x fused into the epilogue (see
+ * KoafGemm.bnb_*): dx receives the masked gradient dz; part [*part_rows][nsum][Cin] (nsum = 2, or 3 with c2) feeds
+ * koaf_bn_bwd_finalize.  koaf_conv2d_dgrad_bnb_rows() bounds *part_rows for sizing. */
+typedef struct KoafBnb {
+    int32_t mode, _pad;     /* 1: mask y > 0; 2: mask sc*c+sh > 0 */
+    const float* c;
+    const float* y;
+    const float* sc;
+    const float* sh;
+    const float* mean;
+    const float* invstd;
+    const float* c2;        /* optional second BatchNorm on the same dz */
+    const float* mean2;
+    const float* invstd2;
+} KoafBnb;
+int32_t koaf_conv2d_dgrad_bnb_rows(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t stride);
+int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
+                          int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                          const float* residual, const KoafBnb* bnb, float* part, int32_t* part_rows,
+                          void* stream);
 /* dw packed [Cout,KH,KW,Cin] = sum_pixels dy^T x, x optionally transformed on load.  Deterministic
  * split-K: slabs = workspace of koaf_conv2d_wgrad_ws() floats (0 = none needed).  */
 int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
@@ -170,10 +206,11 @@ int koaf_bn_bwd_reduce(const float* g, const float* c, const float* ymask, const
                        const float* sh, const float* mean, const float* invstd, int32_t mask_mode,
                        float* dz_out, float* part, int32_t* part_rows, int64_t rows, int32_t C,
                        void* stream);
-/* part -> dgamma, dbeta, and apply coefficients coef [3][C] = {sc, dbeta/M, sc*invstd*dgamma/M} */
+/* part [rows][nsum][C] -> dgamma (= sum index i1), dbeta (= sum index 0), and apply coefficients
+ * coef [3][C] = {sc, dbeta/M, sc*invstd*dgamma/M}.  (nsum, i1) = (2, 1) for the plain layout. */
 int koaf_bn_bwd_finalize(const float* part, int32_t part_rows, int32_t C, int64_t count,
                          const float* sc, const float* invstd, float* dgamma, float* dbeta,
-                         float* coef, void* stream);
+                         float* coef, int32_t nsum, int32_t i1, void* stream);
 /* dc = coef0*(dz - coef1) - coef2*(c - mean) */
 int koaf_bn_bwd_apply(const float* dz, const float* c, const float* mean, const float* coef,
                       float* dc, int64_t rows, int32_t C, void* stream);

@@ -77,6 +77,34 @@ class KoafGemm(ctypes.Structure):
         ("cm_py", ctypes.c_int32),
         ("cm_px", ctypes.c_int32),
         ("_pad2", ctypes.c_int32),
+        ("bnb_mode", ctypes.c_int32),
+        ("_pad3", ctypes.c_int32),
+        ("bnb_c", ctypes.c_void_p),
+        ("bnb_y", ctypes.c_void_p),
+        ("bnb_sc", ctypes.c_void_p),
+        ("bnb_sh", ctypes.c_void_p),
+        ("bnb_mean", ctypes.c_void_p),
+        ("bnb_invstd", ctypes.c_void_p),
+        ("bnb2_c", ctypes.c_void_p),
+        ("bnb2_mean", ctypes.c_void_p),
+        ("bnb2_invstd", ctypes.c_void_p),
+        ("bnb_part", ctypes.c_void_p),
+    ]
+
+
+class KoafBnb(ctypes.Structure):
+    _fields_ = [
+        ("mode", ctypes.c_int32),
+        ("_pad", ctypes.c_int32),
+        ("c", ctypes.c_void_p),
+        ("y", ctypes.c_void_p),
+        ("sc", ctypes.c_void_p),
+        ("sh", ctypes.c_void_p),
+        ("mean", ctypes.c_void_p),
+        ("invstd", ctypes.c_void_p),
+        ("c2", ctypes.c_void_p),
+        ("mean2", ctypes.c_void_p),
+        ("invstd2", ctypes.c_void_p),
     ]
 
 
@@ -95,6 +123,8 @@ def _ctype(decl: str):
         base = decl.replace("const", "").replace("*", "").split()[0]
         if base == "KoafGemm":
             return ctypes.POINTER(KoafGemm)
+        if base == "KoafBnb":
+            return ctypes.POINTER(KoafBnb)
         if base == "char":
             return ctypes.c_char_p
         return ctypes.c_void_p

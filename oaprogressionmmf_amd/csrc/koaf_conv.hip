@@ -247,10 +247,34 @@ extern "C" int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout) {
     return (int32_t)cdiv64(M, g.bm);
 }
 
-extern "C" int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
-                                 int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
-                                 const float* residual, void* stream) {
+static void set_bnb(KoafGemm* g, const KoafBnb* b, float* part) {
+    if (!b) return;
+    g->bnb_mode = b->mode;
+    g->bnb_c = b->c; g->bnb_y = b->y; g->bnb_sc = b->sc; g->bnb_sh = b->sh;
+    g->bnb_mean = b->mean; g->bnb_invstd = b->invstd;
+    g->bnb2_c = b->c2; g->bnb2_mean = b->mean2; g->bnb2_invstd = b->invstd2;
+    g->bnb_part = part;
+}
+
+extern "C" int32_t koaf_conv2d_dgrad_bnb_rows(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t stride) {
+    // upper bound: 64-row tiles; stride 2 = four parity classes
+    if (stride == 2) {
+        int64_t r = 0;
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) r += cdiv64((int64_t)N * ((H - py + 1) / 2) * ((W - px + 1) / 2), 64);
+        return (int32_t)r;
+    }
+    return (int32_t)cdiv64((int64_t)N * H * W, 64);
+}
+
+extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
+                                     int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                                     const float* residual, const KoafBnb* bnb, float* part, int32_t* part_rows,
+                                     void* stream) {
     KOAF_REQUIRE(dy && w && dx && N > 0 && Cout % 32 == 0 && Cin % 4 == 0, "koaf_conv2d_dgrad: bad args");
+    KOAF_REQUIRE(!bnb || (part && part_rows), "koaf_conv2d_dgrad_bnb: part / part_rows required");
+    const int nsum = (bnb && bnb->c2) ? 3 : 2;
+    int rows_done = 0;
     const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
     const int64_t M = (int64_t)N * H * W;
     KOAF_REQUIRE(M < (1ll << 31), "koaf_conv2d_dgrad: too many pixels");
@@ -279,9 +303,15 @@ extern "C" int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int
                 g.C = dx; g.ldc = Cin;
                 g.residual = residual; g.ldr = Cin;
                 g.cmap = 1; g.cm_PH = Hc; g.cm_PW = Wc; g.cm_H = H; g.cm_W = W; g.cm_py = py; g.cm_px = px;
+                if (bnb) {
+                    koaf_gemm_pick_tile(&g, &g.bm, &g.bn);
+                    set_bnb(&g, bnb, part + (int64_t)rows_done * nsum * Cin);
+                    rows_done += (int)cdiv64(g.M, g.bm);
+                }
                 int rc = koaf_gemm(&g, stream);
                 if (rc != KOAF_OK) return rc;
             }
+        if (part_rows) *part_rows = rows_done;
         return KOAF_OK;
     }
     zero_gemm(&g);
@@ -309,7 +339,19 @@ extern "C" int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int
     g.M = (int)M; g.N = Cin; g.K = KH * KW * Cout;
     g.C = dx; g.ldc = Cin;
     g.residual = residual; g.ldr = Cin;
+    if (bnb) {
+        koaf_gemm_pick_tile(&g, &g.bm, &g.bn);
+        set_bnb(&g, bnb, part);
+        *part_rows = (int)cdiv64(g.M, g.bm);
+    }
     return koaf_gemm(&g, stream);
+}
+
+extern "C" int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
+                                 int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                                 const float* residual, void* stream) {
+    return koaf_conv2d_dgrad_bnb(dy, w, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, residual, nullptr, nullptr,
+                                 nullptr, stream);
 }
 
 extern "C" int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH,

@@ -241,15 +241,15 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
 __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C,
                                                                double inv_count, const float* __restrict__ sc,
                                                                const float* __restrict__ invstd, float* dgamma,
-                                                               float* dbeta, float* coef) {
+                                                               float* dbeta, float* coef, int nsum, int i1) {
     __shared__ double red[2][16][64];
     const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     double a = 0.0, b = 0.0;
     if (c < C)
         for (int r = gy; r < rows; r += 16) {
-            a += (double)part[((int64_t)r * 2 + 0) * C + c];
-            b += (double)part[((int64_t)r * 2 + 1) * C + c];
+            a += (double)part[((int64_t)r * nsum + 0) * C + c];
+            b += (double)part[((int64_t)r * nsum + i1) * C + c];
         }
     red[0][gy][cx] = a;
     red[1][gy][cx] = b;
@@ -745,10 +745,12 @@ extern "C" int koaf_bn_bwd_reduce(const float* g, const float* c, const float* y
     return koaf_check_launch("koaf_bn_bwd_reduce");
 }
 extern "C" int koaf_bn_bwd_finalize(const float* part, int32_t part_rows, int32_t C, int64_t count, const float* sc,
-                                    const float* invstd, float* dgamma, float* dbeta, float* coef, void* stream) {
+                                    const float* invstd, float* dgamma, float* dbeta, float* coef, int32_t nsum,
+                                    int32_t i1, void* stream) {
     KOAF_REQUIRE(part && part_rows > 0 && C > 0 && count > 0 && sc && invstd && coef, "koaf_bn_bwd_finalize: bad args");
+    KOAF_REQUIRE(nsum >= 2 && i1 >= 1 && i1 < nsum, "koaf_bn_bwd_finalize: bad (nsum, i1)");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, STREAM, part, part_rows, C,
-                       1.0 / (double)count, sc, invstd, dgamma, dbeta, coef);
+                       1.0 / (double)count, sc, invstd, dgamma, dbeta, coef, nsum, i1);
     return koaf_check_launch("koaf_bn_bwd_finalize");
 }
 extern "C" int koaf_bn_bwd_apply(const float* dz, const float* c, const float* mean, const float* coef, float* dc,

@@ -421,9 +421,18 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         constexpr int RPP = 256 / C4;          // rows per pass
         const int c4 = t % C4, rr = t / C4;
         const int col = n0 + 4 * c4;
+        const bool bnb = (p.bnb_mode != 0) && !slab;
+        v4f q1 = {0.f, 0.f, 0.f, 0.f}, q2 = q1, q3 = q1;   // fused BN-backward column sums of this thread's rows
         if (col < p.N) {                         // N % 4 == 0 on this path
             v4f bv = {0.f, 0.f, 0.f, 0.f};
             if (bias) bv = *(const v4f*)(bias + col);
+            v4f mu = bv, is = bv, ms = bv, mh = bv, mu2 = bv, is2 = bv;
+            if (bnb) {
+                mu = *(const v4f*)(p.bnb_mean + col);
+                is = *(const v4f*)(p.bnb_invstd + col);
+                if (p.bnb_mode == 2) { ms = *(const v4f*)(p.bnb_sc + col); mh = *(const v4f*)(p.bnb_sh + col); }
+                if (p.bnb2_c) { mu2 = *(const v4f*)(p.bnb2_mean + col); is2 = *(const v4f*)(p.bnb2_invstd + col); }
+            }
 #pragma unroll 4
             for (int row = rr; row < BM; row += RPP) {
                 const int grow = m0 + row;
@@ -439,8 +448,40 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
                     }
                     v4f v = *(const v4f*)&Cs[row * LDC_S + 4 * c4] + bv;
                     if (Rp) v += *(const v4f*)(Rp + orow * p.ldr + col);
+                    if (bnb) {
+                        const v4f cv = *(const v4f*)(p.bnb_c + orow * ldc + col);
+                        if (p.bnb_mode == 1) {
+                            const v4f yv = *(const v4f*)(p.bnb_y + orow * ldc + col);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = yv[j] > 0.f ? v[j] : 0.f;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = (cv[j] * ms[j] + mh[j]) > 0.f ? v[j] : 0.f;
+                        }
+                        q1 += v;
+                        q2 += v * ((cv - mu) * is);
+                        if (p.bnb2_c) {
+                            const v4f c2 = *(const v4f*)(p.bnb2_c + orow * ldc + col);
+                            q3 += v * ((c2 - mu2) * is2);
+                        }
+                    }
                     *(v4f*)(Cp + orow * ldc + col) = v;
                 }
+            }
+        }
+        if (bnb) {
+            // column sums over the block's rows: RPP row-threads per column vector -> LDS -> one partial row
+            __syncthreads();                     // Cs fully consumed
+            v4f* red4 = reinterpret_cast<v4f*>(smem);   // [3][RPP][C4]
+            red4[(0 * RPP + rr) * C4 + c4] = q1;
+            red4[(1 * RPP + rr) * C4 + c4] = q2;
+            red4[(2 * RPP + rr) * C4 + c4] = q3;
+            __syncthreads();
+            const int nsum = p.bnb2_c ? 3 : 2;
+            if (rr < nsum && col < p.N) {
+                v4f a = red4[(rr * RPP) * C4 + c4];
+                for (int j = 1; j < RPP; ++j) a += red4[(rr * RPP + j) * C4 + c4];
+                *(v4f*)(p.bnb_part + ((int64_t)tm * nsum + rr) * p.N + col) = a;
             }
         }
         if (do_stats) __syncthreads();           // Cs is about to be reused by the statistics reduction
@@ -604,6 +645,10 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     if (g.B.CS == 0) g.B.CS = g.B.C;
     if (g.stats_ld == 0) g.stats_ld = g.N;
     KOAF_REQUIRE(!g.cmap || (g.splitk == 1 && !g.stats), "koaf_gemm: row map excludes split-K / stats");
+    KOAF_REQUIRE(!g.bnb_mode || (g.splitk == 1 && !g.stats && g.nb0 * g.nb1 == 1 && g.bnb_c && g.bnb_mean &&
+                                 g.bnb_invstd && g.bnb_part && (g.bnb_mode == 1 ? g.bnb_y != nullptr
+                                                                                 : (g.bnb_sc && g.bnb_sh))),
+                 "koaf_gemm: fused BN-backward epilogue needs c/mean/invstd/part (+y or sc/sh), no split-K/batch");
     KOAF_REQUIRE(g.splitk == 1 || (!g.bias && !g.residual && !g.stats),
                  "koaf_gemm: split-K writes raw slabs (no epilogue)");
     KOAF_REQUIRE((int64_t)g.nb0 * g.nb1 <= 65535 && g.splitk <= 65535, "koaf_gemm: batch/splitk too large");
@@ -620,6 +665,7 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     if (g.residual && (!aligned16(g.residual) || (g.ldr & 3) || (g.rbs0 & 3) || (g.rbs1 & 3))) vec = false;
     if (g.bias && !aligned16(g.bias)) vec = false;
     KOAF_REQUIRE(!g.cmap || vec, "koaf_gemm: row map needs the vector epilogue");
+    KOAF_REQUIRE(!g.bnb_mode || vec, "koaf_gemm: fused BN-backward needs the vector epilogue");
     if (g.A.gather || g.B.gather) KOAF_REQUIRE(vec, "koaf_gemm: gathered operands need aligned, C%%32==0 tensors");
     if (g.B.kind == 1 && g.B.gather == 1)
         KOAF_REQUIRE(g.B.C % bn == 0, "koaf_gemm: wgrad tile (%d) must divide channels per tap (%d)", bn, g.B.C);

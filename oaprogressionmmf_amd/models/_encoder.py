@@ -141,7 +141,7 @@ class _SideStream:
         self.pending = []
 
 
-def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True, side=None):
+def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True, side=None, bnb=None):
     """weight gradient (x transformed on load by in_saved) and data gradient of one conv."""
     w = packed_weight(conv.weight)
     cin, cout = conv.in_channels, conv.out_channels
@@ -161,9 +161,9 @@ def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True,
     dx = None
     if need_dx:
         if g == 1:
-            dx = ops.conv2d_dgrad(dc, w, N, H, W, cin, cout, k, k, s, p, residual=residual)
+            dx = ops.conv2d_dgrad(dc, w, N, H, W, cin, cout, k, k, s, p, residual=residual, bnb=bnb)
         else:
-            assert residual is None
+            assert residual is None and bnb is None
             dx = ops.gconv3x3_dgrad(dc, wexp, N, H, W, cin, s)
     if side is not None:
         # enqueued BEHIND the sibling dgrad: the side stream starts this wgrad when the dgrad is done, so it
@@ -180,6 +180,31 @@ def _bn_bwd(bn, g, c, saved, rows, mask_mode, ymask=None, dz_out=None, dc_out=No
     deliver_grad(bn.weight, gg, ag)
     deliver_grad(bn.bias, gb, ab)
     return dc
+
+
+def _bn_bwd_part(bn, part, nsum, i1, dz, c, saved, rows, dc_out=None):
+    """BatchNorm backward whose reduction was fused into the producing dgrad's epilogue."""
+    C = bn.num_features
+    gg, ag = grad_target(bn.weight)
+    gb, ab = grad_target(bn.bias)
+    dc = ops.bn_bwd_from_part(part, nsum, i1, dz, c, saved, rows, C, rows, gg, gb, dc_out=dc_out)
+    deliver_grad(bn.weight, gg, ag)
+    deliver_grad(bn.bias, gb, ab)
+    return dc
+
+
+FUSE_BNB = os.environ.get("KOAF_FUSE_BNB", "1") != "0"
+
+
+def _tail_bnb(prev):
+    """epilogue descriptor for the tail (relu(bn(c_last) + identity)) of block record `prev`"""
+    if prev is None or not FUSE_BNB:
+        return None
+    c_last, s_last = (prev.c3, prev.s3) if prev.kind == "bottleneck" else (prev.c2, prev.s2)
+    d = dict(mode=1, c=c_last, y=prev.y, saved=s_last)
+    if prev.cd is not None:
+        d["c2"], d["saved2"] = prev.cd, prev.sd
+    return d
 
 
 class EncoderFn(torch.autograd.Function):
@@ -278,37 +303,72 @@ class EncoderFn(torch.autograd.Function):
                 dy = dy.clone()  # masked in place below
         recs = S["recs"]
         side = _SideStream(gout.device, side_stream) if USE_SIDE_STREAM else None
+        pend = None   # (part, nsum) of THIS block's tail when the previous dgrad's epilogue already reduced it
         while recs:
             r = recs.pop()
+            prev = recs[-1] if recs else None
             blk = r.blk
             N, Hi, Wi, OH, OW = r.dims
             rows_o, rows_i = N * OH * OW, N * Hi * Wi
-            if r.kind == "bottleneck":
-                # tail: dz = dy*[y>0] (in place), BN3
-                dc3 = _bn_bwd(blk.bn3, dy, r.c3, r.s3, rows_o, 1, ymask=r.y, dz_out=dy)
-                dz = dy
-                da2 = _conv_bwd(blk.conv3, dc3, r.c2, N, OH, OW, r.s2, None, side=side)
-                del dc3
-                dc2 = _bn_bwd(blk.bn2, da2, r.c2, r.s2, rows_o, 2, dc_out=da2)
-                da1 = _conv_bwd(blk.conv2, dc2, r.c1, N, Hi, Wi, r.s1, r.wexp, side=side)
+            bott = r.kind == "bottleneck"
+            tail_bn = blk.bn3 if bott else blk.bn2
+            tail_c, tail_s = (r.c3, r.s3) if bott else (r.c2, r.s2)
+            # tail: dz = dy*[y>0] and the BatchNorm behind it
+            if pend is None:
+                dcl = _bn_bwd(tail_bn, dy, tail_c, tail_s, rows_o, 1, ymask=r.y, dz_out=dy)
+            else:
+                dcl = _bn_bwd_part(tail_bn, pend[0], pend[1], 1, dy, tail_c, tail_s, rows_o)
+            dz = dy
+            inner = FUSE_BNB
+            if bott:
+                g2 = blk.conv2.groups == 1 and inner
+                res = _conv_bwd(blk.conv3, dcl, r.c2, N, OH, OW, r.s2, None, side=side,
+                                bnb=dict(mode=2, c=r.c2, saved=r.s2) if inner else None)
+                del dcl
+                if inner:
+                    da2, part2 = res
+                    dc2 = _bn_bwd_part(blk.bn2, part2, 2, 1, da2, r.c2, r.s2, rows_o, dc_out=da2)
+                else:
+                    da2 = res
+                    dc2 = _bn_bwd(blk.bn2, da2, r.c2, r.s2, rows_o, 2, dc_out=da2)
+                res = _conv_bwd(blk.conv2, dc2, r.c1, N, Hi, Wi, r.s1, r.wexp, side=side,
+                                bnb=dict(mode=2, c=r.c1, saved=r.s1) if g2 else None)
                 del dc2, da2
-                dc1 = _bn_bwd(blk.bn1, da1, r.c1, r.s1, rows_i, 2, dc_out=da1)
-                first = blk.conv1
+                if g2:
+                    da1, part1 = res
+                    dc1 = _bn_bwd_part(blk.bn1, part1, 2, 1, da1, r.c1, r.s1, rows_i, dc_out=da1)
+                else:
+                    da1 = res
+                    dc1 = _bn_bwd(blk.bn1, da1, r.c1, r.s1, rows_i, 2, dc_out=da1)
             else:
-                dc2 = _bn_bwd(blk.bn2, dy, r.c2, r.s2, rows_o, 1, ymask=r.y, dz_out=dy)
-                dz = dy
-                da1 = _conv_bwd(blk.conv2, dc2, r.c1, N, OH, OW, r.s1, None, side=side)
-                del dc2
-                dc1 = _bn_bwd(blk.bn1, da1, r.c1, r.s1, rows_o, 2, dc_out=da1)
-                first = blk.conv1
+                res = _conv_bwd(blk.conv2, dcl, r.c1, N, OH, OW, r.s1, None, side=side,
+                                bnb=dict(mode=2, c=r.c1, saved=r.s1) if inner else None)
+                del dcl
+                if inner:
+                    da1, part1 = res
+                    dc1 = _bn_bwd_part(blk.bn1, part1, 2, 1, da1, r.c1, r.s1, rows_o, dc_out=da1)
+                else:
+                    da1 = res
+                    dc1 = _bn_bwd(blk.bn1, da1, r.c1, r.s1, rows_o, 2, dc_out=da1)
+            first = blk.conv1
+            # identity branch
             if blk.downsample is not None:
-                dcd = _bn_bwd(blk.downsample[1], dz, r.cd, r.sd, rows_o, 0, dc_out=dz)
-                t = _conv_bwd(blk.downsample[0], dcd, r.yin, N, Hi, Wi, None, None, side=side)
-                dy = _conv_bwd(first, dc1, r.yin, N, Hi, Wi, None, None, residual=t, side=side)
-                del t, dcd
+                if pend is None:
+                    dcd = _bn_bwd(blk.downsample[1], dz, r.cd, r.sd, rows_o, 0, dc_out=dz)
+                else:
+                    dcd = _bn_bwd_part(blk.downsample[1], pend[0], pend[1], 2, dz, r.cd, r.sd, rows_o, dc_out=dz)
+                resid = _conv_bwd(blk.downsample[0], dcd, r.yin, N, Hi, Wi, None, None, side=side)
             else:
-                dy = _conv_bwd(first, dc1, r.yin, N, Hi, Wi, None, None, residual=dz, side=side)
-            del dc1, da1, dz, r
+                resid = dz
+            # block-entry dgrad (+identity gradient); its epilogue reduces the PREVIOUS block's tail BatchNorm(s)
+            bnb = _tail_bnb(prev)
+            res = _conv_bwd(first, dc1, r.yin, N, Hi, Wi, None, None, residual=resid, side=side, bnb=bnb)
+            if bnb is not None:
+                dy, part = res
+                pend = (part, 3 if "c2" in bnb else 2)
+            else:
+                dy, pend = res, None
+            del dc1, da1, dz, resid, r
         # stem: max-pool, BN0, conv1 weight gradient (no data gradient: the input is a leaf)
         conv1, bn1 = st["conv1"], st["bn1"]
         da0 = ops.maxpool_bwd(dy, S["am"], N, H1, W1, 64)

@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from ._lib import KoafGemm, KoafError, check, lib
+from ._lib import KoafBnb, KoafGemm, KoafError, check, lib
 
 _i32 = ctypes.c_int32
 
@@ -79,15 +79,33 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     return y, part
 
 
-def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None):
+def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, bnb=None):
+    """dx = conv_transpose(dy, w) (+residual).  bnb = dict(mode, c, saved[, y][, c2, saved2]): fuse the
+    BatchNorm(+ReLU)-backward reduction of the layer that produced x into the epilogue; then returns
+    (dz, part [rows][nsum][Cin]) instead of dx."""
     L = lib()
     dx = _empty((N, H, W, Cin), dy)
+    fl = 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin
+    tag = f"conv_dgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}"
+    if bnb is None:
+        e0 = _prof_begin()
+        check(L.koaf_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                  _ptr(residual), _stream()), "conv2d_dgrad")
+        _prof_end(e0, "gemm", fl, tag)
+        return dx
+    sv, sv2 = bnb["saved"], bnb.get("saved2")
+    kb = KoafBnb(mode=bnb["mode"], c=_ptr(bnb["c"]), y=_ptr(bnb.get("y")), sc=_ptr(sv[2]), sh=_ptr(sv[3]),
+                 mean=_ptr(sv[0]), invstd=_ptr(sv[1]), c2=_ptr(bnb.get("c2")),
+                 mean2=_ptr(sv2[0]) if sv2 is not None else None, invstd2=_ptr(sv2[1]) if sv2 is not None else None)
+    nsum = 3 if bnb.get("c2") is not None else 2
+    part = _empty((L.koaf_conv2d_dgrad_bnb_rows(N, H, W, Cin, stride), nsum, Cin), dy)
+    rows = _i32(0)
     e0 = _prof_begin()
-    check(L.koaf_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(residual),
-                              _stream()), "conv2d_dgrad")
-    _prof_end(e0, "gemm", 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin,
-              f"conv_dgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}")
-    return dx
+    check(L.koaf_conv2d_dgrad_bnb(_ptr(dy), _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                  _ptr(residual), ctypes.byref(kb), _ptr(part), ctypes.addressof(rows), _stream()),
+          "conv2d_dgrad_bnb")
+    _prof_end(e0, "gemm", fl, tag + " +bnb")
+    return dx, part[:rows.value]
 
 
 def conv2d_wgrad(dy, x, dw, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None):
@@ -215,8 +233,20 @@ def bn_bwd(g, c, saved, rows, C, count, dgamma, dbeta, mask_mode, ymask=None, dz
                                _stream()), "bn_bwd_reduce")
     coef = _empty((3, C), g)
     check(L.koaf_bn_bwd_finalize(_ptr(part), r.value, C, count, _ptr(saved[2]), _ptr(saved[1]), _ptr(dgamma),
-                                 _ptr(dbeta), _ptr(coef), _stream()), "bn_bwd_finalize")
+                                 _ptr(dbeta), _ptr(coef), 2, 1, _stream()), "bn_bwd_finalize")
     dz = dz_out if dz_out is not None else g
+    dc = dc_out if dc_out is not None else torch.empty_like(c)
+    check(L.koaf_bn_bwd_apply(_ptr(dz), _ptr(c), _ptr(saved[0]), _ptr(coef), _ptr(dc), rows, C, _stream()),
+          "bn_bwd_apply")
+    return dc
+
+
+def bn_bwd_from_part(part, nsum, i1, dz, c, saved, rows, C, count, dgamma, dbeta, dc_out=None):
+    """BatchNorm backward when the reduction already happened in a dgrad epilogue: finalize + apply."""
+    L = lib()
+    coef = _empty((3, C), dz)
+    check(L.koaf_bn_bwd_finalize(_ptr(part), part.shape[0], C, count, _ptr(saved[2]), _ptr(saved[1]), _ptr(dgamma),
+                                 _ptr(dbeta), _ptr(coef), nsum, i1, _stream()), "bn_bwd_finalize")
     dc = dc_out if dc_out is not None else torch.empty_like(c)
     check(L.koaf_bn_bwd_apply(_ptr(dz), _ptr(c), _ptr(saved[0]), _ptr(coef), _ptr(dc), rows, C, _stream()),
           "bn_bwd_apply")

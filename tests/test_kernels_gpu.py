@@ -331,3 +331,33 @@ def test_pointwise_loss_adam(dev):
         opt.step()
         ops.adam_step(pd, g[s].to(dev), m, v, n, 1e-3, 0.9, 0.999, 1e-8, 1e-4, s + 1)
     assert rel_err(pd, pr.detach()) < 1e-6
+
+
+@pytest.mark.parametrize("case", [(3, 20, 20, 64, 64, 3, 1, 1), (2, 21, 19, 128, 128, 3, 2, 1), (2, 20, 20, 256, 512, 1, 2, 0),
+                                  (3, 20, 20, 256, 64, 1, 1, 0)])
+@pytest.mark.parametrize("mode,second", [(1, True), (1, False), (2, False)])
+def test_conv2d_dgrad_fused_bn_backward(dev, case, mode, second):
+    """dgrad epilogue = residual add + ReLU mask + BatchNorm-backward column sums (one or two BatchNorms)"""
+    from oaprogressionmmf_amd import ops
+    N, H, W, Cin, Cout, k, s, p = case
+    OH, OW = ops.conv_out(H, k, s, p), ops.conv_out(W, k, s, p)
+    w = rnd(Cout, Cin, k, k, scale=(Cin * k * k) ** -0.5)
+    dy, res = rnd(N, OH, OW, Cout), rnd(N, H, W, Cin)
+    c, y, c2 = rnd(N, H, W, Cin), rnd(N, H, W, Cin), rnd(N, H, W, Cin)
+    sv = torch.stack([rnd(Cin) * 0.3, torch.rand(Cin, generator=G) + 0.5, rnd(Cin) * 0.5 + 1, rnd(Cin) * 0.2])
+    sv2 = torch.stack([rnd(Cin) * 0.3, torch.rand(Cin, generator=G) + 0.5, rnd(Cin), rnd(Cin)])
+    wp = packw(w).to(dev)
+    g = ops.conv2d_dgrad(dy.to(dev), wp, N, H, W, Cin, Cout, k, k, s, p, residual=res.to(dev)).cpu().double()
+    mask = (y > 0) if mode == 1 else ((c * sv[2] + sv[3]) > 0)
+    dz_ref = g * mask
+    xh = (c.double() - sv[0].double()) * sv[1].double()
+    sums = [dz_ref.sum((0, 1, 2)), (dz_ref * xh).sum((0, 1, 2))]
+    bnb = dict(mode=mode, c=c.to(dev), saved=sv.to(dev), y=y.to(dev) if mode == 1 else None)
+    if second:
+        bnb["c2"], bnb["saved2"] = c2.to(dev), sv2.to(dev)
+        sums.append((dz_ref * ((c2.double() - sv2[0].double()) * sv2[1].double())).sum((0, 1, 2)))
+    dz, part = ops.conv2d_dgrad(dy.to(dev), wp, N, H, W, Cin, Cout, k, k, s, p, residual=res.to(dev), bnb=bnb)
+    assert rel_err(dz, dz_ref) < 1e-6
+    assert part.shape[1] == len(sums)
+    for i, ref in enumerate(sums):
+        assert rel_err(part[:, i].double().sum(0), ref) < 2e-5, i
