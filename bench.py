@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", default="", help="write a per-shape table of the instrumented step to this file")
+    ap.add_argument("--serial", action="store_true",
+                    help="one HIP stream only (no encoder lanes / wgrad side stream): kernel durations seen by a profiler "
+                         "are then not inflated by co-running kernels -- the mode the roofline step always uses")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,6 +134,10 @@ def main():
     from oaprogressionmmf_amd.various import dict_losses, dict_optimizers, set_ultimate_seed
 
     set_ultimate_seed()
+    if args.serial:
+        from oaprogressionmmf_amd.models import _common as _c, _encoder as _e
+        _e.USE_SIDE_STREAM = False
+        _c.USE_LANES = False
     cfg, bdef = workload_cfg(args.workload)
     B = args.batch or bdef
     model = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None).to(dev)
