@@ -93,11 +93,17 @@ typedef struct KoafGemm {
     const float* bnb2_mean;
     const float* bnb2_invstd;
     float* bnb_part;
+    /* row-space origin of this launch (mixed-height tiling: one GEMM = a 128-row-tile launch over rows
+       [0, M1) + a 64-row-tile launch over [M1, M)); partial-statistics rows continue at part_row0 */
+    int32_t m_base, part_row0;
 } KoafGemm;
 
 int koaf_gemm(const KoafGemm* g, void* stream);
-/* rows of `stats` koaf_gemm will write for (M, bm) -- callers size the buffer with this */
+/* block tile koaf_gemm picks for (M, N, batch) when bm = bn = 0 */
 int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn);
+/* number of per-tile partial rows (stats / bnb_part) koaf_gemm writes for this descriptor (mixed-height tiling
+ * included); callers size / slice their buffers with it */
+int koaf_gemm_part_rows(const KoafGemm* g);
 /* out[i] = sum_s slabs[s][i], i < n, n % 4 == 0 (deterministic split-K combine).  The slab workspace must
  * hold (nslab + 16) * n floats: large counts are folded in two levels through the 16 trailing slabs. */
 int koaf_slab_reduce(const float* slabs, int32_t nslab, int64_t n, float* out, void* stream);

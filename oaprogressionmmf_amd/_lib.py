@@ -89,6 +89,8 @@ class KoafGemm(ctypes.Structure):
         ("bnb2_mean", ctypes.c_void_p),
         ("bnb2_invstd", ctypes.c_void_p),
         ("bnb_part", ctypes.c_void_p),
+        ("m_base", ctypes.c_int32),
+        ("part_row0", ctypes.c_int32),
     ]
 
 

@@ -234,18 +234,12 @@ extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t
     g.M = (int)M; g.N = Cout; g.K = KH * KW * Cin;
     g.C = y; g.ldc = Cout;
     g.stats = stats;
-    koaf_gemm_pick_tile(&g, &g.bm, &g.bn);
-    if (stats_rows) *stats_rows = (int)cdiv64(M, g.bm);
+    if (stats_rows) *stats_rows = koaf_gemm_part_rows(&g);
     return koaf_gemm(&g, stream);
 }
 
-extern "C" int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout) {
-    KoafGemm g;
-    zero_gemm(&g);
-    g.M = (int)M; g.N = Cout; g.K = 32;
-    koaf_gemm_pick_tile(&g, &g.bm, &g.bn);
-    return (int32_t)cdiv64(M, g.bm);
-}
+// upper bound of the statistics rows koaf_conv2d_fwd writes for M output pixels (64-row tiles everywhere)
+extern "C" int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout) { return (int32_t)cdiv64(M, 64); }
 
 static void set_bnb(KoafGemm* g, const KoafBnb* b, float* part) {
     if (!b) return;
@@ -304,9 +298,8 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
                 g.residual = residual; g.ldr = Cin;
                 g.cmap = 1; g.cm_PH = Hc; g.cm_PW = Wc; g.cm_H = H; g.cm_W = W; g.cm_py = py; g.cm_px = px;
                 if (bnb) {
-                    koaf_gemm_pick_tile(&g, &g.bm, &g.bn);
                     set_bnb(&g, bnb, part + (int64_t)rows_done * nsum * Cin);
-                    rows_done += (int)cdiv64(g.M, g.bm);
+                    rows_done += koaf_gemm_part_rows(&g);
                 }
                 int rc = koaf_gemm(&g, stream);
                 if (rc != KOAF_OK) return rc;
@@ -340,9 +333,8 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
     g.C = dx; g.ldc = Cin;
     g.residual = residual; g.ldr = Cin;
     if (bnb) {
-        koaf_gemm_pick_tile(&g, &g.bm, &g.bn);
         set_bnb(&g, bnb, part);
-        *part_rows = (int)cdiv64(g.M, g.bm);
+        *part_rows = koaf_gemm_part_rows(&g);
     }
     return koaf_gemm(&g, stream);
 }

@@ -49,6 +49,9 @@ struct TileLoader {
     v4l base;          // element offset of each unit's row / image from the operand pointer
     v4i iy0, ix0;
     unsigned rvm;      // row-valid bits
+    v4i toff;          // conv gathers: per-image element offset of the CURRENT filter tap (recomputed per tap,
+    unsigned tvm;      //   not per k-step: a tap spans C/32 k-steps) and its validity bits
+    int tap_cur;
     // KM state
     int col, cc, kh_, kw_;
     unsigned cvm;      // column-valid bits
@@ -59,7 +62,9 @@ struct TileLoader {
         ts4 = th4 = (v4f){0.f, 0.f, 0.f, 0.f};
         rvm = cvm = 0;
         base = (v4l){0, 0, 0, 0};
-        iy0 = ix0 = (v4i){0, 0, 0, 0};
+        iy0 = ix0 = toff = (v4i){0, 0, 0, 0};
+        tvm = 0;
+        tap_cur = -1;
         col = cc = kh_ = kw_ = 0;
         if constexpr (KC) {
 #pragma unroll
@@ -118,14 +123,45 @@ struct TileLoader {
         if constexpr (KC) {
             const int kk = k0 + 4 * (t & 7);
             const bool kok = kk < kend;
-            int ch = kk, kh = 0, kw = 0, coff = k0;
+            int ch = kk, coff = k0;
             if constexpr (MODE != M_KC) {
                 // a 32-wide k chunk lies inside one filter tap (C % 32 == 0)
                 const int tap = k0 / op.C;
                 coff = k0 - tap * op.C;
-                kh = tap / op.KW;
-                kw = tap - kh * op.KW;
                 ch = coff + 4 * (t & 7);
+                if (tap != tap_cur) {          // wave-uniform: new tap -> new source pixel / bounds for every unit
+                    tap_cur = tap;
+                    const int kh = tap / op.KW;
+                    const int kw = tap - kh * op.KW;
+                    tvm = 0;
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) {
+                        int sy, sx;
+                        bool ok = (rvm >> i) & 1u;
+                        if constexpr (MODE == M_KC_G1) {
+                            sy = iy0[i] + kh;
+                            sx = ix0[i] + kw;
+                        } else {
+                            const int ny = iy0[i] - kh, nx = ix0[i] - kw;
+                            ok = ok && ny >= 0 && nx >= 0;
+                            if (op.stride == 1) {
+                                sy = ny;
+                                sx = nx;
+                            } else if (op.stride == 2) {
+                                sy = ny >> 1;
+                                sx = nx >> 1;
+                                ok = ok && (((ny | nx) & 1) == 0);
+                            } else {
+                                sy = ny / op.stride;
+                                sx = nx / op.stride;
+                                ok = ok && (sy * op.stride == ny) && (sx * op.stride == nx);
+                            }
+                        }
+                        ok = ok && (unsigned)sy < (unsigned)op.H && (unsigned)sx < (unsigned)op.W;
+                        toff[i] = (sy * op.W + sx) * op.CS;   // per-image offset fits 32 bits
+                        tvm |= (ok ? 1u : 0u) << i;
+                    }
+                }
             }
             if constexpr (TF) {
                 const float* sc = op.sc + z1 * op.tf_bs;
@@ -160,30 +196,8 @@ struct TileLoader {
                         }
                     }
                 } else {
-                    int sy, sx;
-                    bool ok = rok && kok;
-                    if constexpr (MODE == M_KC_G1) {
-                        sy = iy0[i] + kh;
-                        sx = ix0[i] + kw;
-                    } else {
-                        const int ny = iy0[i] - kh, nx = ix0[i] - kw;
-                        ok = ok && ny >= 0 && nx >= 0;
-                        if (op.stride == 1) {
-                            sy = ny;
-                            sx = nx;
-                        } else if (op.stride == 2) {
-                            sy = ny >> 1;
-                            sx = nx >> 1;
-                            ok = ok && (((ny | nx) & 1) == 0);
-                        } else {
-                            sy = ny / op.stride;
-                            sx = nx / op.stride;
-                            ok = ok && (sy * op.stride == ny) && (sx * op.stride == nx);
-                        }
-                    }
-                    ok = ok && (unsigned)sy < (unsigned)op.H && (unsigned)sx < (unsigned)op.W;
-                    const int off = (sy * op.W + sx) * op.CS + coff;   // per-image offset fits 32 bits
-                    r[i] = *(const v4f*)(ptr + (ok ? base[i] + off : 0));
+                    const bool ok = kok && ((tvm >> i) & 1u);
+                    r[i] = *(const v4f*)(ptr + (ok ? base[i] + (toff[i] + coff) : 0));
                     vm |= (ok ? 1u : 0u) << i;
                 }
             }
@@ -280,7 +294,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     const int ntn = (p.N + BN - 1) / BN;
     const int tn = blockIdx.x % ntn;
     const int tm = blockIdx.x / ntn;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = p.m_base + tm * BM, n0 = tn * BN;
     const int z0 = blockIdx.z / p.nb1, z1 = blockIdx.z - z0 * p.nb1;
     const int split = blockIdx.y;
     const int kchunk = (((p.K + p.splitk - 1) / p.splitk + BK - 1) / BK) * BK;
@@ -481,7 +495,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
             if (rr < nsum && col < p.N) {
                 v4f a = red4[(rr * RPP) * C4 + c4];
                 for (int j = 1; j < RPP; ++j) a += red4[(rr * RPP + j) * C4 + c4];
-                *(v4f*)(p.bnb_part + ((int64_t)tm * nsum + rr) * p.N + col) = a;
+                *(v4f*)(p.bnb_part + ((int64_t)(p.part_row0 + tm) * nsum + rr) * p.N + col) = a;
             }
         }
         if (do_stats) __syncthreads();           // Cs is about to be reused by the statistics reduction
@@ -522,7 +536,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         }
         __syncthreads();
         if (t < BN && (n0 + t) < p.N) {
-            float* st = p.stats + (int64_t)tm * 2 * p.stats_ld + (int64_t)blockIdx.z * p.stats_bs;
+            float* st = p.stats + (int64_t)(p.part_row0 + tm) * 2 * p.stats_ld + (int64_t)blockIdx.z * p.stats_bs;
             st[n0 + t] = red[0 * BN + t] + red[2 * BN + t];
             st[p.stats_ld + n0 + t] = red[1 * BN + t] + red[3 * BN + t];
         }
@@ -634,6 +648,55 @@ extern "C" int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn) 
     return KOAF_OK;
 }
 
+namespace {
+struct TilePlan { int bm, bn; bool vec; int m_split; int part_rows; };   // m_split > 0: mixed-height tiling
+
+bool gemm_vec_ok(const KoafGemm& g) {
+    bool vec = operand_vec_ok(g.A, g.M, g.K) && operand_vec_ok(g.B, g.N, g.K);
+    // vector epilogue: 16-B aligned rows of C / residual / bias
+    if ((g.N & 3) || !aligned16(g.C) || (g.ldc & 3) || (g.cbs0 & 3) || (g.cbs1 & 3)) vec = false;
+    if (g.residual && (!aligned16(g.residual) || (g.ldr & 3) || (g.rbs0 & 3) || (g.rbs1 & 3))) vec = false;
+    if (g.bias && !aligned16(g.bias)) vec = false;
+    return vec;
+}
+
+// g must already have its defaults filled (nb*, splitk, CS, stats_ld)
+TilePlan plan_tiles(const KoafGemm& g) {
+    TilePlan t;
+    const bool autot = (g.bm == 0 && g.bn == 0);
+    KoafGemm q = g;
+    koaf_gemm_pick_tile(&q, &t.bm, &t.bn);
+    t.vec = gemm_vec_ok(g);
+    if (!t.vec) { t.bm = 64; t.bn = 64; }
+    t.m_split = -1;
+    t.part_rows = (int)cdiv64(g.M - g.m_base, t.bm);
+    // Mixed-height tiling.  With 128x128 tiles a CU holds 2 blocks, so T tiles over 256 CUs leave some CUs with
+    // ceil(T/256) tiles while the average is T/256 (800 tiles: 4 vs 3.1 = 78 %).  Run the whole multiples of 512
+    // tiles as 128-row tiles and the remainder as 64-row tiles (half the grain, 3 blocks per CU) in a second
+    // launch over the same row space; epilogue semantics (statistics rows, residual, row map) are per tile and
+    // carry over unchanged.
+    if (autot && t.vec && t.bm == 128 && t.bn == 128 && g.splitk == 1 && g.nb0 * g.nb1 == 1 && g.m_base == 0 &&
+        getenv("KOAF_MIXED_TILES")) {   // opt-in: measured 146.5 ms vs 143.4 ms without on the native step (no gain)
+        const int64_t ntn = cdiv64(g.N, 128), ntm = cdiv64(g.M, 128);
+        const int64_t tm_full = (((ntm * ntn) / 512) * 512) / ntn;     // whole tile-rows inside the full rounds
+        const int64_t rem_tiles = (ntm - tm_full) * ntn;
+        if (rem_tiles > 0 && rem_tiles < 448) {
+            t.m_split = (int)(tm_full * 128);
+            t.part_rows = (int)(tm_full + cdiv64(g.M - t.m_split, 64));
+        }
+    }
+    return t;
+}
+}  // namespace
+
+extern "C" int koaf_gemm_part_rows(const KoafGemm* gp) {
+    KoafGemm g = *gp;
+    if (g.nb0 < 1) g.nb0 = 1;
+    if (g.nb1 < 1) g.nb1 = 1;
+    if (g.splitk < 1) g.splitk = 1;
+    return plan_tiles(g).part_rows;
+}
+
 extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     KoafGemm g = *gp;
     KOAF_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0, "koaf_gemm: bad dims M=%d N=%d K=%d", g.M, g.N, g.K);
@@ -656,31 +719,40 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     KOAF_REQUIRE(!(g.A.kind == 0 && g.A.gather == 3) && !(g.B.kind == 0 && g.B.gather == 3),
                  "koaf_gemm: tapped gather needs a K-major operand");
     KOAF_REQUIRE(!(g.B.kind == 0 && g.B.gather), "koaf_gemm: K-contiguous B cannot be gathered");
-    int bm, bn;
-    koaf_gemm_pick_tile(&g, &bm, &bn);
-    KOAF_REQUIRE((bm == 64 || bm == 128) && (bn == 64 || bn == 128), "koaf_gemm: tile must be 64|128");
-    bool vec = operand_vec_ok(g.A, g.M, g.K) && operand_vec_ok(g.B, g.N, g.K);
-    // vector epilogue: 16-B aligned rows of C / residual / bias
-    if ((g.N & 3) || !aligned16(g.C) || (g.ldc & 3) || (g.cbs0 & 3) || (g.cbs1 & 3)) vec = false;
-    if (g.residual && (!aligned16(g.residual) || (g.ldr & 3) || (g.rbs0 & 3) || (g.rbs1 & 3))) vec = false;
-    if (g.bias && !aligned16(g.bias)) vec = false;
-    KOAF_REQUIRE(!g.cmap || vec, "koaf_gemm: row map needs the vector epilogue");
-    KOAF_REQUIRE(!g.bnb_mode || vec, "koaf_gemm: fused BN-backward needs the vector epilogue");
+    const TilePlan tp = plan_tiles(g);
+    const bool vec = tp.vec;
+    KOAF_REQUIRE((tp.bm == 64 || tp.bm == 128) && (tp.bn == 64 || tp.bn == 128), "koaf_gemm: tile must be 64|128");
     if (g.A.gather || g.B.gather) KOAF_REQUIRE(vec, "koaf_gemm: gathered operands need aligned, C%%32==0 tensors");
     if (g.B.kind == 1 && g.B.gather == 1)
-        KOAF_REQUIRE(g.B.C % bn == 0, "koaf_gemm: wgrad tile (%d) must divide channels per tap (%d)", bn, g.B.C);
-    if (!vec) { bm = 64; bn = 64; }
-    g.bm = bm;
-    g.bn = bn;
-    const int64_t tiles = cdiv64(g.M, bm) * cdiv64(g.N, bn);
-    KOAF_REQUIRE(tiles < (1ll << 31), "koaf_gemm: grid too large");
-    dim3 grid((unsigned)tiles, (unsigned)g.splitk, (unsigned)(g.nb0 * g.nb1));
+        KOAF_REQUIRE(g.B.C % tp.bn == 0, "koaf_gemm: wgrad tile (%d) must divide channels per tap (%d)", tp.bn, g.B.C);
+    KOAF_REQUIRE(!g.cmap || vec, "koaf_gemm: row map needs the vector epilogue");
+    KOAF_REQUIRE(!g.bnb_mode || vec, "koaf_gemm: fused BN-backward needs the vector epilogue");
     hipStream_t s = (hipStream_t)stream;
-    if (!vec) return launch_modes<64, 64, false>(g, grid, s);
-    if (bm == 128 && bn == 128) return launch_modes<128, 128, true>(g, grid, s);
-    if (bm == 128 && bn == 64) return launch_modes<128, 64, true>(g, grid, s);
-    if (bm == 64 && bn == 128) return launch_modes<64, 128, true>(g, grid, s);
-    return launch_modes<64, 64, true>(g, grid, s);
+    auto launch = [&](KoafGemm& q, int qbm, int qbn) -> int {
+        q.bm = qbm;
+        q.bn = qbn;
+        const int64_t tiles = cdiv64(q.M - q.m_base, qbm) * cdiv64(q.N, qbn);
+        if (tiles <= 0) return KOAF_OK;
+        if (tiles >= (1ll << 31)) { koaf_set_error("koaf_gemm: grid too large"); return KOAF_EINVAL; }
+        dim3 grid((unsigned)tiles, (unsigned)q.splitk, (unsigned)(q.nb0 * q.nb1));
+        if (!vec) return launch_modes<64, 64, false>(q, grid, s);
+        if (qbm == 128 && qbn == 128) return launch_modes<128, 128, true>(q, grid, s);
+        if (qbm == 128 && qbn == 64) return launch_modes<128, 64, true>(q, grid, s);
+        if (qbm == 64 && qbn == 128) return launch_modes<64, 128, true>(q, grid, s);
+        return launch_modes<64, 64, true>(q, grid, s);
+    };
+    if (tp.m_split >= 0) {
+        KoafGemm a = g, b = g;
+        if (tp.m_split > 0) {
+            a.M = tp.m_split;
+            int rc = launch(a, 128, 128);
+            if (rc != KOAF_OK) return rc;
+        }
+        b.m_base = tp.m_split;
+        b.part_row0 = g.part_row0 + tp.m_split / 128;
+        return launch(b, 64, 128);
+    }
+    return launch(g, tp.bm, tp.bn);
 }
 
 extern "C" int koaf_slab_reduce(const float* slabs, int32_t nslab, int64_t n, float* out, void* stream) {

@@ -97,25 +97,30 @@ USE_LANES = os.environ.get("KOAF_ENCODER_LANES", "1") != "0"
 
 def run_trunks(jobs):
     """Run independent encoders concurrently, one HIP stream pair ("lane") each.
-    jobs: [(trunk, input, dims_view or None)] -- dims_view None = 2-D radiograph, else the MRI slice fold.
+    jobs: [(trunk, input, dims_view or None[, post])] -- dims_view None = 2-D radiograph, else the MRI slice fold;
+    `post(feature_map)` (optional) runs on the same lane right after the encoder (the per-MRI aggregator of the
+    hierarchical models: small-grid kernels that overlap the other lanes instead of running alone after the join).
     The encoders share nothing but read-only inputs, so their ~160 kernels each interleave on the 256 CUs: one
     lane's HBM-bound BatchNorm kernels and GEMM tails are filled by the other lanes' MFMA blocks.  The caller's
-    stream waits for all lanes before the tokens are consumed; in backward each encoder replays on its lane."""
-    def one(trunk, x, view, lane):
+    stream waits for all lanes before the results are consumed; in backward each node replays on its lane."""
+    def one(job, lane):
+        trunk, x, view = job[0], job[1], job[2]
+        post = job[3] if len(job) > 3 else None
         xin = fold_slices(x, view) if view is not None else x
-        return trunk(xin, lane=lane)
+        out = trunk(xin, lane=lane)
+        return post(out) if post is not None else out
     if not USE_LANES or len(jobs) < 2:
-        return [one(t, x, v, None) for t, x, v in jobs]
+        return [one(j, None) for j in jobs]
     main = torch.cuda.current_stream()
     ev = main.record_event()
     outs = []
     dev = jobs[0][1].device
-    for lane, (trunk, x, view) in enumerate(jobs):
+    for lane, job in enumerate(jobs):
         s, _ = lane_streams(dev, lane)
         s.wait_event(ev)
         with torch.cuda.stream(s):
-            out = one(trunk, x, view, lane)
-        x.record_stream(s)
+            out = one(job, lane)
+        job[1].record_stream(s)
         out.record_stream(main)
         outs.append(out)
     for lane in range(len(jobs)):

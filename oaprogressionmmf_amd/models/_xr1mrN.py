@@ -114,12 +114,13 @@ class XR1MR2CnnTrf(nn.Module):
     def forward(self, input0, input1, input2):
         C.adopt(self, input0, input1, input2)
         B = input0.shape[0]
-        f1, f2, f0 = C.run_trunks([(self._fe1, input1, "rc"), (self._fe2, input2, "rc"), (self._fe0, input0, None)])
+        # each MRI's aggregator runs on its encoder's lane (Q4: its mlp_head0 output is computed and discarded)
+        def agg(drop, feat):
+            return lambda f: feat(C.tokens(drop(f), B))[1]
+        res_agg1, res_agg2, f0 = C.run_trunks([(self._fe1, input1, "rc", agg(self._fe1_drop, self._agg_1)),
+                                               (self._fe2, input2, "rc", agg(self._fe2_drop, self._agg_2)),
+                                               (self._fe0, input0, None)])
         t_fe0 = C.tokens(self._fe0_drop(f0), B)
-        t_fe1 = C.tokens(self._fe1_drop(f1), B)
-        t_fe2 = C.tokens(self._fe2_drop(f2), B)
         # Q4: the reference runs mlp_head0 of the cls-less aggregators and discards it
-        _, res_agg1, _ = self._agg_1(t_fe1)
-        _, res_agg2, _ = self._agg_2(t_fe2)
         res_agg_final, _, _ = self._agg_final(torch.cat([t_fe0, res_agg1, res_agg2], dim=1))
         return C.finish(self.config, res_agg_final.reshape(B, -1))

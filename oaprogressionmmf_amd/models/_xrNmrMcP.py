@@ -82,13 +82,14 @@ class XR1MR2C1CnnTrf(nn.Module):
         C.adopt(self, input0, input1, input2, input3)
         B = input0.shape[0]
         # largest encoder first so the short ones fill its tails
-        f1, f2, f0 = C.run_trunks([(self._fe1, input1, "rc"), (self._fe2, input2, "rc"), (self._fe0, input0, None)])
+        # each MRI's aggregator runs on its encoder's lane (Q4: its mlp_head0 output is computed and discarded)
+        def agg(drop, feat):
+            return lambda f: feat(C.tokens(drop(f), B))[1]
+        res_agg1, res_agg2, f0 = C.run_trunks([(self._fe1, input1, "rc", agg(self._fe1_drop, self._agg_1)),
+                                               (self._fe2, input2, "rc", agg(self._fe2_drop, self._agg_2)),
+                                               (self._fe0, input0, None)])
         t_fe0 = C.tokens(self._fe0_drop(f0), B)
-        t_fe1 = C.tokens(self._fe1_drop(f1), B)
-        t_fe2 = C.tokens(self._fe2_drop(f2), B)
         t_fe3 = self._fe3_drop(self._fe3(input3))
-        _, res_agg1, _ = self._agg_1(t_fe1)
-        _, res_agg2, _ = self._agg_2(t_fe2)
         t_fe_m = torch.cat([t_fe0, res_agg1, res_agg2, t_fe3], dim=1)
         res_agg_final, _, _ = self._agg_final(t_fe_m)
         return C.finish(self.config, res_agg_final.reshape(B, -1))

@@ -75,7 +75,7 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
                             _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _stream()), "conv2d_fwd")
     _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin, f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}")
     if stats:
-        assert rows.value == part.shape[0], (rows.value, part.shape)
+        part = part[:rows.value]
     return y, part
 
 
