@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", default="", help="write a per-shape table of the instrumented step to this file")
+    ap.add_argument("--recompute", action="store_true",
+                    help="stage-level activation recompute in the encoders (keeps stage inputs + BatchNorm statistics only); "
+                         "needed for --workload syn at batch 8")
     ap.add_argument("--serial", action="store_true",
                     help="one HIP stream only (no encoder lanes / wgrad side stream): kernel durations seen by a profiler "
                          "are then not inflated by co-running kernels -- the mode the roofline step always uses")
@@ -141,6 +144,11 @@ def main():
     cfg, bdef = workload_cfg(args.workload)
     B = args.batch or bdef
     model = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None).to(dev)
+    if args.recompute:
+        from oaprogressionmmf_amd.models import KoafTrunk
+        for m in model.modules():
+            if isinstance(m, KoafTrunk):
+                m.recompute = True
     ddp = DataParallelRCCL(model)
     loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
     opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4)
@@ -217,9 +225,9 @@ def main():
                                    f"per-GPU batch {B}, global batch {world * B}, "
                                    + {"native": "XR 1x350x350 + DESS 160x160x64 + T2 160x160x25 + 9 clinical; random-init weights",
                                       "syn": "BASELINE synthetic shapes XR 1x310x310 + 2 x MRI 1x160x384x384 + 9 clinical "
-                                             "(per-GPU batch 2: batch 8 at these shapes needs activation recompute, not built); "
+                                             "(default per-GPU batch 2; batch 8 with --recompute); "
                                              "random-init weights"}.get(args.workload, "random-init weights"),
-                       "parallelism": f"dp{world}", "last_loss": round(lv, 6)},
+                       "parallelism": f"dp{world}", "last_loss": round(lv, 6), "activation_recompute": bool(args.recompute)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                          "kernel": "koaf_gemm_kernel (fp32 MFMA implicit GEMM: conv fwd/dgrad/wgrad, linear, attention)",

@@ -109,7 +109,9 @@ def run_trunks(jobs):
         xin = fold_slices(x, view) if view is not None else x
         out = trunk(xin, lane=lane)
         return post(out) if post is not None else out
-    if not USE_LANES or len(jobs) < 2:
+    # activation recompute trades memory for FLOPs; concurrent lanes would hold several stages' rebuilt
+    # activations at once and defeat it, so recomputing trunks run one after the other
+    if not USE_LANES or len(jobs) < 2 or any(getattr(j[0], "recompute", False) for j in jobs):
         return [one(j, None) for j in jobs]
     main = torch.cuda.current_stream()
     ev = main.record_event()

@@ -207,6 +207,45 @@ def _tail_bnb(prev):
     return d
 
 
+def _block_fwd(blk, y, N, Hc, Wc, train, given):
+    """Forward of one residual block.  given = None: statistics are collected by the conv epilogues and
+    finalised (normal forward).  given = (s1, s2, s3, sd): activation RECOMPUTE in backward -- the saved
+    BatchNorm statistics are reused, nothing is reduced and no running statistic is touched."""
+    r = _Rec()
+    r.blk, r.yin = blk, y
+    want = train and given is None
+
+    def fin(bn, part, count, idx):
+        return given[idx] if given is not None else _bn_fin(bn, part, count)
+    if isinstance(blk, Bottleneck):
+        r.kind = "bottleneck"
+        r.c1, part, _, _, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, want)
+        r.s1 = fin(blk.bn1, part, N * Hc * Wc, 0)
+        r.c2, part, OH, OW, r.wexp = _conv_fwd(r.c1, blk.conv2, N, Hc, Wc, r.s1, want)
+        r.s2 = fin(blk.bn2, part, N * OH * OW, 1)
+        r.c3, part, _, _, _ = _conv_fwd(r.c2, blk.conv3, N, OH, OW, r.s2, want)
+        r.s3 = fin(blk.bn3, part, N * OH * OW, 2)
+        last_c, last_s, cout = r.c3, r.s3, blk.conv3.out_channels
+    elif isinstance(blk, BasicBlock):
+        r.kind = "basic"
+        r.c1, part, OH, OW, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, want)
+        r.s1 = fin(blk.bn1, part, N * OH * OW, 0)
+        r.c2, part, _, _, _ = _conv_fwd(r.c1, blk.conv2, N, OH, OW, r.s1, want)
+        r.s2 = fin(blk.bn2, part, N * OH * OW, 1)
+        last_c, last_s, cout = r.c2, r.s2, blk.conv2.out_channels
+    else:
+        raise TypeError(f"unsupported block {type(blk)}")
+    rows_o = N * OH * OW
+    if blk.downsample is not None:
+        r.cd, part, _, _, _ = _conv_fwd(y, blk.downsample[0], N, Hc, Wc, None, want)
+        r.sd = fin(blk.downsample[1], part, rows_o, 3)
+        r.y = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=r.cd, idsaved=r.sd)
+    else:
+        r.y = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=y)
+    r.dims = (N, Hc, Wc, OH, OW)
+    return r
+
+
 class EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, trunk, anchor, keep, lane):
@@ -227,48 +266,26 @@ class EncoderFn(torch.autograd.Function):
         s0 = _bn_fin(bn1, part, N * H1 * W1)
         y, am = ops.maxpool_fwd(c0, s0, N, H1, W1, 64)
         Hc, Wc = y.shape[1], y.shape[2]
-        recs = []
-        for blk in st["blocks"]:
-            r = _Rec()
-            r.blk, r.yin = blk, y
-            if isinstance(blk, Bottleneck):
-                r.kind = "bottleneck"
-                r.c1, part, _, _, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, train)
-                r.s1 = _bn_fin(blk.bn1, part, N * Hc * Wc)
-                r.c2, part, OH, OW, r.wexp = _conv_fwd(r.c1, blk.conv2, N, Hc, Wc, r.s1, train)
-                r.s2 = _bn_fin(blk.bn2, part, N * OH * OW)
-                r.c3, part, _, _, _ = _conv_fwd(r.c2, blk.conv3, N, OH, OW, r.s2, train)
-                r.s3 = _bn_fin(blk.bn3, part, N * OH * OW)
-                last_c, last_s, cout = r.c3, r.s3, blk.conv3.out_channels
-            elif isinstance(blk, BasicBlock):
-                r.kind = "basic"
-                r.c1, part, OH, OW, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, train)
-                r.s1 = _bn_fin(blk.bn1, part, N * OH * OW)
-                r.c2, part, _, _, _ = _conv_fwd(r.c1, blk.conv2, N, OH, OW, r.s1, train)
-                r.s2 = _bn_fin(blk.bn2, part, N * OH * OW)
-                last_c, last_s, cout = r.c2, r.s2, blk.conv2.out_channels
-            else:
-                raise TypeError(f"unsupported block {type(blk)}")
-            rows_o = N * OH * OW
-            if blk.downsample is not None:
-                r.cd, part, _, _, _ = _conv_fwd(y, blk.downsample[0], N, Hc, Wc, None, train)
-                r.sd = _bn_fin(blk.downsample[1], part, rows_o)
-                ynew = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=r.cd, idsaved=r.sd)
-            else:
-                ynew = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=y)
-            r.y = ynew
-            r.dims = (N, Hc, Wc, OH, OW)
-            y, Hc, Wc = ynew, OH, OW
-            if keep:
-                recs.append(r)
+        recs, ck = [], []
+        recompute = bool(getattr(trunk, "recompute", False)) and keep
+        for stage in st["stages"]:
+            cks = dict(yin=y, H=Hc, W=Wc, stats=[])
+            for blk in stage:
+                r = _block_fwd(blk, y, N, Hc, Wc, train, None)
+                y, Hc, Wc = r.y, r.dims[3], r.dims[4]
+                if keep and not recompute:
+                    recs.append(r)
+                elif recompute:
+                    cks["stats"].append((r.s1, r.s2, r.s3, r.sd))
+            ck.append(cks)
         C = y.shape[-1]
         if st["gap"]:
             out = ops.gap_fwd(y, N, Hc * Wc, C).view(N, C, 1, 1)
         else:
             out = y.permute(0, 3, 1, 2)  # (N,C,h,w) view of the NHWC buffer
         if keep:
-            ctx.state = dict(x=x, c0=c0, s0=s0, am=am, recs=recs, dims=(N, H, W, H1, W1), last=(Hc, Wc, C),
-                             st=st, lane=lane)
+            ctx.state = dict(x=x, c0=c0, s0=s0, am=am, recs=recs, ck=ck if recompute else None,
+                             dims=(N, H, W, H1, W1), last=(Hc, Wc, C), st=st, lane=lane, train=train)
         return out
 
     @staticmethod
@@ -291,18 +308,8 @@ class EncoderFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def _backward_body(S, gout, side_stream):
-        st = S["st"]
-        N, H, W, H1, W1 = S["dims"]
-        Hc, Wc, C = S["last"]
-        if st["gap"]:
-            dy = ops.gap_bwd(gout.reshape(N, C).contiguous(), N, Hc * Wc, C).view(N, Hc, Wc, C)
-        else:
-            dy = gout.permute(0, 2, 3, 1).contiguous()
-            if dy.data_ptr() == gout.data_ptr():
-                dy = dy.clone()  # masked in place below
-        recs = S["recs"]
-        side = _SideStream(gout.device, side_stream) if USE_SIDE_STREAM else None
+    def _blocks_bwd(recs, dy, side):
+        """backward through a list of block records (last first); returns the gradient w.r.t. the first block's input"""
         pend = None   # (part, nsum) of THIS block's tail when the previous dgrad's epilogue already reduced it
         while recs:
             r = recs.pop()
@@ -369,6 +376,37 @@ class EncoderFn(torch.autograd.Function):
             else:
                 dy, pend = res, None
             del dc1, da1, dz, resid, r
+        return dy
+
+    @staticmethod
+    def _backward_body(S, gout, side_stream):
+        st = S["st"]
+        N, H, W, H1, W1 = S["dims"]
+        Hc, Wc, C = S["last"]
+        if st["gap"]:
+            dy = ops.gap_bwd(gout.reshape(N, C).contiguous(), N, Hc * Wc, C).view(N, Hc, Wc, C)
+        else:
+            dy = gout.permute(0, 2, 3, 1).contiguous()
+            if dy.data_ptr() == gout.data_ptr():
+                dy = dy.clone()  # masked in place below
+        side = _SideStream(gout.device, side_stream) if USE_SIDE_STREAM else None
+        if S["ck"] is None:
+            dy = EncoderFn._blocks_bwd(S["recs"], dy, side)
+        else:
+            # stage-level activation recompute: only the stage inputs and the BatchNorm statistics were kept; the
+            # stage's conv outputs are rebuilt (same kernels, saved statistics, no reductions) right before use
+            stages = st["stages"]
+            for si in range(len(stages) - 1, -1, -1):
+                cks = S["ck"][si]
+                y, Hc2, Wc2 = cks["yin"], cks["H"], cks["W"]
+                recs = []
+                for blk, given in zip(stages[si], cks["stats"]):
+                    r = _block_fwd(blk, y, N, Hc2, Wc2, S["train"], given)
+                    recs.append(r)
+                    y, Hc2, Wc2 = r.y, r.dims[3], r.dims[4]
+                cks["yin"] = None
+                dy = EncoderFn._blocks_bwd(recs, dy, side)
+                del recs, r, y
         # stem: max-pool, BN0, conv1 weight gradient (no data gradient: the input is a leaf)
         conv1, bn1 = st["conv1"], st["bn1"]
         da0 = ops.maxpool_bwd(dy, S["am"], N, H1, W1, 64)
@@ -399,16 +437,17 @@ class KoafTrunk(nn.Sequential):
         c1 = ch[0]
         if c1.kernel_size != (7, 7) or c1.stride != (2, 2) or c1.padding != (3, 3) or c1.out_channels != 64:
             raise NotImplementedError("stem other than 7x7/s2/p3 -> 64 is not built")
-        blocks = []
+        blocks, stages = [], []
         gap = False
         for m in ch[4:]:
             if isinstance(m, nn.Sequential):
                 blocks.extend(list(m.children()))
+                stages.append(list(m.children()))
             elif isinstance(m, nn.AdaptiveAvgPool2d):
                 gap = True
             else:
                 raise TypeError(f"unexpected trunk child {type(m)}")
-        lay = dict(conv1=ch[0], bn1=ch[1], blocks=blocks, gap=gap)
+        lay = dict(conv1=ch[0], bn1=ch[1], blocks=blocks, stages=stages, gap=gap)
         self.__dict__["_koaf_lay"] = lay
         return lay
 

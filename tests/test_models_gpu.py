@@ -193,3 +193,30 @@ def test_losses_interp_vs_reference(dev):
     v = t(P.make_input("interp_mr", (2, 1, 36, 28, 26))).to(dev)
     assert rel(PTInterpolate((0.5, 0.5, 0.5))(v).cpu().numpy(), g["mr_half"]) < 1e-6
     assert rel(PTInterpolate((0.5, 0.5, 1.0))(v).cpu().numpy(), g["mr_keep"]) < 1e-6
+
+
+def test_stage_recompute_matches_stored_activations(dev):
+    """stage-level activation recompute (KoafTrunk.recompute) rebuilds the same conv outputs with the saved
+    BatchNorm statistics: outputs bit-identical, gradients equal up to the summation order of the few
+    BatchNorm reductions that are fused differently at stage boundaries (1e-5), running statistics untouched"""
+    from oaprogressionmmf_amd.models._core_fes import dict_fes
+    from oaprogressionmmf_amd.models._encoder import KoafTrunk
+    for arch, shape in (("resnet50", (3, 1, 96, 112)), ("resnext50_32x4d", (2, 1, 96, 96)), ("resnet18", (2, 1, 64, 96))):
+        res = []
+        for rc in (False, True):
+            net = dict_fes[arch](pretrained=False)
+            trunk = KoafTrunk(*list(net.children())[:-1])
+            P.fill_state_dict(trunk.state_dict())
+            trunk = trunk.to(dev).train()
+            trunk.recompute = rc
+            x = t(P.make_input("trunk", shape)).to(dev)
+            y = trunk(x)
+            (y * t(P.make_input("trunkg", tuple(y.shape))).to(dev)).sum().backward()
+            res.append((y.detach().clone(), {k: p.grad.clone() for k, p in trunk.named_parameters()},
+                        {k: b.clone() for k, b in trunk.named_buffers()}))
+        (y0, g0, b0), (y1, g1, b1) = res
+        assert torch.equal(y0, y1)
+        for k in b0:
+            assert torch.equal(b0[k], b1[k]), k
+        for k in g0:
+            assert rel(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 1e-5, (arch, k)
