@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- knees/sec of the full XR + MRI + clinical fusion train step (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload native|syn|xr1cnn|mr1] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload W] [--batch B] [--recompute]
   (N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
 A "step" is one iteration of the reference's step body (koafusion/run/train_prog_fus.py:132-168) on one
@@ -10,11 +10,17 @@ FocalLoss -> loss.item() (the reference's per-step host sync) -> backward -> gra
 (N>1) -> fused Adam.  Weak scaling: the per-GPU batch is fixed, `value` = global samples / max-over-ranks time.
 
 Workloads:
-  native (default)  XR1MR2C1CnnTrf exactly as runner.sh:341-363 (the reference's biggest registered model, the
-                    oracle-pinned mapping of BASELINE config 4): XR 1x350x350 (ResNeXt-50), SAG-3D-DESS 160x160x64 and
-                    SAG-T2-MAP 160x160x25 (ResNet-50 slice-wise), 9 clinical variables, 3 x FeaT(depth 4, 8 heads,
-                    width 2048); per-GPU batch 8.
-  xr1cnn / mr1      BASELINE configs 1 / 3 analogues (XR1Cnn B=4 @350^2; MR1CnnTrf B=4 @160x160x64).
+  native3 (default) BASELINE config 4 literally -- "Full XR + SAG-DESS/COR-IW-TSE/SAG-T2 + clinical transformer fusion,
+                    batch 8": the registry extension XR1MR3C1CnnTrf (the reference's XR1MR2C1CnnTrf pattern with a third
+                    MRI slot) at the reference's native sizes: XR 1x350x350 (ResNeXt-50), DESS 160x160x64, TSE 160x160x32,
+                    T2 160x160x25 (ResNet-50 slice-wise), 9 clinical variables, 4 x FeaT(depth 4, 8 heads, width 2048).
+                    The same run also times `native` and reports it under "pinned_reference_model".
+  native            XR1MR2C1CnnTrf exactly as runner.sh:341-363 (the reference's biggest registered model, the
+                    reference-pinned 2-MRI mapping of config 4): XR 350^2 + DESS 160x160x64 + T2 160x160x25 + clinical; B=8.
+  syn / syn3        BASELINE's synthetic tensor shapes (XR 1x310x310, MRI 1x160x384x384) through the 2-MRI / 3-MRI model
+                    (default per-GPU batch 2; batch 8 needs --recompute).
+  xr1cnn / xr1c1    BASELINE configs 1 / 2 (XR1Cnn B=4; extension XR1C1Cnn = XR + clinical MLP head, B=32) @350^2.
+  mr1 / mr1c1       BASELINE config 3: MR1CnnTrf B=4 @160x160x64; extension MR1C1CnnTrf (DESS + clinical) B=4 @384x384x160.
 The JSON line carries `roofline` for the dominant kernel (the fp32 MFMA GEMM, timed live with events on the
 launch stream over one extra instrumented step) and `cpu_baseline` (the oracle = CPU port of the same step,
 timed on this box's host cores on a bounded sample).
@@ -46,6 +52,18 @@ def workload_cfg(name):
         cfg = P.cfg_full(xr=(320, 320), mr1=(320, 320, 160), mr2=(320, 320, 160), dropout=0.1)
         cfg["_tensor_shapes"] = [[310, 310], [384, 384, 160], [384, 384, 160], [16]]
         return cfg, 2
+    if name == "native3":
+        return P.cfg_xr1mr3c1(dropout=0.1), 8
+    if name == "syn3":
+        cfg = P.cfg_xr1mr3c1(xr=(320, 320), mr1=(320, 320, 160), mr2=(320, 320, 160), mr3=(320, 320, 160), dropout=0.1)
+        cfg["_tensor_shapes"] = [[310, 310], [384, 384, 160], [384, 384, 160], [384, 384, 160], [16]]
+        return cfg, 2
+    if name == "xr1c1":
+        return P.cfg_xr1c1(size=350, dropout=0.5), 32
+    if name == "mr1c1":
+        cfg = P.cfg_mr1c1(mr=(320, 320, 160), dropout=0.1)
+        cfg["_tensor_shapes"] = [[384, 384, 160], [16]]
+        return cfg, 4
     if name == "xr1cnn":
         return P.cfg_xr1cnn(size=350, dropout=0.5), 4
     if name == "mr1":
@@ -55,16 +73,21 @@ def workload_cfg(name):
 
 def algorithmic_train_gflop_per_sample(name):
     # measured with torch.utils.flop_counter on the imported reference
+    # (ResNet-50 4.1705 GFLOP/slice @160^2, 24.02 @384^2; ResNeXt-50 20.877 @350^2, 16.84 @310^2; FeaT 0.2097/token)
     return {"native": 1280.0, "xr1cnn": 62.1, "mr1": 3 * (64 * 4.1705 + 65 * 0.2097),
-            "syn": 3 * (16.84 + 320 * 24.02 + 641 * 0.2097)}[name]
+            "native3": 1280.0 + 3 * (32 * 4.1705 + 64 * 0.2097),
+            "syn": 3 * (16.84 + 320 * 24.02 + 641 * 0.2097),
+            "syn3": 3 * (16.84 + 480 * 24.02 + 963 * 0.2097),
+            "xr1c1": 62.1 + 3 * 2 * (9 * 2048 + 2048 * 512) / 1e9,
+            "mr1c1": 3 * (160 * 24.02 + 322 * 0.2097)}[name]
 
 
 def cpu_baseline(cfg, workload):
     """The oracle (CPU port of the same train step) on this box's host cores; bounded sample."""
     import procedural as P
     from oracle import koafusion_cpu as O
-    if workload == "syn":
-        return None     # ~200 s per sample on a host CPU: outside the bounded-sample budget
+    if workload in ("syn", "syn3", "mr1c1"):
+        return None     # minutes per sample on a host CPU: outside the bounded-sample budget
     B = 1
     n = min(len(os.sched_getaffinity(0)), 64)
     torch.set_num_threads(n)
@@ -80,7 +103,7 @@ def cpu_baseline(cfg, workload):
     xs = [torch.from_numpy(a) for a in P.model_inputs(cfg, B)]
     y = torch.from_numpy(P.make_target("target", B))
     om.train_step(xs, y)                     # warm-up
-    steps = 2 if workload == "native" else 3
+    steps = 2 if workload in ("native", "native3") else 3
     t0 = time.time()
     for _ in range(steps):
         om.train_step(xs, y)
@@ -95,7 +118,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="native")
+    ap.add_argument("--workload", default="native3")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", default="", help="write a per-shape table of the instrumented step to this file")
@@ -141,50 +164,74 @@ def main():
         from oaprogressionmmf_amd.models import _common as _c, _encoder as _e
         _e.USE_SIDE_STREAM = False
         _c.USE_LANES = False
-    cfg, bdef = workload_cfg(args.workload)
-    B = args.batch or bdef
-    model = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None).to(dev)
-    if args.recompute:
-        from oaprogressionmmf_amd.models import KoafTrunk
-        for m in model.modules():
-            if isinstance(m, KoafTrunk):
-                m.recompute = True
-    ddp = DataParallelRCCL(model)
-    loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
-    opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4)
-    shapes_cfg = dict(cfg, input_size=cfg.pop("_tensor_shapes")) if "_tensor_shapes" in cfg else cfg
-    xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(shapes_cfg, B, seed=1234 + rank)]
-    y = torch.from_numpy(P.make_target("target", B, seed=1234 + rank)).to(dev)
-    model.train()
-
-    def step():
-        opt.zero_grad()
-        logits = ddp(*xs)["main"]
-        loss = loss_fn(input=logits.squeeze(1), target=y.long().squeeze(1))
-        ddp.scale_loss(loss).backward()
-        ddp.reduce_gradients()
-        opt.step()
-        # the reference logs loss.item() every step (:159-163): same value, read after the backward/optimizer
-        # kernels are enqueued so the host sync does not drain the GPU between forward and backward
-        return loss.item()
-
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        lv = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    def make_job(name, batch):
+        """model + optimizer + resident synthetic batch of one workload -> (cfg, B, step)"""
+        cfg, bdef = workload_cfg(name)
+        B = batch or bdef
+        model = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None).to(dev)
+        if args.recompute:
+            from oaprogressionmmf_amd.models import KoafTrunk
+            for m in model.modules():
+                if isinstance(m, KoafTrunk):
+                    m.recompute = True
+        ddp = DataParallelRCCL(model)
+        loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
+        opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4)
+        shapes_cfg = dict(cfg, input_size=cfg.pop("_tensor_shapes")) if "_tensor_shapes" in cfg else cfg
+        xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(shapes_cfg, B, seed=1234 + rank)]
+        y = torch.from_numpy(P.make_target("target", B, seed=1234 + rank)).to(dev)
+        model.train()
+
+        def step():
+            opt.zero_grad()
+            logits = ddp(*xs)["main"]
+            loss = loss_fn(input=logits.squeeze(1), target=y.long().squeeze(1))
+            ddp.scale_loss(loss).backward()
+            ddp.reduce_gradients()
+            opt.step()
+            # the reference logs loss.item() every step (:159-163): same value, read after the backward/optimizer
+            # kernels are enqueued so the host sync does not drain the GPU between forward and backward
+            return loss.item()
+        return cfg, B, step
+
+    def timed(step):
+        """W untimed + exactly K timed steps between barriers; max over ranks"""
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lv = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, lv
+
+    pinned = None
+    if args.workload == "native3" and not args.batch and not args.recompute:
+        # the reference-pinned 2-MRI model of the same configuration, timed first with the same K / W, then freed
+        cfg2, B2, step2 = make_job("native", 0)
+        dt2, lv2 = timed(step2)
+        pinned = {"model": cfg2["name"], "value": round(world * B2 * args.steps / dt2, 3), "unit": "knees/s",
+                  "ms_per_step": round(dt2 / args.steps * 1e3, 2), "per_gpu_batch": B2, "last_loss": round(lv2, 6),
+                  "note": "runner.sh:341-363 (XR 350^2 + DESS 160x160x64 + T2 160x160x25 + clinical): the largest model "
+                          "the reference registers; parity pinned by fixtures of the imported reference"}
+        del step2
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    cfg, B, step = make_job(args.workload, args.batch)
+    dt, lv = timed(step)
 
     # one extra instrumented step: live event timing of every MFMA-GEMM launch on its launch stream
     from oaprogressionmmf_amd.models import _common, _encoder
@@ -224,10 +271,18 @@ def main():
             "config": {"workload": f"{args.workload}: {cfg['name']} train step (fwd+FocalLoss+bwd+Adam), "
                                    f"per-GPU batch {B}, global batch {world * B}, "
                                    + {"native": "XR 1x350x350 + DESS 160x160x64 + T2 160x160x25 + 9 clinical; random-init weights",
+                                      "native3": "XR 1x350x350 + DESS 160x160x64 + TSE 160x160x32 + T2 160x160x25 + 9 clinical "
+                                                 "(BASELINE config 4; 3-MRI registry extension of the reference's "
+                                                 "XR1MR2C1CnnTrf); random-init weights",
+                                      "syn3": "BASELINE synthetic shapes XR 1x310x310 + 3 x MRI 1x160x384x384 + 9 clinical; "
+                                              "random-init weights",
+                                      "xr1c1": "BASELINE config 2: XR 1x350x350 + 9 clinical, early-fusion MLP head; random-init weights",
+                                      "mr1c1": "BASELINE config 3: SAG-3D-DESS 1x160x384x384 + 9 clinical; random-init weights",
                                       "syn": "BASELINE synthetic shapes XR 1x310x310 + 2 x MRI 1x160x384x384 + 9 clinical "
                                              "(default per-GPU batch 2; batch 8 with --recompute); "
                                              "random-init weights"}.get(args.workload, "random-init weights"),
                        "parallelism": f"dp{world}", "last_loss": round(lv, 6), "activation_recompute": bool(args.recompute)},
+            **({"pinned_reference_model": pinned} if pinned else {}),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                          "kernel": "koaf_gemm_kernel (fp32 MFMA implicit GEMM: conv fwd/dgrad/wgrad, linear, attention)",

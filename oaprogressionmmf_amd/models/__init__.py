@@ -7,6 +7,7 @@ from ._mrN_cnn_trf import MR1CnnTrf, MR2CnnTrf
 from ._xr1_cnn import XR1Cnn
 from ._xr1mrN import XR1MR1CnnTrf, XR1MR2CnnTrf
 from ._xrNmrMcP import FeatC1, XR1MR2C1CnnTrf
+from ._ext import MR1C1CnnTrf, XR1C1Cnn, XR1MR3C1CnnTrf
 
 dict_models = {
     "XR1Cnn": XR1Cnn,
@@ -16,3 +17,11 @@ dict_models = {
     "XR1MR2CnnTrf": XR1MR2CnnTrf,
     "XR1MR2C1CnnTrf": XR1MR2C1CnnTrf,
 }
+REFERENCE_MODELS = tuple(dict_models)        # the reference's registry keys (koafusion/models/__init__.py:8-15)
+
+# extensions for the BASELINE.json configurations without a reference class (see _ext.py)
+dict_models.update({
+    "XR1C1Cnn": XR1C1Cnn,
+    "MR1C1CnnTrf": MR1C1CnnTrf,
+    "XR1MR3C1CnnTrf": XR1MR3C1CnnTrf,
+})

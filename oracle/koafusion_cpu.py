@@ -155,6 +155,8 @@ def model_spec(cfg):
         spec = trunk_spec("_fe0", fe["arch"]) + trunk_spec("_fe1", fe["arch"])
         spec += feat_spec("_agg", vs["agg_in_len"], vs["agg_in_depth"], a["depth"], a["mlp_dim"], ncls, True)
         return spec, vs
+    if name in EXT_MODELS:
+        return _ext_spec(cfg)
     # XR + MRI families: _xr1mrN.py:11-103,160-300 ; _xrNmrMcP.py:32-182
     fe = cfg["fe"]
     n_mr = {"XR1MR1CnnTrf": 1, "XR1MR2CnnTrf": 2, "XR1MR2C1CnnTrf": 2}[name]
@@ -194,6 +196,70 @@ def model_spec(cfg):
         tot = vs["agg_in_len_0"] + vs["agg_in_len_1"] + vs["agg_in_len_2"] + (vs["agg_in_len_3"] if has_clin else 0)
         spec += feat_spec("_agg_final", tot, d, a["depth"], a["mlp_dim"], ncls, True)
     return spec, vs
+
+
+# Extensions (no reference class; oaprogressionmmf_amd/models/_ext.py states the definitions): built from the
+# reference's blocks only, so every sub-block is pinned -- the compositions are not.  (n_xr, n_mr); XR1C1Cnn apart.
+EXT_MODELS = {"XR1C1Cnn": None, "MR1C1CnnTrf": (0, 1), "XR1MR3C1CnnTrf": (1, 3)}
+
+
+def _ext_spec(cfg):
+    name, fe, a, ncls = cfg["name"], cfg["fe"], cfg["agg"], cfg["output_channels"]
+    vs = {}
+    if name == "XR1C1Cnn":
+        arch = fe["xr"]["arch"]
+        n = OUT_CH[arch] + fe["clin"]["dim_out"]
+        vs.update(fe_out_ch=OUT_CH[arch], agg_in_len=n)
+        spec = trunk_spec("_fe", arch) + _lin_spec("_fe_clin._fe.0", fe["clin"]["dim_out"], fe["clin"]["dim_in"])
+        spec += _lin_spec("_agg.1", a["hidden_size"], n) + _lin_spec("_final", ncls, a["hidden_size"])
+        return spec, vs
+    nx, nm = EXT_MODELS[name]
+    n_in = nx + nm + 1
+    d = OUT_CH[fe["mr"]["arch"]]
+    spec = []
+    for i in range(n_in):
+        s = _shape_in(cfg, i)
+        vs[f"fe{i}_shape_in"] = s
+        if i < nx:
+            spec += trunk_spec(f"_fe{i}", fe["xr"]["arch"])
+            vs[f"fe{i}_out_ch"] = OUT_CH[fe["xr"]["arch"]]
+            vs[f"fe{i}_out_spat"] = (1, 1) if fe["xr"]["with_gap"] else tuple(SPAT[e] for e in s)
+            vs[f"agg_in_len_{i}"] = math.prod(vs[f"fe{i}_out_spat"])
+        elif i < nx + nm:
+            spec += trunk_spec(f"_fe{i}", fe["mr"]["arch"])
+            vs[f"fe{i}_out_ch"] = d
+            vs[f"fe{i}_out_spat"] = (1, 1) if fe["mr"]["with_gap"] else tuple(SPAT[e] for e in s[:2])
+            vs[f"agg_in_len_{i}"] = a["num_slices"][i] * math.prod(vs[f"fe{i}_out_spat"])
+        else:
+            spec += _lin_spec(f"_fe{i}._fe.0", fe["clin"]["dim_out"], fe["clin"]["dim_in"])
+            vs[f"fe{i}_out_spat"] = (1,)
+            vs[f"agg_in_len_{i}"] = a["num_slices"][i]
+    vs["agg_in_depth"] = d
+    for i in range(nx, nx + nm):
+        spec += feat_spec(f"_agg_{i}", vs[f"agg_in_len_{i}"], d, a["depth"], a["mlp_dim"], ncls, False)
+    tot = sum(vs[f"agg_in_len_{i}"] for i in range(n_in))
+    spec += feat_spec("_agg_final", tot, d, a["depth"], a["mlp_dim"], ncls, True)
+    return spec, vs
+
+
+def _ext_forward(cfg, sd, inputs, train):
+    name, fe, a = cfg["name"], cfg["fe"], cfg["agg"]
+    b = inputs[0].shape[0]
+    if name == "XR1C1Cnn":
+        f = trunk(inputs[0], sd, "_fe", fe["xr"]["arch"], train).flatten(1)
+        c = F.gelu(F.linear(inputs[1], sd["_fe_clin._fe.0.weight"], sd["_fe_clin._fe.0.bias"])).flatten(1)
+        h = torch.relu(F.linear(torch.cat([f, c], 1), sd["_agg.1.weight"], sd["_agg.1.bias"]))
+        return F.linear(h, sd["_final.weight"], sd["_final.bias"])
+    nx, nm = EXT_MODELS[name]
+    gap = bool((nx and fe["xr"]["with_gap"]) or fe["mr"]["with_gap"])
+    toks = [_tok(trunk(inputs[i], sd, f"_fe{i}", fe["xr"]["arch"], train, gap), b) for i in range(nx)]
+    for i in range(nx, nx + nm):
+        t = _tok(trunk(_fold(inputs[i]), sd, f"_fe{i}", fe["mr"]["arch"], train, gap), b)
+        toks.append(feat(t, sd, f"_agg_{i}", a["depth"], a["heads"], False)[1])
+    i = nx + nm
+    toks.append(F.gelu(F.linear(inputs[i], sd[f"_fe{i}._fe.0.weight"], sd[f"_fe{i}._fe.0.bias"])))
+    out, _, _ = feat(torch.cat(toks, 1), sd, "_agg_final", a["depth"], a["heads"], True)
+    return out.reshape(b, -1)
 
 
 def new_state(cfg, fill=None, dtype=torch.float32):
@@ -354,6 +420,8 @@ def forward(cfg, sd, inputs, train):
         f1 = _tok(trunk(_fold(inputs[1]), sd, "_fe1", fe["arch"], train, fe["with_gap"]), b)
         out, _, _ = feat(torch.cat([f0, f1], 1), sd, "_agg", a["depth"], a["heads"], True)
         return out.reshape(b, -1)
+    if name in EXT_MODELS:
+        return _ext_forward(cfg, sd, inputs, train)
     fe = cfg["fe"]
     gap = bool(fe["xr"]["with_gap"] or fe["mr"]["with_gap"])       # Q7
     b = inputs[0].shape[0]
@@ -461,3 +529,51 @@ class OracleModel:
             with torch.no_grad():
                 adam_step(ps, [p.grad for p in ps], self.opt_state, lr=lr, weight_decay=weight_decay)
         return logits.detach(), loss.detach()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Evaluation path.  PIN STATUS of this block: koafusion/run/eval_prog_fus.py is not
+# importable in the build container (thop, captum, cv2, hydra, omegaconf are absent -- ordinary ImportErrors),
+# so the two functions below are pinned by hand-derived known answers (tests/test_eval_cpu.py) only.
+# ---------------------------------------------------------------------------------------------------------
+def eval_accumulate(logits_batches, target_batches, id_batches):
+    """Per-batch accumulation of koafusion/run/eval_prog_fus.py:299-308: argmax over the logits, softmax over
+    the logits (torch fp32 on the CPU copy), python lists in loader order."""
+    acc = dict(exam_knee_id=[], target=[], predict=[], predict_proba=[])
+    for lg, tg, ids in zip(logits_batches, target_batches, id_batches):
+        t = lg.detach().to("cpu")
+        acc["exam_knee_id"].extend(list(ids))
+        acc["target"].extend(tg.detach().to("cpu").numpy().tolist())
+        acc["predict"].extend(torch.argmax(t, dim=1).numpy().tolist())
+        acc["predict_proba"].extend(F.softmax(t, dim=1).tolist())
+    return acc
+
+
+def ensemble_foldw(raw_foldw):
+    """koafusion/run/eval_prog_fus.py:317-343: inner 1:1 join of the folds on exam_knee_id in the first fold's
+    order, then softmax(mean over folds of the per-fold probabilities) -- the softmax is applied on top of
+    probabilities, as the reference does -- and argmax.  Plain numpy/python (no pandas)."""
+    import numpy as np
+    folds = list(raw_foldw.keys())
+    first = raw_foldw[folds[0]]
+    index = []
+    for k in folds:
+        ids = list(raw_foldw[k]["exam_knee_id"])
+        if len(set(ids)) != len(ids):
+            raise ValueError("Merge keys are not unique")          # pd.merge(validate="1:1")
+        index.append({e: i for i, e in enumerate(ids)})
+    keep = [e for e in first["exam_knee_id"] if all(e in ix for ix in index)]
+    out = dict(exam_knee_id=keep, target=[first["target"][index[0][e]] for e in keep])
+    probs = []
+    for k, ix in zip(folds, index):
+        out[f"predict__{k}"] = [raw_foldw[k]["predict"][ix[e]] for e in keep]
+        out[f"predict_proba__{k}"] = [raw_foldw[k]["predict_proba"][ix[e]] for e in keep]
+        probs.append(out[f"predict_proba__{k}"])
+    t = np.asarray(probs, dtype=np.float64).transpose(1, 0, 2) if keep else np.zeros((0, len(folds), 0))
+    m = np.mean(t, axis=1)
+    z = m - np.max(m, axis=-1, keepdims=True) if m.size else m
+    s = np.exp(z)
+    s = s / np.sum(s, axis=-1, keepdims=True) if m.size else s
+    out["predict_proba"] = s.tolist()
+    out["predict"] = np.argmax(s, axis=-1).tolist() if m.size else []
+    return out

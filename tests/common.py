@@ -64,3 +64,28 @@ def check_grads_vs_truth(mine, truth, e32, what, med_factor=2.0, max_factor=10.0
     assert np.median(r) <= med_factor, f"{what}: median error ratio {np.median(r):.2f} > {med_factor}"
     assert r.max() <= max_factor, f"{what}: {worst} is {ratios[worst]:.1f}x the reference fp32 noise ({e32[worst]:.2e})"
     return float(np.median(r)), float(r.max())
+
+
+
+def check_grads_branchy(mine, truth, smooth_keys, what, smooth_tol=1e-4, med_tol=2e-2, max_tol=0.1):
+    """Gradient bar for models WITHOUT a reference-recorded fp32 noise table (registry extensions).
+    A float32 forward whose rounding differs from the float64 truth by ~1e-6 takes the other branch at the few
+    ReLU inputs that close to zero (measured on resnet18 @160^2: 1-3 per forward, whatever the seed); every
+    gradient below such a layer then moves by ~1/sqrt(layer size) = 3e-3 ... 4e-2 -- the reference's own fp32 run
+    shows the same steps in the fixtures' e32 tables.  So: parameters not below any encoder ReLU (`smooth_keys`:
+    heads, fusion transformers above the encoders, clinical embedding) must match to smooth_tol; encoder parameters
+    must match to the branch-noise level (median med_tol, worst max_tol), which still fails on any plumbing error
+    (a lost path, a wrong 1/B, a transposed slice fold are O(1))."""
+    import numpy as np
+    errs = {k: rel(mine[k], tr) for k, tr in truth.items()}
+    tight = {k: e for k, e in errs.items() if smooth_keys(k)}
+    loose = {k: e for k, e in errs.items() if not smooth_keys(k)}
+    assert tight, f"{what}: no smooth parameters selected"
+    wk = max(tight, key=tight.get)
+    assert tight[wk] <= smooth_tol, f"{what}: {wk} off by {tight[wk]:.2e} (> {smooth_tol})"
+    if loose:
+        r = np.array(list(loose.values()))
+        wl = max(loose, key=loose.get)
+        assert np.median(r) <= med_tol, f"{what}: median encoder-gradient error {np.median(r):.2e} > {med_tol}"
+        assert loose[wl] <= max_tol, f"{what}: {wl} off by {loose[wl]:.2e} (> {max_tol})"
+    return max(tight.values()), (float(np.median(list(loose.values()))) if loose else 0.0)

@@ -140,6 +140,40 @@ def cfg_full(xr=(350, 350), mr1=(160, 160, 64), mr2=(160, 160, 25), depth=4, dro
                 output_type="dict", pretrained=False, path_pretrained=None, restore_weights=False, debug=False)
 
 
+def cfg_xr1c1(arch="resnext50_32x4d", size=350, dropout=0.0):
+    """extension XR1C1Cnn (BASELINE config "XR-PA + clinical early-fusion MLP head")"""
+    return dict(name="XR1C1Cnn", input_size=[[size, size], [16]], downscale=False, input_channels=1,
+                output_channels=2,
+                fe=dict(xr=dict(arch=arch, pretrained=False, with_gap=True, dropout=dropout),
+                        clin=dict(dim_in=9, dim_out=2048, dropout=dropout)),
+                agg=dict(hidden_size=512, dropout=dropout), output_type="dict", pretrained=False,
+                path_pretrained=None, restore_weights=False, debug=False)
+
+
+def cfg_mr1c1(mr=(160, 160, 64), depth=4, dropout=0.0):
+    """extension MR1C1CnnTrf (BASELINE config "SAG-3D-DESS encoder + clinical")"""
+    return dict(name="MR1C1CnnTrf", input_size=[list(mr), [16]], downscale=False, input_channels=1,
+                output_channels=2,
+                fe=dict(mr=dict(arch="resnet50", pretrained=False, with_gap=True, dropout=dropout),
+                        clin=dict(dim_in=9, dim_out=2048, dropout=dropout)),
+                agg=dict(num_slices=[mr[2], 1], depth=depth, heads=8, emb_dropout=dropout, mlp_dim=2048,
+                         mlp_dropout=dropout),
+                output_type="dict", pretrained=False, path_pretrained=None, restore_weights=False, debug=False)
+
+
+def cfg_xr1mr3c1(xr=(350, 350), mr1=(160, 160, 64), mr2=(160, 160, 32), mr3=(160, 160, 25), depth=4, dropout=0.0,
+                 xr_arch="resnext50_32x4d"):
+    """extension XR1MR3C1CnnTrf (BASELINE config "Full XR + SAG-DESS/COR-IW-TSE/SAG-T2 + clinical")"""
+    return dict(name="XR1MR3C1CnnTrf", input_size=[list(xr), list(mr1), list(mr2), list(mr3), [16]],
+                downscale=False, input_channels=1, output_channels=2,
+                fe=dict(xr=dict(arch=xr_arch, pretrained=False, with_gap=True, dropout=dropout),
+                        mr=dict(arch="resnet50", pretrained=False, with_gap=True, dropout=dropout),
+                        clin=dict(dim_in=9, dim_out=2048, dropout=dropout)),
+                agg=dict(num_slices=[1, mr1[2], mr2[2], mr3[2], 1], depth=depth, heads=8, emb_dropout=dropout,
+                         mlp_dim=2048, mlp_dropout=dropout),
+                output_type="dict", pretrained=False, path_pretrained=None, restore_weights=False, debug=False)
+
+
 def model_inputs(cfg, B, seed=1234):
     """numpy inputs in the model's positional order"""
     name = cfg["name"]
@@ -155,6 +189,14 @@ def model_inputs(cfg, B, seed=1234):
     if name == "XR1MR2CnnTrf":
         return [make_input("xr", (B, 1, *sz[0]), seed), make_input("mr0", (B, 1, *sz[1]), seed),
                 make_input("mr1", (B, 1, *sz[2]), seed)]
+    if name == "XR1C1Cnn":
+        return [make_input("xr", (B, 1, *sz[0]), seed), make_clin("clin", B, seed)]
+    if name == "MR1C1CnnTrf":
+        return [make_input("mr0", (B, 1, *sz[0]), seed), make_clin("clin", B, seed)]
+    if name == "XR1MR3C1CnnTrf":
+        return [make_input("xr", (B, 1, *sz[0]), seed), make_input("mr0", (B, 1, *sz[1]), seed),
+                make_input("mr1", (B, 1, *sz[2]), seed), make_input("mr2", (B, 1, *sz[3]), seed),
+                make_clin("clin", B, seed)]
     if name == "XR1MR2C1CnnTrf":
         return [make_input("xr", (B, 1, *sz[0]), seed), make_input("mr0", (B, 1, *sz[1]), seed),
                 make_input("mr1", (B, 1, *sz[2]), seed), make_clin("clin", B, seed)]

@@ -58,11 +58,12 @@ def _cfgs():
 
 def test_registries_and_bookkeeping_match_reference():
     from oaprogressionmmf_amd.config import ConfigDict
-    from oaprogressionmmf_amd.models import dict_fes, dict_models
+    from oaprogressionmmf_amd.models import REFERENCE_MODELS, dict_fes, dict_models
     from oaprogressionmmf_amd.various import dict_losses, dict_optimizers, dict_schedulers
     book = json.loads((GOLDEN / "f11_bookkeeping.json").read_text())
     sched = json.loads((GOLDEN / "f9_schedules.json").read_text())
-    assert sorted(dict_models) == book["dict_models"]
+    assert sorted(REFERENCE_MODELS) == book["dict_models"]
+    assert sorted(set(dict_models) - set(REFERENCE_MODELS)) == ["MR1C1CnnTrf", "XR1C1Cnn", "XR1MR3C1CnnTrf"]
     assert sorted(dict_losses) == book["dict_losses"]
     assert sorted(dict_optimizers) == sched["optimizer_keys"]
     assert sorted(dict_schedulers) == sched["scheduler_keys"]
@@ -77,6 +78,31 @@ def test_registries_and_bookkeeping_match_reference():
         assert vs == ref["vs"], name
     m = dict_models["MR1CnnTrf"](config=ConfigDict(P.cfg_mr1(shape=(160, 160, 64), with_gap=False)), path_weights=None)
     assert {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in m.vs.items()} == book["MR1CnnTrf_nogap"]["vs"]
+
+
+def test_extension_models_bookkeeping_matches_oracle_statement():
+    """the three registry extensions (no reference class): state-dict keys/shapes/dtypes and `vs` equal the
+    oracle's statement of the same definitions; the 2-MRI slots of the 3-MRI model are key-compatible with the
+    reference-named XR1MR2C1CnnTrf"""
+    from oracle import koafusion_cpu as O
+    from oaprogressionmmf_amd.config import ConfigDict
+    from oaprogressionmmf_amd.models import dict_models
+    cfgs = [P.cfg_xr1c1(), P.cfg_mr1c1(), P.cfg_xr1mr3c1(depth=1)]
+    for cfg in cfgs:
+        m = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None)
+        spec, vs = O.model_spec(cfg)
+        got = [(k, tuple(v.shape), v.dtype) for k, v in m.state_dict().items()]
+        assert sorted(got) == sorted((k, tuple(s), d) for k, s, d in spec), cfg["name"]
+        norm = lambda d: {k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in d.items()}  # noqa: E731
+        assert norm(m.vs) == norm(vs), cfg["name"]
+    m3 = dict_models["XR1MR3C1CnnTrf"](config=ConfigDict(P.cfg_xr1mr3c1(mr2=(160, 160, 25), depth=1)), path_weights=None)
+    m2 = dict_models["XR1MR2C1CnnTrf"](config=ConfigDict(P.cfg_full(depth=1)), path_weights=None)
+    k3, k2 = dict(m3.state_dict()), dict(m2.state_dict())
+    for k, v in k2.items():
+        if k.startswith(("_fe0.", "_fe1.", "_fe2.", "_agg_1.", "_agg_2.")):
+            assert k in k3 and k3[k].shape == v.shape, k
+    with pytest.raises(ValueError):
+        dict_models["XR1MR3C1CnnTrf"](config=ConfigDict(P.cfg_full()), path_weights=None)   # 4 inputs given
 
 
 def test_config_errors_like_reference():
