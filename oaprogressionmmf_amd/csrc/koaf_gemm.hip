@@ -26,6 +26,29 @@ constexpr int LDK = BK + 4;
 #define KOAF_ISSUE_AT 0   // 0: next tile's loads go out at the top of the k-step (longest flight time);
 #endif                    // 1: between the MFMA groups
 
+#ifndef KOAF_SPLIT3
+#define KOAF_SPLIT3 1
+#endif
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// eight fp32 values (x0 = k-slots 0..3, x1 = k-slots 4..7) -> three packed bf16x8 planes (hi, mid, lo) with
+// x = hi + mid + lo exactly: truncation keeps the top 8 significand bits of the running remainder each time
+__device__ __forceinline__ void split3(const v4f x0, const v4f x1, v4i out[3]) {
+    float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    float r1[8], r2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        r1[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & 0xffff0000u);
+        r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & 0xffff0000u);
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        out[0][d] = (int)__builtin_amdgcn_perm(__float_as_uint(x[2 * d + 1]), __float_as_uint(x[2 * d]), 0x07060302u);
+        out[1][d] = (int)__builtin_amdgcn_perm(__float_as_uint(r1[2 * d + 1]), __float_as_uint(r1[2 * d]), 0x07060302u);
+        out[2][d] = (int)__builtin_amdgcn_perm(__float_as_uint(r2[2 * d + 1]), __float_as_uint(r2[2 * d]), 0x07060302u);
+    }
+}
+
 // operand access modes (compile-time: the loaders are straight-line code, so hipcc can schedule their
 // address arithmetic into the shadows of the 64-cycle fp32 MFMAs)
 enum { M_KC = 0,     // K-contiguous rows, dense
@@ -340,6 +363,56 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
             la.issue(p.A, Ap, k0 + BK, kend, z1);
             lb.issue(p.B, Bp, k0 + BK, kend, z1);
         }
+#if KOAF_SPLIT3
+        // fp32 x fp32 on the bf16 matrix pipe: every operand value is cut (by truncation, exactly) into three bf16
+        // pieces hi + mid + lo = all 24 significand bits; of the nine piece products the six of relative weight
+        // >= 2^-16 go through v_mfma_f32_32x32x16_bf16 (each product exact, fp32 accumulate), the three dropped ones
+        // are <= 2^-23 of the product.  Six 8-pass MFMAs replace eight 16-pass fp32 MFMAs per 16 k: 2.67x the rate.
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+            v4f a[TM][2], b[2];
+            v4i ap[TM][3], bp[3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int kg = 2 * kq + u;
+                    if constexpr (AKC) {
+                        a[i][u] = *(const v4f*)&As[(wm * WM + 32 * i + r) * LDK + 8 * kg + 4 * h];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[i][u][j] = As[(8 * kg + 4 * h + j) * BM + wm * WM + 32 * i + r];
+                    }
+                }
+                split3(a[i][0], a[i][1], ap[i]);
+            }
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int kg = 2 * kq + u;
+                    if constexpr (BKC) {
+                        b[u] = *(const v4f*)&Bs[(wn * WN + 32 * jn + r) * LDK + 8 * kg + 4 * h];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) b[u][j] = Bs[(8 * kg + 4 * h + j) * BN + wn * WN + 32 * jn + r];
+                    }
+                }
+                split3(b[0], b[1], bp);
+                // smallest terms first; TM independent accumulators between two uses of the same one
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+                    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[i][PA[term]]),
+                                                                             __builtin_bit_cast(bf16x8, bp[PB[term]]),
+                                                                             acc[i][jn], 0, 0, 0);
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
             v4f a[TM], b[TN];
@@ -375,6 +448,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
                 if (kg == 1 && more) lb.issue(p.B, Bp, k0 + BK, kend, z1);
             }
         }
+#endif
         if constexpr (DB) {
             if (more) {
                 float* An = smem + (cur ^ 1) * STAGE;

@@ -50,21 +50,51 @@ def e32_table(gold, prefix=""):
     return dict(zip(keys, np.asarray(gold[prefix + "e32_vals"], dtype=np.float64)))
 
 
-def check_grads_vs_truth(mine, truth, e32, what, med_factor=2.0, max_factor=10.0, floor=1e-4):
+def top_relu_elems(cfg, B):
+    """number of elements of the smallest encoder ReLU layer (the last block's output, stride 32) of a registry
+    config at batch B -- sets the size of one ReLU-branch event, see check_grads_vs_truth"""
+    import math
+    name, sz = cfg["name"], cfg["input_size"]
+    ch = {"resnet18": 512, "resnet34": 512, "resnet50": 2048, "resnext50_32x4d": 2048}
+    sp = lambda a, b: math.ceil(a / 32) * math.ceil(b / 32)  # noqa: E731
+    fe = cfg["fe"]
+    out = []
+    for i, s in enumerate(sz):
+        if len(s) == 2:
+            arch = fe["arch"] if "arch" in fe else fe["xr"]["arch"]
+            out.append(B * ch[arch] * sp(s[0], s[1]))
+        elif len(s) == 3:
+            arch = fe["arch"] if "arch" in fe else fe["mr"]["arch"]
+            view = fe.get("dims_view", "rc") if "arch" in fe else "rc"
+            a, b, n = {"rc": (s[0], s[1], s[2]), "cs": (s[1], s[2], s[0]), "rs": (s[0], s[2], s[1])}[view]
+            out.append(B * n * ch[arch] * sp(a, b))
+    return min(out)
+
+
+def check_grads_vs_truth(mine, truth, e32, what, med_factor=2.0, max_factor=10.0, floor=1e-4, n_top=None):
     """Gradient parity bar.  truth = float64 run of the same computation; e32[k] = how far the REFERENCE's own
     fp32 gradient of parameter k is from that truth (recorded in the fixture).  Through ~50 train-mode
     BatchNorm layers with random weights that noise is 1e-4 ... 2e-2 and heavy-tailed per tensor, so the
     requirement is statistical: the typical (median) ratio  err_k / (e32_k + floor)  must be <= med_factor and
-    no single tensor may exceed max_factor."""
-    ratios = {}
-    for k, tr in truth.items():
-        ratios[k] = rel(mine[k], tr) / (e32[k] + floor)
-    r = np.array(list(ratios.values()))
-    worst = max(ratios, key=ratios.get)
-    assert np.median(r) <= med_factor, f"{what}: median error ratio {np.median(r):.2f} > {med_factor}"
-    assert r.max() <= max_factor, f"{what}: {worst} is {ratios[worst]:.1f}x the reference fp32 noise ({e32[worst]:.2e})"
+    no single tensor may exceed max_factor.
+    Branch events: a float32 forward differs from the float64 one by ~1e-6, so the few ReLU inputs that close to
+    zero (1-3 per forward at test sizes, which ones depends on the summation order) take the other branch, and
+    every gradient below that layer moves by about |g_j| / ||g|| ~ 1/sqrt(layer elements).  The reference's own
+    fp32 run shows such steps in e32, at whichever layers ITS rounding hit.  With `n_top` (elements of the smallest
+    encoder ReLU layer) the bar therefore never goes below 4 (median) / 10 (worst tensor) such units -- far under
+    what any composition error (a lost path, a wrong 1/B, a mis-folded slice: O(1)) produces, while rounding-level
+    correctness of every kernel is held at 1e-6 in test_kernels_gpu.py."""
+    unit = (1.0 / n_top ** 0.5) if n_top else 0.0
+    errs = {k: rel(mine[k], tr) for k, tr in truth.items()}
+    over = {k: e / max(max_factor * (e32[k] + floor), 10 * unit) for k, e in errs.items()}
+    worst = max(over, key=over.get)
+    r = np.array([errs[k] / (e32[k] + floor) for k in errs])
+    med_err = float(np.median(list(errs.values())))
+    assert np.median(r) <= med_factor or med_err <= 4 * unit, \
+        f"{what}: median error ratio {np.median(r):.2f} > {med_factor} (median error {med_err:.2e}, branch unit {unit:.1e})"
+    assert over[worst] <= 1.0, \
+        f"{what}: {worst} off by {errs[worst]:.2e} (reference fp32 noise {e32[worst]:.2e}, branch unit {unit:.1e})"
     return float(np.median(r)), float(r.max())
-
 
 
 def check_grads_branchy(mine, truth, smooth_keys, what, smooth_tol=1e-4, med_tol=2e-2, max_tol=0.1):

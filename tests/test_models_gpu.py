@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import procedural as P
-from common import GOLDEN, cfg_of, check_grads_vs_truth, check_summary, e32_table, load, rel
+from common import GOLDEN, cfg_of, check_grads_vs_truth, check_summary, e32_table, load, rel, top_relu_elems
 
 pytestmark = pytest.mark.gpu
 
@@ -68,7 +68,7 @@ def run_case(fname, dev, adam_steps=0):
     assert rel(logits.detach().cpu().numpy(), lg64.numpy()) < 3 * float(gold["e32_logits"]) + 1e-5
     truth = {k: p.grad.numpy() for k, p in om.named_parameters() if p.grad is not None}
     mine = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None}
-    check_grads_vs_truth(mine, truth, e32_table(gold), fname)
+    check_grads_vs_truth(mine, truth, e32_table(gold), fname, n_top=top_relu_elems(cfg, B))
     nbt = [b.item() for k, b in m.named_buffers() if k.endswith("num_batches_tracked")]
     assert nbt == gold["num_batches_tracked"].tolist()
     if adam_steps:
@@ -143,7 +143,8 @@ def test_trunks_vs_reference(dev):
         (yo * t(P.make_input("trunkg", tuple(yo.shape))).double()).sum().backward()
         truth = {k[2:]: v.grad.numpy() for k, v in sd.items() if O.is_param(k)}
         mine = {k: p.grad.cpu().numpy() for k, p in trunk.named_parameters()}
-        check_grads_vs_truth(mine, truth, e32_table(g, tag + ":"), tag)
+        n_top = shape[0] * (512 if arch in ("resnet18", "resnet34") else 2048) * -(-shape[2] // 32) * -(-shape[3] // 32)
+        check_grads_vs_truth(mine, truth, e32_table(g, tag + ":"), tag, n_top=n_top)
 
 
 def test_attention_feat_vs_reference(dev):
