@@ -26,10 +26,14 @@ constexpr int LDK = BK + 4;
 #define KOAF_ISSUE_AT 0   // 0: next tile's loads go out at the top of the k-step (longest flight time);
 #endif                    // 1: between the MFMA groups
 
+#ifndef KOAF_PIN_ACC
+#define KOAF_PIN_ACC 0
+#endif
 #ifndef KOAF_SPLIT3
-#define KOAF_SPLIT3 1
+#define KOAF_SPLIT3 2
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 
 // eight fp32 values (x0 = k-slots 0..3, x1 = k-slots 4..7) -> three packed bf16x8 planes (hi, mid, lo) with
 // x = hi + mid + lo exactly: truncation keeps the top 8 significand bits of the running remainder each time
@@ -46,6 +50,29 @@ __device__ __forceinline__ void split3(const v4f x0, const v4f x1, v4i out[3]) {
         out[0][d] = (int)__builtin_amdgcn_perm(__float_as_uint(x[2 * d + 1]), __float_as_uint(x[2 * d]), 0x07060302u);
         out[1][d] = (int)__builtin_amdgcn_perm(__float_as_uint(r1[2 * d + 1]), __float_as_uint(r1[2 * d]), 0x07060302u);
         out[2][d] = (int)__builtin_amdgcn_perm(__float_as_uint(r2[2 * d + 1]), __float_as_uint(r2[2 * d]), 0x07060302u);
+    }
+}
+
+// KOAF_SPLIT3 == 2: the split runs once per element in the loader and LDS holds three packed-bf16 plane images
+// per operand:  KC operand  plane[row][32 k + 8 pad]   (80-B rows: ds_read_b128 fragments, conflict-free)
+//               KM operand  plane[k][ROWS + 32 pad]    (ds_write_b64 of 4 rows, fragments by the transposing
+//                                                       ds_read_b64_tr_b16; k-row stride = 16 (mod 64) dwords)
+// Lane (r, h) of a 32x32x16 MFMA holds k = 16g + 8h + e (e = 0..7) of its row in both images.
+__host__ __device__ constexpr int plane_dwords(int rows, bool kc) { return kc ? rows * 20 : 32 * (rows / 2 + 16); }
+
+// four fp32 values -> three (hi, mid, lo) pairs of dwords holding 4 packed bf16 each
+__device__ __forceinline__ void split3v(const v4f x, unsigned out[3][2]) {
+    float r1[4], r2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r1[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & 0xffff0000u);
+        r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & 0xffff0000u);
+    }
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        out[0][d] = __builtin_amdgcn_perm(__float_as_uint(x[2 * d + 1]), __float_as_uint(x[2 * d]), 0x07060302u);
+        out[1][d] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * d + 1]), __float_as_uint(r1[2 * d]), 0x07060302u);
+        out[2][d] = __builtin_amdgcn_perm(__float_as_uint(r2[2 * d + 1]), __float_as_uint(r2[2 * d]), 0x07060302u);
     }
 }
 
@@ -282,6 +309,28 @@ struct TileLoader {
         }
     }
 
+#if KOAF_SPLIT3 == 2
+    __device__ __forceinline__ void store(float* Sf) const {
+        unsigned* S = (unsigned*)Sf;
+        const int t = threadIdx.x;
+        constexpr int P = plane_dwords(ROWS, KC);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            unsigned pl[3][2];
+            split3v(r[i], pl);
+            int off;
+            if constexpr (KC) {
+                off = ((t >> 3) + 32 * i) * 20 + 2 * (t & 7);
+            } else {
+                constexpr int CV = ROWS / 4;
+                constexpr int RP = 256 / CV;
+                off = (t / CV + RP * i) * (ROWS / 2 + 16) + 2 * (t % CV);
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *(uint2*)&S[q * P + off] = make_uint2(pl[q][0], pl[q][1]);
+        }
+    }
+#else
     __device__ __forceinline__ void store(float* S) const {
         const int t = threadIdx.x;
         if constexpr (KC) {
@@ -295,19 +344,46 @@ struct TileLoader {
             for (int i = 0; i < NU; ++i) *(v4f*)&S[(t / CV + RP * i) * ROWS + 4 * (t % CV)] = r[i];
         }
     }
+#endif
 };
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+// bf16x8 MFMA fragment of plane image P: rows row0 .. row0+31, k = 16g + 8h + (0..7); lane = 32h + r
+template <int ROWS, bool KC>
+__device__ __forceinline__ v4i frag_load(const unsigned* P, int row0, int g, int lane) {
+    if constexpr (KC) {
+        return *(const v4i*)&P[(row0 + (lane & 31)) * 20 + 8 * g + 4 * (lane >> 5)];
+    } else {
+        // two transposed 4(k) x 16(rows) block reads; lane 4q+p of a 16-lane group addresses block row q, cols 4p..4p+3
+        const int li = lane & 15, q = li >> 2, pp = li & 3;
+        const int rb = row0 + 16 * ((lane >> 4) & 1) + 4 * pp;
+        const int k0 = 16 * g + 8 * (lane >> 5) + q;
+        constexpr int SK = ROWS / 2 + 16;
+        typedef __attribute__((address_space(3))) v4s* lds_v4s;
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(P + k0 * SK + rb / 2));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(P + (k0 + 4) * SK + rb / 2));
+        const v2i l2 = __builtin_bit_cast(v2i, lo), h2 = __builtin_bit_cast(v2i, hi);
+        return (v4i){l2[0], l2[1], h2[0], h2[1]};
+    }
+}
 
 template <int BM, int BN, int AM, int BMD, bool TFA, bool TFB, bool VEC>
 __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr bool AKC = mode_is_kc(AM), BKC = mode_is_kc(BMD);
+#if KOAF_SPLIT3 == 2
+    constexpr int A_PL = plane_dwords(BM, AKC), B_PL = plane_dwords(BN, BKC);
+    constexpr int A_ELEMS = 3 * A_PL, B_ELEMS = 3 * B_PL;
+#else
     constexpr int A_ELEMS = AKC ? BM * LDK : BK * BM;
     constexpr int B_ELEMS = BKC ? BN * LDK : BK * BN;
+#endif
     constexpr int STAGE = A_ELEMS + B_ELEMS;
     // LDS double buffering (one barrier per k-step) only where it does not cost a resident block: the 128x128
     // tile is register-limited to 2 blocks/CU either way; the rectangular tiles fit 3 blocks single-buffered
     // (27 KB) but only 2 double-buffered (55 KB), and the third block hides more than the saved barrier.
-    constexpr bool DB = KOAF_DB_ALL ? true : (BM == BN);
+    constexpr bool DB = KOAF_SPLIT3 == 2 ? false : (KOAF_DB_ALL ? true : (BM == BN));
     constexpr int NSTAGE = DB ? 2 : 1;
     constexpr int LDC_S = BN + 4;                                    // epilogue staging row (floats)
     constexpr int C_ELEMS = VEC ? BM * LDC_S : 0;
@@ -363,7 +439,33 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
             la.issue(p.A, Ap, k0 + BK, kend, z1);
             lb.issue(p.B, Bp, k0 + BK, kend, z1);
         }
-#if KOAF_SPLIT3
+#if KOAF_SPLIT3 == 2
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const unsigned* Au = (const unsigned*)As;
+            const unsigned* Bu = (const unsigned*)Bs;
+            v4i ap[TM][3], bp[3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) ap[i][q] = frag_load<BM, AKC>(Au + q * A_PL, wm * WM + 32 * i, g, lane);
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) bp[q] = frag_load<BN, BKC>(Bu + q * B_PL, wn * WN + 32 * jn, g, lane);
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+                    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[i][PA[term]]),
+                                                                             __builtin_bit_cast(bf16x8, bp[PB[term]]),
+                                                                             acc[i][jn], 0, 0, 0);
+                }
+            }
+        }
+#elif KOAF_SPLIT3
         // fp32 x fp32 on the bf16 matrix pipe: every operand value is cut (by truncation, exactly) into three bf16
         // pieces hi + mid + lo = all 24 significand bits; of the nine piece products the six of relative weight
         // >= 2^-16 go through v_mfma_f32_32x32x16_bf16 (each product exact, fp32 accumulate), the three dropped ones
@@ -448,6 +550,14 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
                 if (kg == 1 && more) lb.issue(p.B, Bp, k0 + BK, kend, z1);
             }
         }
+#endif
+#if KOAF_PIN_ACC
+        // keep the loop-carried accumulators in AGPRs (hipcc otherwise carries them in VGPRs and copies all 64
+        // into AGPRs at the top of every k-step: 64 v_accvgpr_write per step)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) asm volatile("" : "+a"(acc[i][jn]));
 #endif
         if constexpr (DB) {
             if (more) {
