@@ -189,6 +189,10 @@ int koaf_stem_unfold_dw(const float* dw1t, float* dw, void* stream);
 int koaf_colstats(const float* x, int64_t rows, int32_t C, float* part, int32_t* part_rows,
                   void* stream);
 int32_t koaf_colpart_rows(int64_t rows, int32_t C);
+/* Bytes of the fp64 workspace `ws` the two finalisations below use to spread a long list of partial rows over
+ * the chip (two-stage, fixed-order reduction); 0 = not needed for this row count.  ws may always be NULL
+ * (single-stage). */
+int64_t koaf_bn_reduce_ws(int32_t rows, int32_t C);
 /* stats [rows][2][C] -> mean, invstd, sc = gamma*invstd, sh = beta - mean*sc; train: updates
  * running_mean/var (momentum, unbiased var) and ++num_batches_tracked (int64).  eval (train==0):
  * stats ignored, uses running stats.  */
@@ -196,7 +200,7 @@ int koaf_bn_finalize(const float* stats, int32_t rows, int32_t C, int64_t count,
                      const float* gamma, const float* beta, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
                      int32_t train, float* mean, float* invstd, float* sc, float* sh,
-                     void* stream);
+                     double* ws, void* stream);
 /* y = relu(sc*c + sh + identity-term); identity-term = idt (materialised) or idsc*idt+idsh
  * (downsample branch BN folded).  Bottleneck tail, _torchvision.py:132-136.  */
 int koaf_bn_add_relu(const float* c, const float* sc, const float* sh, const float* idt,
@@ -216,7 +220,7 @@ int koaf_bn_bwd_reduce(const float* g, const float* c, const float* ymask, const
  * coef [3][C] = {sc, dbeta/M, sc*invstd*dgamma/M}.  (nsum, i1) = (2, 1) for the plain layout. */
 int koaf_bn_bwd_finalize(const float* part, int32_t part_rows, int32_t C, int64_t count,
                          const float* sc, const float* invstd, float* dgamma, float* dbeta,
-                         float* coef, int32_t nsum, int32_t i1, void* stream);
+                         float* coef, int32_t nsum, int32_t i1, double* ws, void* stream);
 /* dc = coef0*(dz - coef1) - coef2*(c - mean) */
 int koaf_bn_bwd_apply(const float* dz, const float* c, const float* mean, const float* coef,
                       float* dc, int64_t rows, int32_t C, void* stream);

@@ -135,7 +135,36 @@ __global__ void __launch_bounds__(1024) colfinal_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // BatchNorm finalize (train: from partial column sums; eval: running stats)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) bn_finalize_kernel(const float* __restrict__ stats, int rows, int C,
+// Stage 1 of the per-channel finalisations when there are many partial rows (one per 128-row GEMM tile: 6400 for a
+// layer-1 activation of the native batch): src [rows][nsum][C] fp32 -> ws [S][2][C] fp64, block (bx, s) sums row
+// slice s of sums (0, i1) for 64 channels.  Fixed slice boundaries and summation order: deterministic.
+__global__ void __launch_bounds__(1024) part_reduce_kernel(const float* __restrict__ src, int rows, int C, int nsum,
+                                                           int i1, int chunk, double* __restrict__ ws) {
+    __shared__ double red[2][16][64];
+    const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int r0 = blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int r = r0 + gy; r < r1; r += 16) {
+            a += (double)src[((int64_t)r * nsum + 0) * C + c];
+            b += (double)src[((int64_t)r * nsum + i1) * C + c];
+        }
+    red[0][gy][cx] = a;
+    red[1][gy][cx] = b;
+    __syncthreads();
+    if (gy < 2 && c < C) {
+        double t = 0.0;
+        for (int j = 0; j < 16; ++j) t += red[gy][j][cx];
+        ws[((int64_t)blockIdx.y * 2 + gy) * C + c] = t;
+    }
+}
+
+// slices of the two-stage reduction: 0 = single stage
+static inline int part_slices(int rows) { return rows > 128 ? (rows >= 4096 ? 64 : (rows + 63) / 64) : 0; }
+
+template <typename T>
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(const T* __restrict__ stats, int rows, int C,
                                                            double inv_count, double unbias,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* running_mean,
@@ -238,7 +267,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
     col_block_reduce<2>(s, part, blockIdx.x, C, blockIdx.y * geo.CW, geo.CV, geo.RP);
 }
 
-__global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const float* __restrict__ part, int rows, int C,
+template <typename T>
+__global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const T* __restrict__ part, int rows, int C,
                                                                double inv_count, const float* __restrict__ sc,
                                                                const float* __restrict__ invstd, float* dgamma,
                                                                float* dbeta, float* coef, int nsum, int i1) {
@@ -688,17 +718,37 @@ inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // ================================================================================================
 #define STREAM ((hipStream_t)stream)
 
+extern "C" int64_t koaf_bn_reduce_ws(int32_t rows, int32_t C) {
+    const int S = part_slices(rows);
+    return S ? (int64_t)S * 2 * C * (int64_t)sizeof(double) : 0;
+}
+
+// stage 1 when it pays; returns the slice count (0: the caller reads the fp32 rows itself)
+static int part_reduce(const float* src, int rows, int C, int nsum, int i1, double* ws, hipStream_t st) {
+    const int S = ws ? part_slices(rows) : 0;
+    if (!S) return 0;
+    const int chunk = (rows + S - 1) / S;
+    hipLaunchKernelGGL(part_reduce_kernel, dim3((C + 63) / 64, S), dim3(1024), 0, st, src, rows, C, nsum, i1, chunk, ws);
+    return S;
+}
+
 extern "C" int koaf_bn_finalize(const float* stats, int32_t rows, int32_t C, int64_t count, const float* gamma,
                                 const float* beta, float* running_mean, float* running_var,
                                 int64_t* num_batches_tracked, float momentum, float eps, int32_t train, float* mean,
-                                float* invstd, float* sc, float* sh, void* stream) {
+                                float* invstd, float* sc, float* sh, double* ws, void* stream) {
     KOAF_REQUIRE(C > 0 && mean && invstd && sc && sh && running_mean && running_var, "koaf_bn_finalize: bad args");
     KOAF_REQUIRE(!train || (stats && rows > 0 && count > 0), "koaf_bn_finalize: train mode needs stats");
     const double inv = train ? 1.0 / (double)count : 0.0;
     const double unbias = (train && count > 1) ? (double)count / (double)(count - 1) : 1.0;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, STREAM, stats, rows, C, inv, unbias,
-                       gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, train, mean,
-                       invstd, sc, sh);
+    const int S = train ? part_reduce(stats, rows, C, 2, 1, ws, STREAM) : 0;
+    if (S)
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, ws, S, C, inv, unbias,
+                           gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, train, mean,
+                           invstd, sc, sh);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, stats, rows, C, inv,
+                           unbias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, train,
+                           mean, invstd, sc, sh);
     return koaf_check_launch("koaf_bn_finalize");
 }
 
@@ -746,11 +796,16 @@ extern "C" int koaf_bn_bwd_reduce(const float* g, const float* c, const float* y
 }
 extern "C" int koaf_bn_bwd_finalize(const float* part, int32_t part_rows, int32_t C, int64_t count, const float* sc,
                                     const float* invstd, float* dgamma, float* dbeta, float* coef, int32_t nsum,
-                                    int32_t i1, void* stream) {
+                                    int32_t i1, double* ws, void* stream) {
     KOAF_REQUIRE(part && part_rows > 0 && C > 0 && count > 0 && sc && invstd && coef, "koaf_bn_bwd_finalize: bad args");
     KOAF_REQUIRE(nsum >= 2 && i1 >= 1 && i1 < nsum, "koaf_bn_bwd_finalize: bad (nsum, i1)");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, STREAM, part, part_rows, C,
-                       1.0 / (double)count, sc, invstd, dgamma, dbeta, coef, nsum, i1);
+    const int S = part_reduce(part, part_rows, C, nsum, i1, ws, STREAM);
+    if (S)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, ws, S, C,
+                           1.0 / (double)count, sc, invstd, dgamma, dbeta, coef, 2, 1);
+    else
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, part, part_rows, C,
+                           1.0 / (double)count, sc, invstd, dgamma, dbeta, coef, nsum, i1);
     return koaf_check_launch("koaf_bn_bwd_finalize");
 }
 extern "C" int koaf_bn_bwd_apply(const float* dz, const float* c, const float* mean, const float* coef, float* dc,

@@ -40,7 +40,7 @@ def _ptr(t):
         return None
     if not t.is_cuda:
         raise KoafError("koaf ops need tensors on a HIP device (no CPU fallback exists)")
-    if t.dtype not in (torch.float32, torch.int64, torch.uint8):
+    if t.dtype not in (torch.float32, torch.int64, torch.uint8, torch.float64):   # float64: reduction workspaces only
         raise KoafError(f"unexpected dtype {t.dtype}")
     return t.data_ptr()
 
@@ -201,13 +201,20 @@ def colstats(x, rows, C):
     return part
 
 
+def _reduce_ws(rows, C, like):
+    """fp64 workspace of the two-stage partial-row reduction (None when one stage does)"""
+    n = lib().koaf_bn_reduce_ws(rows, C)
+    return torch.empty(n // 8, dtype=torch.float64, device=like.device) if n else None
+
+
 def bn_finalize(part, C, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, train):
     """-> saved [4][C] = mean, invstd, sc, sh"""
     saved = _empty((4, C), gamma if gamma is not None else running_mean)
     rows = part.shape[0] if part is not None else 0
+    ws = _reduce_ws(rows, C, saved) if train else None
     check(lib().koaf_bn_finalize(_ptr(part), rows, C, count, _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                  _ptr(running_var), _ptr(nbt), momentum, eps, 1 if train else 0, _ptr(saved[0]),
-                                 _ptr(saved[1]), _ptr(saved[2]), _ptr(saved[3]), _stream()), "bn_finalize")
+                                 _ptr(saved[1]), _ptr(saved[2]), _ptr(saved[3]), _ptr(ws), _stream()), "bn_finalize")
     return saved
 
 
@@ -233,7 +240,8 @@ def bn_bwd(g, c, saved, rows, C, count, dgamma, dbeta, mask_mode, ymask=None, dz
                                _stream()), "bn_bwd_reduce")
     coef = _empty((3, C), g)
     check(L.koaf_bn_bwd_finalize(_ptr(part), r.value, C, count, _ptr(saved[2]), _ptr(saved[1]), _ptr(dgamma),
-                                 _ptr(dbeta), _ptr(coef), 2, 1, _stream()), "bn_bwd_finalize")
+                                 _ptr(dbeta), _ptr(coef), 2, 1, _ptr(_reduce_ws(r.value, C, g)), _stream()),
+          "bn_bwd_finalize")
     dz = dz_out if dz_out is not None else g
     dc = dc_out if dc_out is not None else torch.empty_like(c)
     check(L.koaf_bn_bwd_apply(_ptr(dz), _ptr(c), _ptr(saved[0]), _ptr(coef), _ptr(dc), rows, C, _stream()),
@@ -246,7 +254,8 @@ def bn_bwd_from_part(part, nsum, i1, dz, c, saved, rows, C, count, dgamma, dbeta
     L = lib()
     coef = _empty((3, C), dz)
     check(L.koaf_bn_bwd_finalize(_ptr(part), part.shape[0], C, count, _ptr(saved[2]), _ptr(saved[1]), _ptr(dgamma),
-                                 _ptr(dbeta), _ptr(coef), nsum, i1, _stream()), "bn_bwd_finalize")
+                                 _ptr(dbeta), _ptr(coef), nsum, i1, _ptr(_reduce_ws(part.shape[0], C, dz)), _stream()),
+          "bn_bwd_finalize")
     dc = dc_out if dc_out is not None else torch.empty_like(c)
     check(L.koaf_bn_bwd_apply(_ptr(dz), _ptr(c), _ptr(saved[0]), _ptr(coef), _ptr(dc), rows, C, _stream()),
           "bn_bwd_apply")
