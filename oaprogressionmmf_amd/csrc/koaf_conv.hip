@@ -464,18 +464,20 @@ extern "C" int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp
     KOAF_REQUIRE(P < (1ll << 31), "koaf_gconv3x3_wgrad: too many pixels");
     const int nz = C / 64;
     WgradPlan p = wgrad_plan(64, 576, P, 64, nz);
-    for (int z = 0; z < nz; ++z) {
+    {
+        // one launch: the C/64 slabs are the batch dimension (split-K slabs laid out [slab][split][64][576])
         KoafGemm g;
         zero_gemm(&g);
-        g.A.ptr = dy + 64 * z; g.A.kind = 1; g.A.ld = C;
-        g.B.ptr = x + 64 * z; g.B.kind = 1; g.B.gather = 1;
+        g.A.ptr = dy; g.A.kind = 1; g.A.ld = C; g.A.bs1 = 64;
+        g.B.ptr = x; g.B.kind = 1; g.B.gather = 1; g.B.bs1 = 64;
         g.B.H = H; g.B.W = W; g.B.C = 64; g.B.CS = C; g.B.PH = OH; g.B.PW = OW;
         g.B.KH = 3; g.B.KW = 3; g.B.stride = stride; g.B.pad = 1; g.B.pad_w = 1;
-        if (in_sc) { g.B.tf = 1; g.B.sc = in_sc + 64 * z; g.B.sh = in_sh + 64 * z; }
+        if (in_sc) { g.B.tf = 1; g.B.sc = in_sc; g.B.sh = in_sh; g.B.tf_bs = 64; }
         g.M = 64; g.N = 576; g.K = (int)P;
+        g.nb0 = 1; g.nb1 = nz;
         g.bm = 64; g.bn = 64; g.splitk = p.splitk;
-        g.C = slabs + (int64_t)z * p.splitk * 64 * 576;
-        g.ldc = 576;
+        g.C = slabs;
+        g.ldc = 576; g.cbs1 = 64 * 576;      // (unsplit case; split-K slabs are addressed by the kernel)
         int rc = koaf_gemm(&g, stream);
         if (rc != KOAF_OK) return rc;
     }
