@@ -1,18 +1,28 @@
 // koaf_gemm.hip -- the one MFMA GEMM under every dense contraction of the koafusion train step:
 // implicit-GEMM conv forward / dgrad / wgrad (NHWC), nn.Linear forward / dgrad / wgrad and the
-// attention contractions.  fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 fma
-// chain, 157 TFLOP/s dense peak on MI355X).
+// attention contractions.  fp32 in, fp32 out, fp32 accumulate.
 //
-// Block = 256 threads = 4 waves (2x2), block tile BM x BN x 32, wave tile (BM/2) x (BN/2) built from
-// 32x32 MFMA tiles.  Operand tiles are staged global -> registers -> LDS (single LDS buffer, the
-// next tile's global loads are in flight under the current tile's MFMAs; an fp32 MFMA k-step is
-// 4096 cycles per wave at 128x128, so HBM latency is covered with one block per SIMD set).
-//   K-contiguous operand ("KC"): LDS image [row][32+4] -- fragment = one ds_read_b128 per 4 MFMAs,
-//       conflict-free (row stride 36 dwords: 16 consecutive rows hit 16 distinct 4-bank slots).
-//   K-major operand ("KM"):      LDS image [k][rows]   -- ds_write_b128 rows, ds_read_b32 fragments
-//       (consecutive lanes, consecutive dwords).
-// Both images present the same k order to the MFMA: lane (r, h), step j of k-group g uses
-// k = 8g + 4h + j for A and for B, so any pairing of KC/KM operands works.
+// Arithmetic ("split3", KOAF_SPLIT3 == 2, the shipped mode): gfx950 has no TF32-class matrix mode and its fp32
+// MFMA runs at 1/16 of the bf16 rate, so the fp32 x fp32 products go through the bf16 matrix pipe without losing
+// bits: every operand value is cut by truncation into three bf16 pieces hi + mid + lo that together hold all 24
+// significand bits (exact), and of the nine piece products the six of relative weight >= 2^-16
+// (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) are issued as v_mfma_f32_32x32x16_bf16 (each product exact,
+// fp32 accumulate); the three dropped ones are <= 2^-23 of the product, i.e. at fp32 rounding level.  Measured
+// against float64 the result is as accurate as the fp32-MFMA path (KOAF_SPLIT3 == 0, kept for comparison) and
+// rocBLAS sgemm (scripts/gemm_accuracy.py).  Six 8-pass MFMAs replace eight 16-pass fp32 MFMAs per 16 k: the
+// matrix-pipe bound rises from 157 to 2500/6 = 417 TFLOP/s fp32-equivalent.  Inf operands become NaN (inf - inf
+// in the split); NaN stays NaN.
+//
+// Block = 256 threads = 4 waves (2x2), block tile BM x BN x 32, wave tile (BM/2) x (BN/2) built from 32x32 MFMA
+// tiles; 2 blocks per CU.  Operand tiles are staged global -> registers (fused BN+ReLU prologue, zero fill) ->
+// split -> LDS; the next tile's global loads are in flight under the current tile's MFMAs.  LDS holds three
+// packed-bf16 plane images per operand (see plane_dwords()):
+//   K-contiguous operand ("KC"): plane[row][32 k + 8 pad] -- ds_write_b64, fragments by ds_read_b128
+//       (80-B rows: the 16 lanes of a b128 group hit 16 distinct 4-bank slots).
+//   K-major operand ("KM"):      plane[k][ROWS + 32 pad]  -- ds_write_b64 of 4 rows, fragments by the transposing
+//       ds_read_b64_tr_b16 (k-row stride = 16 mod 64 dwords: conflict-free).
+// Both present the same k order to the MFMA (lane (r, h), element e: k = 16g + 8h + e), so any pairing of KC / KM
+// operands works.  Accumulators live in VGPRs (built with -mllvm -amdgpu-mfma-vgpr-form, see the Makefile).
 #include "koaf_common.h"
 
 namespace {
