@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", default="", help="write a per-shape table of the instrumented step to this file")
     ap.add_argument("--recompute", action="store_true",
-                    help="stage-level activation recompute in the encoders (keeps stage inputs + BatchNorm statistics only); "
+                    help="activation recompute in the encoders (keeps stage inputs + BatchNorm statistics only; blocks rebuilt one at a time); "
                          "needed for --workload syn at batch 8")
     ap.add_argument("--serial", action="store_true",
                     help="one HIP stream only (no encoder lanes / wgrad side stream): kernel durations seen by a profiler "
@@ -182,7 +182,7 @@ def main():
             from oaprogressionmmf_amd.models import KoafTrunk
             for m in model.modules():
                 if isinstance(m, KoafTrunk):
-                    m.recompute = True
+                    m.recompute = "block"
         ddp = DataParallelRCCL(model)
         loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
         opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4)

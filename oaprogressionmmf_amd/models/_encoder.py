@@ -5,7 +5,7 @@ koafusion/models/_xrNmrMcP.py:47-59 / _xr1_cnn.py:17-21 executing koafusion/mode
 (stem :170-174, Bottleneck.forward :118-138, BasicBlock.forward :62-80, avgpool :182).
 
 MI355X-first layout of the computation (all activations NHWC fp32, rows = (image, pixel)):
-  * every conv is an implicit GEMM on the fp32 MFMA kernel (koaf_gemm.hip); its epilogue emits the
+  * every conv is an implicit GEMM on the MFMA kernel (koaf_gemm.hip: fp32 in/out, split-bf16 products); its epilogue emits the
     per-channel partial sums the following train-mode BatchNorm needs;
   * BatchNorm+ReLU are never materialised: the consumer conv applies relu(sc*x+sh) while it loads its
     operand (forward A operand, wgrad B operand), so each conv output is written once and only the raw
@@ -284,7 +284,10 @@ class EncoderFn(torch.autograd.Function):
         else:
             out = y.permute(0, 3, 1, 2)  # (N,C,h,w) view of the NHWC buffer
         if keep:
+            if recompute:
+                c0 = None          # the stem output is rebuilt in backward too (one cheap 7x7 conv; 64 x H/2 x W/2 floats)
             ctx.state = dict(x=x, c0=c0, s0=s0, am=am, recs=recs, ck=ck if recompute else None,
+                             block_level=getattr(trunk, "recompute", False) == "block",
                              dims=(N, H, W, H1, W1), last=(Hc, Wc, C), st=st, lane=lane, train=train)
         return out
 
@@ -389,7 +392,10 @@ class EncoderFn(torch.autograd.Function):
             dy = gout.permute(0, 2, 3, 1).contiguous()
             if dy.data_ptr() == gout.data_ptr():
                 dy = dy.clone()  # masked in place below
-        side = _SideStream(gout.device, side_stream) if USE_SIDE_STREAM else None
+        # (no wgrad side stream under activation recompute: tensors handed to a second stream are recycled by the
+        # caching allocator only once that stream's events have completed, which at recompute-sized footprints
+        # drives the reserved pool to the HBM limit and every later allocation into a synchronising retry)
+        side = _SideStream(gout.device, side_stream) if (USE_SIDE_STREAM and S["ck"] is None) else None
         if S["ck"] is None:
             dy = EncoderFn._blocks_bwd(S["recs"], dy, side)
         else:
@@ -399,18 +405,38 @@ class EncoderFn(torch.autograd.Function):
             for si in range(len(stages) - 1, -1, -1):
                 cks = S["ck"][si]
                 y, Hc2, Wc2 = cks["yin"], cks["H"], cks["W"]
+                cks["yin"] = None
+                if S["block_level"] and len(stages[si]) > 1:
+                    # block-granular: pass 1 rebuilds only the block INPUTS of the stage, then every block is rebuilt
+                    # alone (last first) and back-propagated -- one block's conv outputs live at a time instead of
+                    # the whole stage's, for one more forward of the stage's blocks but the last
+                    ins = [(y, Hc2, Wc2)]
+                    for blk, given in zip(stages[si][:-1], cks["stats"][:-1]):
+                        r = _block_fwd(blk, y, N, Hc2, Wc2, S["train"], given)
+                        y, Hc2, Wc2 = r.y, r.dims[3], r.dims[4]
+                        ins.append((y, Hc2, Wc2))
+                        del r
+                    for bi in range(len(stages[si]) - 1, -1, -1):
+                        yb, hb, wb = ins.pop()
+                        r = _block_fwd(stages[si][bi], yb, N, hb, wb, S["train"], cks["stats"][bi])
+                        dy = EncoderFn._blocks_bwd([r], dy, side)
+                        del r, yb
+                    del y
+                    continue
                 recs = []
                 for blk, given in zip(stages[si], cks["stats"]):
                     r = _block_fwd(blk, y, N, Hc2, Wc2, S["train"], given)
                     recs.append(r)
                     y, Hc2, Wc2 = r.y, r.dims[3], r.dims[4]
-                cks["yin"] = None
                 dy = EncoderFn._blocks_bwd(recs, dy, side)
                 del recs, r, y
         # stem: max-pool, BN0, conv1 weight gradient (no data gradient: the input is a leaf)
         conv1, bn1 = st["conv1"], st["bn1"]
         da0 = ops.maxpool_bwd(dy, S["am"], N, H1, W1, 64)
-        dc0 = _bn_bwd(bn1, da0, S["c0"], S["s0"], N * H1 * W1, 2, dc_out=da0)
+        c0 = S["c0"]
+        if c0 is None:
+            c0 = ops.stem_fwd(S["x"], ops.stem_fold_w(packed_weight(conv1.weight)), N, H, W)
+        dc0 = _bn_bwd(bn1, da0, c0, S["s0"], N * H1 * W1, 2, dc_out=da0)
         gw, acc = grad_target(conv1.weight)
         ops.stem_wgrad(dc0, S["x"], gw, N, H, W)
         deliver_grad(conv1.weight, gw, acc)

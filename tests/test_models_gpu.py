@@ -197,14 +197,15 @@ def test_losses_interp_vs_reference(dev):
 
 
 def test_stage_recompute_matches_stored_activations(dev):
-    """stage-level activation recompute (KoafTrunk.recompute) rebuilds the same conv outputs with the saved
+    """activation recompute (KoafTrunk.recompute = True: per stage; "block": one block at a time, stem included)
+    rebuilds the same conv outputs with the saved
     BatchNorm statistics: outputs bit-identical, gradients equal up to the summation order of the few
     BatchNorm reductions that are fused differently at stage boundaries (1e-5), running statistics untouched"""
     from oaprogressionmmf_amd.models._core_fes import dict_fes
     from oaprogressionmmf_amd.models._encoder import KoafTrunk
     for arch, shape in (("resnet50", (3, 1, 96, 112)), ("resnext50_32x4d", (2, 1, 96, 96)), ("resnet18", (2, 1, 64, 96))):
         res = []
-        for rc in (False, True):
+        for rc in (False, True, "block"):
             net = dict_fes[arch](pretrained=False)
             trunk = KoafTrunk(*list(net.children())[:-1])
             P.fill_state_dict(trunk.state_dict())
@@ -215,9 +216,10 @@ def test_stage_recompute_matches_stored_activations(dev):
             (y * t(P.make_input("trunkg", tuple(y.shape))).to(dev)).sum().backward()
             res.append((y.detach().clone(), {k: p.grad.clone() for k, p in trunk.named_parameters()},
                         {k: b.clone() for k, b in trunk.named_buffers()}))
-        (y0, g0, b0), (y1, g1, b1) = res
-        assert torch.equal(y0, y1)
-        for k in b0:
-            assert torch.equal(b0[k], b1[k]), k
-        for k in g0:
-            assert rel(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 1e-5, (arch, k)
+        y0, g0, b0 = res[0]
+        for y1, g1, b1 in res[1:]:            # stage-level, then block-granular (+ stem) recompute
+            assert torch.equal(y0, y1)
+            for k in b0:
+                assert torch.equal(b0[k], b1[k]), k
+            for k in g0:
+                assert rel(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 1e-5, (arch, k)
