@@ -10,7 +10,7 @@
 They are built from the reference's own blocks only (trunks, FeaT, FeatC1) and follow its naming scheme
 (`_fe{i}` / `_fe{i}_drop` by input position, `_agg_{i}` per MRI, `_agg_final`), so XR1MR2C1CnnTrf state dicts
 load into the first 2 MRI slots of XR1MR3C1CnnTrf except `_fe3` (clinical there, MRI here) and `_agg_final`
-(position embedding length).  Parity: against oracle/koafusion_cpu.py's statement of the same definitions; the
+(position embedding length).  Parity: against the CPU test oracle's statement of the same definitions (tests/test_ext_gpu.py); the
 shared blocks are pinned by fixtures F2-F8, the compositions themselves have no reference to pin against."""
 import math
 
