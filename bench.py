@@ -266,6 +266,16 @@ def main():
             for tag, (n, fl, ms) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
                 fh.write(f"{tag:48s} {n:4d} {ms:9.3f} {fl / 1e9:10.1f} {fl / ms / 1e9 if ms > 0 else 0:8.1f}\n")
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    # HBM-side bytes per launch of the dominant kernel cannot be counted from inside the process: they come from
+    # the committed PMC summary of this same workload (profiles/README.md has the command and the corrections)
+    traffic, traffic_src = None, None
+    tj = ROOT / "profiles" / "r01_gemm_traffic.json"
+    if args.workload == "native3" and B == 8 and tj.exists():
+        try:
+            tjd = json.loads(tj.read_text())
+            traffic, traffic_src = tjd["bytes_per_launch"], "profiles/r01_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+        except (ValueError, KeyError):
+            pass
 
     if rank == 0:
         value = world * B * args.steps / dt
@@ -291,7 +301,8 @@ def main():
                        "hbm_peak_gib": {"allocated": hbm_gb[0], "reserved": hbm_gb[1]}},
             **({"pinned_reference_model": pinned} if pinned else {}),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(MFMA_SPLIT3_PEAK_TFLOPS, 1),
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_SPLIT3_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_SPLIT3_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per koaf_gemm_kernel launch (average)", "traffic_source": traffic_src,
                          "kernel": "koaf_gemm_kernel (implicit GEMM: conv fwd/dgrad/wgrad, linear, attention; fp32 in/out/"
                                    "accumulate, products as 6 x v_mfma_f32_32x32x16_bf16 on an exact 3-way bf16 split)",
                          "peak_is": "2.5 PFLOP/s dense bf16 MFMA / 6 MFMAs per fp32 product (fp32-equivalent TFLOP/s)",
