@@ -36,6 +36,9 @@ constexpr int LDK = BK + 4;
 #define KOAF_ISSUE_AT 0   // 0: next tile's loads go out at the top of the k-step (longest flight time);
 #endif                    // 1: between the MFMA groups
 
+#ifndef KOAF_XCD_SWIZZLE
+#define KOAF_XCD_SWIZZLE 1
+#endif
 #ifndef KOAF_PIN_ACC
 #define KOAF_PIN_ACC 0
 #endif
@@ -101,9 +104,15 @@ template <int ROWS, int MODE, bool TF, bool VEC>
 struct TileLoader {
     static constexpr int NU = ROWS / 32;
     static constexpr bool KC = mode_is_kc(MODE);
-    v4f r[NU];
-    unsigned vm;       // validity bits of the tile in flight: VEC 1 bit / unit, else 4 bits / unit
-    v4f ts4, th4;      // transform coefficients of the tile in flight (KC) / of this thread's columns (KM)
+    // registers of one k-tile in flight; two slots so that the tile after next can be on its way while the next one
+    // is transformed and split under the current tile's MFMAs (KOAF_SPLIT3 == 3)
+    struct Slot {
+        v4f r[NU];
+        unsigned vm;   // validity bits: VEC 1 bit / unit, else 4 bits / unit
+        v4f ts4, th4;  // transform coefficients of the tile (KC operands: they depend on k)
+    };
+    Slot sa, sb;
+    v4f kts4, kth4;    // transform coefficients of this thread's columns (KM operands: fixed)
     // KC state (ext-vector values, not arrays: arrays of per-unit state were left in scratch by hipcc and
     // every scratch reload drained the in-flight global loads through the in-order vmcnt)
     v4l base;          // element offset of each unit's row / image from the operand pointer
@@ -118,8 +127,8 @@ struct TileLoader {
 
     __device__ __forceinline__ void init(const KoafOperand& op, int r0, int R, int z1) {
         const int t = threadIdx.x;
-        vm = 0;
-        ts4 = th4 = (v4f){0.f, 0.f, 0.f, 0.f};
+        sa.vm = sb.vm = 0;
+        sa.ts4 = sa.th4 = sb.ts4 = sb.th4 = kts4 = kth4 = (v4f){0.f, 0.f, 0.f, 0.f};
         rvm = cvm = 0;
         base = (v4l){0, 0, 0, 0};
         iy0 = ix0 = toff = (v4i){0, 0, 0, 0};
@@ -165,11 +174,11 @@ struct TileLoader {
                 const float* sc = op.sc + z1 * op.tf_bs;
                 const float* sh = op.sh + z1 * op.tf_bs;
                 if (VEC) {
-                    if (cvm & 1u) { ts4 = *(const v4f*)(sc + cc); th4 = *(const v4f*)(sh + cc); }
+                    if (cvm & 1u) { kts4 = *(const v4f*)(sc + cc); kth4 = *(const v4f*)(sh + cc); }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if ((cvm >> j) & 1u) { ts4[j] = sc[cc + j]; th4[j] = sh[cc + j]; }
+                        if ((cvm >> j) & 1u) { kts4[j] = sc[cc + j]; kth4[j] = sh[cc + j]; }
                 }
             }
         }
@@ -177,9 +186,9 @@ struct TileLoader {
 
     // Issue the global loads of the k-tile [k0, k0+32): nothing here consumes a loaded value, so the
     // s_waitcnt lands in finish(), after the MFMAs of the tile currently in LDS.
-    __device__ __forceinline__ void issue(const KoafOperand& op, const float* ptr, int k0, int kend, int z1) {
+    __device__ __forceinline__ void issue(Slot& s, const KoafOperand& op, const float* ptr, int k0, int kend, int z1) {
         const int t = threadIdx.x;
-        vm = 0;
+        s.vm = 0;
         if constexpr (KC) {
             const int kk = k0 + 4 * (t & 7);
             const bool kok = kk < kend;
@@ -228,14 +237,14 @@ struct TileLoader {
                 const float* sh = op.sh + z1 * op.tf_bs;
                 if (VEC) {
                     const int c = kok ? ch : 0;
-                    ts4 = *(const v4f*)(sc + c);
-                    th4 = *(const v4f*)(sh + c);
+                    s.ts4 = *(const v4f*)(sc + c);
+                    s.th4 = *(const v4f*)(sh + c);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int c = (kk + j < kend) ? ch + j : 0;
-                        ts4[j] = sc[c];
-                        th4[j] = sh[c];
+                        s.ts4[j] = sc[c];
+                        s.th4[j] = sh[c];
                     }
                 }
             }
@@ -245,20 +254,20 @@ struct TileLoader {
                 if constexpr (MODE == M_KC) {
                     if (VEC) {
                         const bool ok = rok && kok;
-                        r[i] = *(const v4f*)(ptr + (ok ? base[i] + k0 : 0));
-                        vm |= (ok ? 1u : 0u) << i;
+                        s.r[i] = *(const v4f*)(ptr + (ok ? base[i] + k0 : 0));
+                        s.vm |= (ok ? 1u : 0u) << i;
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const bool ok = rok && (kk + j) < kend;
-                            r[i][j] = ptr[ok ? base[i] + k0 + j : 0];
-                            vm |= (ok ? 1u : 0u) << (4 * i + j);
+                            s.r[i][j] = ptr[ok ? base[i] + k0 + j : 0];
+                            s.vm |= (ok ? 1u : 0u) << (4 * i + j);
                         }
                     }
                 } else {
                     const bool ok = kok && ((tvm >> i) & 1u);
-                    r[i] = *(const v4f*)(ptr + (ok ? base[i] + (toff[i] + coff) : 0));
-                    vm |= (ok ? 1u : 0u) << i;
+                    s.r[i] = *(const v4f*)(ptr + (ok ? base[i] + (toff[i] + coff) : 0));
+                    s.vm |= (ok ? 1u : 0u) << i;
                 }
             }
         } else {
@@ -291,14 +300,14 @@ struct TileLoader {
                 }
                 if (VEC) {
                     ok = ok && (cvm & 1u);
-                    r[i] = *(const v4f*)(ptr + (ok ? off : 0));
-                    vm |= (ok ? 1u : 0u) << i;
+                    s.r[i] = *(const v4f*)(ptr + (ok ? off : 0));
+                    s.vm |= (ok ? 1u : 0u) << i;
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const bool okj = ok && ((cvm >> j) & 1u);
-                        r[i][j] = ptr[okj ? off + j : 0];
-                        vm |= (okj ? 1u : 0u) << (4 * i + j);
+                        s.r[i][j] = ptr[okj ? off + j : 0];
+                        s.vm |= (okj ? 1u : 0u) << (4 * i + j);
                     }
                 }
             }
@@ -306,52 +315,68 @@ struct TileLoader {
     }
 
     // transform + zero-fill of the tile issued by issue(); first consumer of the loaded registers
-    __device__ __forceinline__ void finish() {
+    __device__ __forceinline__ void finish_unit(Slot& s, int i) {
+        const v4f a = KC ? s.ts4 : kts4, b = KC ? s.th4 : kth4;
 #pragma unroll
-        for (int i = 0; i < NU; ++i) {
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = VEC ? ((s.vm >> i) & 1u) : ((s.vm >> (4 * i + j)) & 1u);
+            float x = s.r[i][j];
+            if constexpr (TF) x = fmaxf(x * a[j] + b[j], 0.f);
+            s.r[i][j] = ok ? x : 0.f;
+        }
+    }
+    __device__ __forceinline__ void finish(Slot& s) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = VEC ? ((vm >> i) & 1u) : ((vm >> (4 * i + j)) & 1u);
-                float x = r[i][j];
-                if constexpr (TF) x = fmaxf(x * ts4[j] + th4[j], 0.f);
-                r[i][j] = ok ? x : 0.f;
-            }
+        for (int i = 0; i < NU; ++i) finish_unit(s, i);
+    }
+    // LDS dword offset (within a plane) of unit i of this thread
+    __device__ __forceinline__ int plane_off(int i) const {
+        const int t = threadIdx.x;
+        if constexpr (KC) {
+            return ((t >> 3) + 32 * i) * 20 + 2 * (t & 7);
+        } else {
+            constexpr int CV = ROWS / 4;
+            constexpr int RP = 256 / CV;
+            return (t / CV + RP * i) * (ROWS / 2 + 16) + 2 * (t % CV);
         }
     }
 
-#if KOAF_SPLIT3 == 2
-    __device__ __forceinline__ void store(float* Sf) const {
+#if KOAF_SPLIT3 >= 2
+    __device__ __forceinline__ void store(const Slot& s, float* Sf) const {
         unsigned* S = (unsigned*)Sf;
-        const int t = threadIdx.x;
         constexpr int P = plane_dwords(ROWS, KC);
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             unsigned pl[3][2];
-            split3v(r[i], pl);
-            int off;
-            if constexpr (KC) {
-                off = ((t >> 3) + 32 * i) * 20 + 2 * (t & 7);
-            } else {
-                constexpr int CV = ROWS / 4;
-                constexpr int RP = 256 / CV;
-                off = (t / CV + RP * i) * (ROWS / 2 + 16) + 2 * (t % CV);
-            }
+            split3v(s.r[i], pl);
+            const int off = plane_off(i);
 #pragma unroll
             for (int q = 0; q < 3; ++q) *(uint2*)&S[q * P + off] = make_uint2(pl[q][0], pl[q][1]);
         }
     }
+    // split already done (planes in registers): LDS stores only
+    __device__ __forceinline__ void store_planes(const unsigned (&pl)[NU][3][2], float* Sf) const {
+        unsigned* S = (unsigned*)Sf;
+        constexpr int P = plane_dwords(ROWS, KC);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int off = plane_off(i);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *(uint2*)&S[q * P + off] = make_uint2(pl[i][q][0], pl[i][q][1]);
+        }
+    }
 #else
-    __device__ __forceinline__ void store(float* S) const {
+    __device__ __forceinline__ void store(const Slot& s, float* S) const {
         const int t = threadIdx.x;
         if constexpr (KC) {
             const int kv = t & 7;
 #pragma unroll
-            for (int i = 0; i < NU; ++i) *(v4f*)&S[((t >> 3) + 32 * i) * LDK + 4 * kv] = r[i];
+            for (int i = 0; i < NU; ++i) *(v4f*)&S[((t >> 3) + 32 * i) * LDK + 4 * kv] = s.r[i];
         } else {
             constexpr int CV = ROWS / 4;
             constexpr int RP = 256 / CV;
 #pragma unroll
-            for (int i = 0; i < NU; ++i) *(v4f*)&S[(t / CV + RP * i) * ROWS + 4 * (t % CV)] = r[i];
+            for (int i = 0; i < NU; ++i) *(v4f*)&S[(t / CV + RP * i) * ROWS + 4 * (t % CV)] = s.r[i];
         }
     }
 #endif
@@ -401,8 +426,20 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM];        // double-buffered operand tiles
 
     const int ntn = (p.N + BN - 1) / BN;
-    const int tn = blockIdx.x % ntn;
-    const int tm = blockIdx.x / ntn;
+#if KOAF_XCD_SWIZZLE
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MiB L2): without a remap the ntn blocks that
+    // share an A row tile land on ntn different L2s and the tile is fetched from beyond L2 ntn times.  Bijective remap:
+    // XCD x works through one contiguous chunk of the tile order, so a row tile's blocks follow each other on one L2.
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, x = bid & 7, j = bid >> 3;
+        bid = x * q + (x < rem ? x : rem) + j;
+    }
+#else
+    const unsigned bid = blockIdx.x;
+#endif
+    const int tn = bid % ntn;
+    const int tm = bid / ntn;
     const int m0 = p.m_base + tm * BM, n0 = tn * BN;
     const int z0 = blockIdx.z / p.nb1, z1 = blockIdx.z - z0 * p.nb1;
     const int split = blockIdx.y;
@@ -432,12 +469,12 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     const int r = lane & 31, h = lane >> 5;
 
     if (kbeg < kend) {
-        la.issue(p.A, Ap, kbeg, kend, z1);
-        lb.issue(p.B, Bp, kbeg, kend, z1);
-        la.finish();
-        lb.finish();
-        la.store(smem);
-        lb.store(smem + A_ELEMS);
+        la.issue(la.sa, p.A, Ap, kbeg, kend, z1);
+        lb.issue(lb.sa, p.B, Bp, kbeg, kend, z1);
+        la.finish(la.sa);
+        lb.finish(lb.sa);
+        la.store(la.sa, smem);
+        lb.store(lb.sa, smem + A_ELEMS);
     }
     __syncthreads();
     int cur = 0;
@@ -446,8 +483,8 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         const float* As = smem + cur * STAGE;
         const float* Bs = As + A_ELEMS;
         if (KOAF_ISSUE_AT == 0 && more) {
-            la.issue(p.A, Ap, k0 + BK, kend, z1);
-            lb.issue(p.B, Bp, k0 + BK, kend, z1);
+            la.issue(la.sa, p.A, Ap, k0 + BK, kend, z1);
+            lb.issue(lb.sa, p.B, Bp, k0 + BK, kend, z1);
         }
 #if KOAF_SPLIT3 == 2
 #pragma unroll
@@ -556,8 +593,8 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
             // the next tile's global loads go out between the MFMA groups (their address VALU work
             // executes in the shadow of the MFMAs just issued)
             if (KOAF_ISSUE_AT == 1) {
-                if (kg == 0 && more) la.issue(p.A, Ap, k0 + BK, kend, z1);
-                if (kg == 1 && more) lb.issue(p.B, Bp, k0 + BK, kend, z1);
+                if (kg == 0 && more) la.issue(la.sa, p.A, Ap, k0 + BK, kend, z1);
+                if (kg == 1 && more) lb.issue(lb.sa, p.B, Bp, k0 + BK, kend, z1);
             }
         }
 #endif
@@ -572,20 +609,20 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         if constexpr (DB) {
             if (more) {
                 float* An = smem + (cur ^ 1) * STAGE;
-                la.finish();
-                lb.finish();
-                la.store(An);
-                lb.store(An + A_ELEMS);
+                la.finish(la.sa);
+                lb.finish(lb.sa);
+                la.store(la.sa, An);
+                lb.store(lb.sa, An + A_ELEMS);
             }
             __syncthreads();
             cur ^= 1;
         } else {
             __syncthreads();
             if (more) {
-                la.finish();
-                lb.finish();
-                la.store(smem);
-                lb.store(smem + A_ELEMS);
+                la.finish(la.sa);
+                lb.finish(lb.sa);
+                la.store(la.sa, smem);
+                lb.store(lb.sa, smem + A_ELEMS);
                 __syncthreads();
             }
         }
