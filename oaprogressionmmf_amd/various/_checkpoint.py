@@ -18,6 +18,32 @@ def portable_state_dict(model):
     return {k: v.detach().to("cpu").contiguous().clone() for k, v in sd.items()}
 
 
+def save_train_state(path, model, optimizer=None, scheduler=None, **extra):
+    """Everything needed to RESUME a run (the reference's handler stores the model only): model state_dict
+    (standalone CPU tensors), optimizer state in torch.optim's layout (the fused Adam exports its flat moment buffers
+    per parameter, so torch.optim.Adam can continue the run and vice versa), scheduler state, and `extra` (epoch,
+    fold, ...)."""
+    blob = dict(model=portable_state_dict(model), extra=dict(extra))
+    if optimizer is not None:
+        blob["optimizer"] = optimizer.state_dict()
+    if scheduler is not None:
+        blob["scheduler"] = scheduler.state_dict()
+    torch.save(blob, path)
+    return path
+
+
+def load_train_state(path, model, optimizer=None, scheduler=None):
+    """Inverse of save_train_state; returns the `extra` dict.  The model must already sit on its HIP device."""
+    blob = torch.load(path, map_location="cpu", weights_only=False)
+    target = model.module if hasattr(model, "module") else model
+    target.load_state_dict(blob["model"])
+    if optimizer is not None and "optimizer" in blob:
+        optimizer.load_state_dict(blob["optimizer"])
+    if scheduler is not None and "scheduler" in blob:
+        scheduler.load_state_dict(blob["scheduler"])
+    return blob.get("extra", {})
+
+
 class CheckpointHandler(object):
     def __init__(self, path_root, fname_pattern=("{model_name}__fold_{fold_idx}__epoch_{epoch_idx:>03d}.pth"),
                  num_saved=1):

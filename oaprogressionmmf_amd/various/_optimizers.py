@@ -21,8 +21,10 @@ class Adam(optim.Optimizer):
         if lr < 0 or eps < 0 or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._flat = {}      # id(arena) -> dict(m, v, step)
-        self._loose = {}     # id(param) -> dict(m, v, step) for parameters outside any arena
+        self._flat = {}      # id(arena) -> dict(m, v) flat moment buffers
+        self._loose = {}     # id(param) -> dict(m, v) for parameters outside any arena
+        self._steps = {}     # id(param) -> number of updates it has received (torch keeps `step` per parameter)
+        self._pending = {}   # id(param) -> (exp_avg, exp_avg_sq) loaded before the parameter moved into its arena
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -30,6 +32,8 @@ class Adam(optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self._pending:
+            self._place_pending()            # (placement is final here: the forward that produced the gradients ran)
         for group in self.param_groups:
             lr, (b1, b2), eps, wd = group["lr"], group["betas"], group["eps"], group["weight_decay"]
             by_arena = {}
@@ -46,27 +50,110 @@ class Adam(optim.Optimizer):
                 else:
                     self._step_loose(p, lr, b1, b2, eps, wd)
             for a, plist in by_arena.values():
-                stt = self._flat.get(id(a))
-                if stt is None:
-                    stt = dict(m=torch.zeros_like(a.P), v=torch.zeros_like(a.P), step=0)
-                    self._flat[id(a)] = stt
-                stt["step"] += 1
-                for lo, hi in a.active_ranges(plist):
-                    ops.adam_step(a.P[lo:hi], a.G[lo:hi], stt["m"][lo:hi], stt["v"][lo:hi], hi - lo, lr, b1, b2, eps,
-                                  wd, stt["step"], self._ADAMW)
+                stt = self._arena_state(a)
+                # the bias correction depends on the parameter's own update count: one fused launch per contiguous run
+                # of parameters with the same count (for the reference models: every trained parameter, one count)
+                by_step = {}
+                for p in plist:
+                    n = self._steps.get(id(p), 0) + 1
+                    self._steps[id(p)] = n
+                    by_step.setdefault(n, []).append(p)
+                for n, ps in by_step.items():
+                    for lo, hi in a.active_ranges(ps):
+                        ops.adam_step(a.P[lo:hi], a.G[lo:hi], stt["m"][lo:hi], stt["v"][lo:hi], hi - lo, lr, b1, b2,
+                                      eps, wd, n, self._ADAMW)
         return loss
+
+    def _arena_state(self, a):
+        stt = self._flat.get(id(a))
+        if stt is None:
+            stt = dict(m=torch.zeros_like(a.P), v=torch.zeros_like(a.P))
+            self._flat[id(a)] = stt
+        return stt
+
+    def _loose_state(self, p):
+        stt = self._loose.get(id(p))
+        if stt is None:
+            stt = dict(m=torch.zeros(p.numel(), device=p.device), v=torch.zeros(p.numel(), device=p.device))
+            self._loose[id(p)] = stt
+        return stt
+
+    # ---- checkpointing: torch.optim.Adam's state_dict layout, so either side resumes the other's run ----------
+    def _moments(self, p, create=False):
+        """(exp_avg, exp_avg_sq) of p as tensors of p's logical shape (views of the flat buffers), or None"""
+        a = getattr(p, "_koaf_arena", None)
+        if a is not None and a.valid():
+            if id(a) not in self._flat and not create:
+                return None
+            stt = self._arena_state(a)
+            o, n = a.slot(p)
+            return a._view(stt["m"], o, n, p), a._view(stt["v"], o, n, p)
+        if id(p) not in self._loose and not create:
+            return None
+        stt = self._loose_state(p)
+        return stt["m"].view(p.shape), stt["v"].view(p.shape)
+
+    def _place_pending(self):
+        """moments loaded by load_state_dict() go to their flat buffers once the parameters' final placement is known
+        (a model adopts its arena at its first forward, which may come after the optimizer state was loaded)"""
+        for g in self.param_groups:
+            for p in g["params"]:
+                mv = self._pending.pop(id(p), None)
+                if mv is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("koaf Adam updates HIP-resident parameters only (no CPU fallback)")
+                m, v = self._moments(p, create=True)
+                m.copy_(mv[0].to(device=p.device, dtype=torch.float32))
+                v.copy_(mv[1].to(device=p.device, dtype=torch.float32))
+        self._pending = {}
+
+    def state_dict(self):
+        sd = super().state_dict()            # param_groups with index lists; `state` is kept outside self.state
+        params = [p for g in self.param_groups for p in g["params"]]
+        state = {}
+        for idx, p in enumerate(params):
+            n = self._steps.get(id(p), 0)
+            mv = self._pending.get(id(p)) or (self._moments(p) if n else None)   # loaded but not yet placed / live
+            if mv is None:
+                continue                      # never updated (no gradient so far): torch has no entry either
+            state[idx] = dict(step=torch.tensor(float(n)), exp_avg=mv[0].detach().to("cpu").contiguous().clone(),
+                              exp_avg_sq=mv[1].detach().to("cpu").contiguous().clone())
+        sd["state"] = state
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        groups = state_dict["param_groups"]
+        super().load_state_dict(dict(state={}, param_groups=groups))
+        params = [p for g in self.param_groups for p in g["params"]]
+        ids = [i for g in groups for i in g["params"]]
+        if len(ids) != len(params):
+            raise ValueError("loaded state dict has a different number of parameters")
+        self._steps, self._pending = {}, {}
+        for stt in list(self._flat.values()) + list(self._loose.values()):
+            stt["m"].zero_()
+            stt["v"].zero_()
+        for key, st in state_dict["state"].items():
+            p = params[ids.index(key)] if key in ids else None
+            if p is None:
+                raise KeyError(f"optimizer state for unknown parameter index {key}")
+            if st.get("amsgrad") or "max_exp_avg_sq" in st:
+                raise NotImplementedError("amsgrad state is not built")
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state shape {tuple(st['exp_avg'].shape)} != parameter shape {tuple(p.shape)}")
+            self._pending[id(p)] = (st["exp_avg"].detach().clone(), st["exp_avg_sq"].detach().clone())
+            self._steps[id(p)] = int(round(float(st["step"])))
 
     def _step_loose(self, p, lr, b1, b2, eps, wd):
         if not p.is_cuda:
             raise RuntimeError("koaf Adam updates HIP-resident parameters only (no CPU fallback)")
-        stt = self._loose.get(id(p))
-        if stt is None:
-            stt = dict(m=torch.zeros(p.numel(), device=p.device), v=torch.zeros(p.numel(), device=p.device), step=0)
-            self._loose[id(p)] = stt
-        stt["step"] += 1
+        stt = self._loose_state(p)
+        n = self._steps.get(id(p), 0) + 1
+        self._steps[id(p)] = n
         pc = p.data.contiguous().view(-1)
         g = p.grad.contiguous().view(-1)
-        ops.adam_step(pc, g, stt["m"], stt["v"], pc.numel(), lr, b1, b2, eps, wd, stt["step"], self._ADAMW)
+        ops.adam_step(pc, g, stt["m"], stt["v"], pc.numel(), lr, b1, b2, eps, wd, n, self._ADAMW)
         if pc.data_ptr() != p.data.data_ptr():
             p.data.copy_(pc.view_as(p.data))
 

@@ -180,3 +180,32 @@ def test_checkpoint_roundtrip(tmp_path):
         assert torch.equal(a, b), k
     sd = torch.load(h.get_last_ckpt())
     assert all(v.is_contiguous() for v in sd.values())           # plain tensors: loadable by the reference
+
+
+def test_fused_adam_state_dict_is_torch_layout():
+    """resume bookkeeping without a device: a torch.optim.Adam state_dict loads into the fused Adam and comes back
+    unchanged (same keys, steps, moment tensors, hyper-parameters); nothing is computed on the CPU"""
+    from oaprogressionmmf_amd.various import dict_optimizers
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(4, 3, 3, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 5))]
+    ref = torch.optim.Adam(ps, lr=3e-4, weight_decay=1e-4)
+    for p in ps[:2]:                      # the third parameter never receives a gradient -> no state entry
+        p.grad = torch.randn_like(p)
+    ref.step()
+    ref.step()
+    sd = ref.state_dict()
+    mine = dict_optimizers["Adam"](ps, lr=1.0)
+    mine.load_state_dict(sd)
+    out = mine.state_dict()
+    assert out["param_groups"][0]["lr"] == 3e-4 and out["param_groups"][0]["weight_decay"] == 1e-4
+    assert sorted(out["state"]) == sorted(sd["state"]) == [0, 1]
+    for k in sd["state"]:
+        assert float(out["state"][k]["step"]) == float(sd["state"][k]["step"]) == 2.0
+        assert torch.equal(out["state"][k]["exp_avg"], sd["state"][k]["exp_avg"])
+        assert torch.equal(out["state"][k]["exp_avg_sq"], sd["state"][k]["exp_avg_sq"])
+    back = torch.optim.Adam(ps, lr=1.0)
+    back.load_state_dict(out)             # and torch accepts what the fused optimizer exports
+    with pytest.raises(RuntimeError):
+        mine.step()                       # CPU parameters: refused, no fallback
+    with pytest.raises(ValueError):
+        dict_optimizers["Adam"](ps[:2], lr=1.0).load_state_dict(sd)
