@@ -225,6 +225,20 @@ int koaf_bn_bwd_finalize(const float* part, int32_t part_rows, int32_t C, int64_
 int koaf_bn_bwd_apply(const float* dz, const float* c, const float* mean, const float* coef,
                       float* dc, int64_t rows, int32_t C, void* stream);
 
+/* ---- input pipeline on the device (koafusion/preproc/_pt.py; applied per sample by the reference's CPU loader
+ * workers, koafusion/datasets/_data_provider.py:295-335) ------------------------------------------------------- */
+/* per-sample minimum and maximum of x [B][n] -> mm [B][2]; ws: B * koaf_minmax_ws(n) floats.  PTToUnitRange :75-99 */
+int64_t koaf_minmax_ws(int64_t n);
+int koaf_minmax(const float* x, int32_t B, int64_t n, float* mm, float* ws, void* stream);
+/* y = ((gamma(rotate(unit(x)))) - mean) / std on a batch x [B][R][C][S] (S = 1: radiographs):
+ *   unit(v) = (v - min_b) / (max_b - min_b)                                   PTToUnitRange        :75-99
+ *   rotate: in-plane (R, C) bilinear resampling, zero padding, F.affine_grid + F.grid_sample with
+ *           align_corners=False and [[cos,-sin,0],[sin,cos,0]]                PTRotate3DInSlice / PTRotate2D :257-345
+ *   gamma(v) = pow(v, e)                                                      PTGammaCorrection    :203-232
+ * params [B][4] = {cos(theta), sin(theta), e (0 = no gamma), rotate flag (0 = copy)}.  */
+int koaf_augment(const float* x, float* y, const float* mm, const float* params, int32_t B, int32_t R, int32_t C,
+                 int32_t S, float mean, float stdv, void* stream);
+
 /* ---- MaxPool2d 3x3 s2 p1 over relu(sc*c+sh) (_torchvision.py:173-174), GAP (:182) ------------ */
 int koaf_maxpool_fwd(const float* c, const float* sc, const float* sh, float* y, uint8_t* argmax,
                      int32_t N, int32_t H, int32_t W, int32_t C, void* stream);

@@ -311,6 +311,93 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// input pipeline on the device (koafusion/preproc/_pt.py:75-99 PTToUnitRange, :257-345 PTRotate3DInSlice / PTRotate2D,
+// :203-232 PTGammaCorrection, :101-135 PTNormalize -- applied per sample by the reference's CPU data-loader workers)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) minmax_part_kernel(const float* __restrict__ x, int64_t n, int nblk,
+                                                          float* __restrict__ part) {
+    const int b = blockIdx.y;
+    const float* xb = x + (int64_t)b * n;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) {
+        const float v = xb[i];
+        lo = fminf(lo, v);
+        hi = fmaxf(hi, v);
+    }
+    lo = -wave_max(-lo);
+    hi = wave_max(hi);
+    __shared__ float red[2][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lo; red[1][threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((int64_t)b * nblk + blockIdx.x) * 2 + 0] = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
+        part[((int64_t)b * nblk + blockIdx.x) * 2 + 1] = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    }
+}
+__global__ void __launch_bounds__(64) minmax_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ mm) {
+    const int b = blockIdx.x;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < nblk; i += 64) {
+        lo = fminf(lo, part[((int64_t)b * nblk + i) * 2 + 0]);
+        hi = fmaxf(hi, part[((int64_t)b * nblk + i) * 2 + 1]);
+    }
+    lo = -wave_max(-lo);
+    hi = wave_max(hi);
+    if (threadIdx.x == 0) { mm[2 * b] = lo; mm[2 * b + 1] = hi; }
+}
+
+// one thread per (sample, row, column); the S slices of that position share the four bilinear source positions
+__global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      const float* __restrict__ mm, const float* __restrict__ prm,
+                                                      int B, int R, int C, int S, float mean, float stdv) {
+    const int64_t total = (int64_t)B * R * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int r = (int)((i / C) % R);
+        const int b = (int)(i / ((int64_t)R * C));
+        const float mn = mm[2 * b], den = mm[2 * b + 1] - mn;
+        const float cs = prm[4 * b], sn = prm[4 * b + 1], ex = prm[4 * b + 2];
+        const bool rot = prm[4 * b + 3] != 0.f;
+        const float* xb = x + (int64_t)b * R * C * S;
+        float* yo = y + i * S;
+        int off[4] = {0, 0, 0, 0};
+        float w[4] = {1.f, 0.f, 0.f, 0.f};
+        bool ok[4] = {true, false, false, false};
+        if (rot) {
+            // F.affine_grid(theta, align_corners=False) then F.grid_sample(bilinear, zeros, align_corners=False)
+            const float xn = (2.f * c + 1.f) / C - 1.f, yn = (2.f * r + 1.f) / R - 1.f;
+            const float gx = cs * xn - sn * yn, gy = sn * xn + cs * yn;
+            const float ix = ((gx + 1.f) * C - 1.f) * 0.5f, iy = ((gy + 1.f) * R - 1.f) * 0.5f;
+            const float fx = floorf(ix), fy = floorf(iy);
+            const int x0 = (int)fx, y0 = (int)fy;
+            const float tx = ix - fx, ty = iy - fy;
+            w[0] = (1.f - tx) * (1.f - ty); w[1] = tx * (1.f - ty); w[2] = (1.f - tx) * ty; w[3] = tx * ty;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+                ok[k] = (unsigned)xx < (unsigned)C && (unsigned)yy < (unsigned)R;
+                off[k] = ok[k] ? (yy * C + xx) * S : 0;
+            }
+        } else {
+            off[0] = (r * C + c) * S;
+        }
+        for (int s = 0; s < S; ++s) {
+            float v;
+            if (rot) {
+                v = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (ok[k]) v += ((xb[off[k] + s] - mn) / den) * w[k];
+            } else {
+                v = (xb[off[0] + s] - mn) / den;
+            }
+            if (ex != 0.f) v = powf(v, ex);
+            yo[s] = (v - mean) / stdv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // max-pool 3x3 s2 p1 over relu(sc*c+sh); GAP
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restrict__ c, const float* __restrict__ sc,
@@ -860,6 +947,26 @@ extern "C" int koaf_downscale2(const float* x, float* out, int32_t B, int32_t R,
     const int64_t total = (int64_t)B * (R / 2) * (Cc / 2) * (S / fs);
     hipLaunchKernelGGL(downscale2_kernel, dim3(ew_grid(total)), dim3(EB), 0, STREAM, x, out, B, R, Cc, S, fs);
     return koaf_check_launch("koaf_downscale2");
+}
+
+extern "C" int64_t koaf_minmax_ws(int64_t n) {
+    int64_t nb = cdiv64(n, 256 * 16);
+    return (nb < 1 ? 1 : (nb > 256 ? 256 : nb)) * 2;      // floats per sample
+}
+extern "C" int koaf_minmax(const float* x, int32_t B, int64_t n, float* mm, float* ws, void* stream) {
+    KOAF_REQUIRE(x && mm && ws && B > 0 && n > 0, "koaf_minmax: bad args");
+    const int nblk = (int)(koaf_minmax_ws(n) / 2);
+    hipLaunchKernelGGL(minmax_part_kernel, dim3(nblk, B), dim3(256), 0, STREAM, x, n, nblk, ws);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(B), dim3(64), 0, STREAM, ws, nblk, mm);
+    return koaf_check_launch("koaf_minmax");
+}
+extern "C" int koaf_augment(const float* x, float* y, const float* mm, const float* params, int32_t B, int32_t R,
+                            int32_t C, int32_t S, float mean, float stdv, void* stream) {
+    KOAF_REQUIRE(x && y && mm && params && B > 0 && R > 0 && C > 0 && S > 0, "koaf_augment: bad args");
+    KOAF_REQUIRE((int64_t)R * C * S < (1ll << 31), "koaf_augment: sample too large");
+    const int64_t total = (int64_t)B * R * C;
+    hipLaunchKernelGGL(augment_kernel, dim3(ew_grid(total)), dim3(EB), 0, STREAM, x, y, mm, params, B, R, C, S, mean, stdv);
+    return koaf_check_launch("koaf_augment");
 }
 
 extern "C" int koaf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,

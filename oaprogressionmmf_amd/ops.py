@@ -307,6 +307,21 @@ def downscale2(x, B, R, Cc, S, fs):
 # ------------------------------------------------------------------------------------------------
 # transformer pieces
 # ------------------------------------------------------------------------------------------------
+def minmax(x, B):
+    """per-sample (min, max) of a contiguous batch -> [B, 2]"""
+    n = x.numel() // B
+    mm = _empty((B, 2), x)
+    ws = _empty((B * lib().koaf_minmax_ws(n),), x)
+    check(lib().koaf_minmax(_ptr(x), B, n, _ptr(mm), _ptr(ws), _stream()), "minmax")
+    return mm
+
+
+def augment(x, mm, params, B, R, C, S, mean, std):
+    y = torch.empty_like(x)
+    check(lib().koaf_augment(_ptr(x), _ptr(y), _ptr(mm), _ptr(params), B, R, C, S, mean, std, _stream()), "augment")
+    return y
+
+
 def linear_fwd(x, w, b, M, N, K, residual=None):
     L = lib()
     y = _empty((M, N), x)

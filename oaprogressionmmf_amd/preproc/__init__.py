@@ -1,1 +1,1 @@
-from ._pt import PTInterpolate
+from ._pt import PTBatchAugment, PTInterpolate

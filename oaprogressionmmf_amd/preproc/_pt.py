@@ -2,6 +2,11 @@
 koafusion/run/train_prog_fus.py:111-116).  F.interpolate(scale 0.5, recompute_scale_factor=True,
 align_corners=False, linear/bilinear/trilinear) on even sizes is exactly 2x average pooling -- one
 HBM-bound HIP kernel here."""
+import math
+import random
+
+import torch
+
 from .. import ops
 
 
@@ -27,3 +32,52 @@ class PTInterpolate(object):
             fs = 2 if float(sf[2]) == 0.5 else 1
             return ops.downscale2(x, B, R, C, S, fs).view(B, 1, R // 2, C // 2, S // fs)
         raise NotImplementedError(f"scale_factor {sf} is not built (the recipes use 0.5 / 1.0 only, runner.sh:347-361)")
+
+
+class PTBatchAugment(object):
+    """The reference's per-sample tensor pipeline for one image modality
+        PTToUnitRange -> PTRotate2D | PTRotate3DInSlice (prob) -> PTGammaCorrection (prob) -> PTNormalize
+    (koafusion/datasets/_data_provider.py:295-335, transforms koafusion/preproc/_pt.py:75-345), applied to a whole
+    BATCH already resident on the device: one min/max reduction and one fused HBM-bound kernel instead of four CPU
+    passes per sample in the loader workers.  Validation / test = the same without the random parts
+    (`rotate_prob = gamma_prob = 0`).
+
+    Random state: like the reference's transforms, a rotation draws (p, theta) and a gamma correction (p, gamma) from
+    Python's `random` per sample (`randomize()`, _pt.py:228-232, :305-307); `draw(B)` does that for a batch in sample
+    order, or pass `states` explicitly ([(p_rot, theta_rad, p_gamma, gamma)] * B)."""
+
+    def __init__(self, mean, std, degree_range=(-15., 15.), rotate_prob=0.5, gamma_range=(0.5, 2.0), gamma_prob=0.5,
+                 clip_to_unit=False):
+        if clip_to_unit:
+            raise NotImplementedError("clip_to_unit=True is not built (the recipes use False)")
+        self.mean = float(mean[0] if isinstance(mean, (list, tuple)) else mean)
+        self.std = float(std[0] if isinstance(std, (list, tuple)) else std)
+        self.theta_range = (math.radians(degree_range[0]), math.radians(degree_range[1]))
+        self.rotate_prob, self.gamma_range, self.gamma_prob = rotate_prob, tuple(gamma_range), gamma_prob
+
+    def draw(self, B):
+        out = []
+        for _ in range(B):
+            p_rot, theta = random.random(), random.uniform(*self.theta_range)
+            p_gam, gamma = random.random(), random.uniform(*self.gamma_range)
+            out.append((p_rot, theta, p_gam, gamma))
+        return out
+
+    def __call__(self, image, states=None):
+        """image: (B, 1, R, C) or (B, 1, R, C, S) raw intensities on the device -> same shape, float32"""
+        if image.ndim not in (4, 5) or image.shape[1] != 1:
+            raise ValueError(f"Unsupported tensor shape: {tuple(image.shape)}")
+        B, _, R, C = image.shape[:4]
+        S = image.shape[4] if image.ndim == 5 else 1
+        x = image.contiguous().float()
+        states = self.draw(B) if states is None else list(states)
+        if len(states) != B:
+            raise ValueError("one (p_rot, theta, p_gamma, gamma) tuple per sample")
+        prm = []
+        for p_rot, theta, p_gam, gamma in states:
+            rot = p_rot < self.rotate_prob
+            gam = p_gam < self.gamma_prob
+            prm.append([math.cos(theta) if rot else 1.0, math.sin(theta) if rot else 0.0,
+                        (1.0 / gamma) if gam else 0.0, 1.0 if rot else 0.0])
+        prm = torch.tensor(prm, dtype=torch.float32).to(x.device)
+        return ops.augment(x, ops.minmax(x, B), prm, B, R, C, S, self.mean, self.std)

@@ -457,6 +457,28 @@ def interpolate(x, scale_factor):
     return F.interpolate(x, scale_factor=scale_factor, recompute_scale_factor=True, align_corners=False, mode=mode)
 
 
+def augment_sample(x, state, mean, std, rotate_prob=0.5, gamma_prob=0.5):
+    """One sample through the reference's train-time tensor pipeline of an image modality
+    (koafusion/datasets/_data_provider.py:295-335): PTToUnitRange (_pt.py:75-99) -> PTRotate2D / PTRotate3DInSlice
+    (:257-345: the same in-plane rotation for every slice, F.affine_grid + F.grid_sample, bilinear, zeros,
+    align_corners=False) -> PTGammaCorrection (:203-232) -> PTNormalize (:101-135).
+    x: (1, R, C) or (1, R, C, S) raw intensities; state = (p_rot, theta_rad, p_gamma, gamma)."""
+    p_rot, theta, p_gam, gamma = state
+    x = x.float()
+    lo, hi = torch.min(x), torch.max(x)
+    x = x.sub(lo).div(hi - lo)
+    if p_rot < rotate_prob:
+        th = torch.tensor(float(theta))
+        mat = torch.tensor([[torch.cos(th), -torch.sin(th), 0], [torch.sin(th), torch.cos(th), 0]])
+        img = x.permute(3, 0, 1, 2) if x.dim() == 4 else x[None]              # (slices | 1, CH, R, C)
+        grid = F.affine_grid(mat[None].to(img.dtype).repeat(img.shape[0], 1, 1), img.size(), align_corners=False)
+        img = F.grid_sample(img, grid.to(img.dtype), align_corners=False)
+        x = img.permute(1, 2, 3, 0) if x.dim() == 4 else img[0]
+    if p_gam < gamma_prob:
+        x = torch.pow(x, 1. / gamma)
+    return ((x - mean) / std).float()
+
+
 def lr_factor_static_decay(epoch, epochs_warmup, epochs_static, warmup_factor=0.1, decay_factor=0.9):
     """CustomWarmupStaticDecayLR's lambda (koafusion/various/_optimizers.py:6-27)"""
     end_w = epochs_warmup

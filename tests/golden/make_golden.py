@@ -325,6 +325,31 @@ def case_f8_interp(preproc, **_):
     print("  wrote f8_interp.npz")
 
 
+AUG_STATES = [(0.1, 0.2, 0.3, 1.7), (0.9, 0.1, 0.2, 0.6), (0.4, -0.26, 0.8, 1.2), (0.7, 0.15, 0.9, 0.8)]   # (p_rot, theta, p_gamma, gamma)
+
+
+def case_f12_augment(preproc, **_):
+    """the reference's per-sample train pipeline of one modality (_data_provider.py:295-335) with pinned random states"""
+    out = {"states": np.asarray(AUG_STATES, dtype=np.float64)}
+    for tag, shape, rot_cls, mean, std in (("mr", (4, 1, 24, 20, 6), preproc.PTRotate3DInSlice, 0.257, 0.235),
+                                           ("xr", (4, 1, 28, 22), preproc.PTRotate2D, 0.543, 0.296)):
+        raw = np.abs(P.make_input("aug_" + tag, shape)) * 300.0 + 5.0
+        res = []
+        for b, (p_rot, theta, p_gam, gamma) in enumerate(AUG_STATES):
+            rot = rot_cls(degree_range=[-15., 15.], prob=0.5)
+            rot.state = {"p": p_rot, "theta": torch.tensor(theta)}
+            gam = preproc.PTGammaCorrection(gamma_range=(0.5, 2.0), prob=0.5, clip_to_unit=False)
+            gam.state = {"p": p_gam, "gamma": gamma}
+            x = t(raw[b].astype(np.float32))
+            for tf in (preproc.PTToUnitRange(), rot, gam, preproc.PTNormalize(mean=[mean, ], std=[std, ])):
+                x = tf(x)
+            res.append(x.numpy())
+        out[tag] = np.stack(res)
+        out[tag + ":norm"] = np.array([mean, std])
+    np.savez_compressed(HERE / "f12_augment.npz", **out)
+    print("  wrote f12_augment.npz")
+
+
 def case_f9_sched(optims, **_):
     p = [torch.nn.Parameter(torch.zeros(1))]
     tab = {}
@@ -376,7 +401,7 @@ def case_f11_bookkeeping(km, losses, **_):
 CASES = {
     "f1": case_f1_attention_feat, "f2": case_f2_bottleneck, "f3": case_f3_trunk, "f4": case_f4_xr1cnn,
     "f5": case_f5_mr, "f6": case_f6_full, "f7": case_f7_focal, "f8": case_f8_interp, "f9": case_f9_sched,
-    "f11": case_f11_bookkeeping,
+    "f11": case_f11_bookkeeping, "f12": case_f12_augment,
 }
 
 

@@ -7,6 +7,9 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+import procedural as P
+from common import load
+
 pytestmark = pytest.mark.gpu
 
 
@@ -361,3 +364,29 @@ def test_conv2d_dgrad_fused_bn_backward(dev, case, mode, second):
     assert part.shape[1] == len(sums)
     for i, ref in enumerate(sums):
         assert rel_err(part[:, i].double().sum(0), ref) < 2e-5, i
+
+
+def test_batch_augment_vs_reference(dev):
+    """device input pipeline (PTBatchAugment: unit range -> in-plane rotation -> gamma -> normalise, one fused kernel)
+    against the reference's own transform classes, fixture F12 (pinned random states); 2e-5 absolute on values of
+    order 1 (bilinear weights and powf in fp32)"""
+    from oaprogressionmmf_amd.preproc import PTBatchAugment
+    g = load("f12_augment.npz")
+    states = [tuple(s) for s in g["states"]]
+    for tag, shape in (("mr", (4, 1, 24, 20, 6)), ("xr", (4, 1, 28, 22))):
+        raw = (np.abs(P.make_input("aug_" + tag, shape)) * 300.0 + 5.0).astype(np.float32)
+        mean, std = g[tag + ":norm"]
+        aug = PTBatchAugment(mean=[float(mean)], std=[float(std)])
+        y = aug(torch.from_numpy(raw).to(dev), states=states).cpu().numpy()
+        assert y.shape == g[tag].shape
+        assert np.abs(y - g[tag]).max() < 2e-5, tag
+    # validation / test pipeline (no random parts) == unit range + normalise, and the drawn-state path runs
+    ev = PTBatchAugment(mean=0.5, std=0.25, rotate_prob=0.0, gamma_prob=0.0)
+    x = torch.from_numpy(raw).to(dev)
+    want = ((raw - raw.reshape(4, -1).min(1)[:, None, None, None]) /
+            (raw.reshape(4, -1).max(1) - raw.reshape(4, -1).min(1))[:, None, None, None] - 0.5) / 0.25
+    assert np.abs(ev(x).cpu().numpy() - want).max() < 1e-6
+    out = PTBatchAugment(mean=0.5, std=0.25)(x)
+    assert out.shape == x.shape and torch.isfinite(out).all()
+    with pytest.raises(ValueError):
+        aug(x[:, 0])

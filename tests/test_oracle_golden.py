@@ -180,3 +180,15 @@ def test_oracle_bookkeeping():
         assert {k: (list(v) if isinstance(v, tuple) else v) for k, v in vs.items()} == ref["vs"], name
     _, vs = O.model_spec(P.cfg_mr1(shape=(160, 160, 64), with_gap=False))
     assert {k: (list(v) if isinstance(v, tuple) else v) for k, v in vs.items()} == book["MR1CnnTrf_nogap"]["vs"]
+
+
+def test_f12_augment_pipeline():
+    """oracle.augment_sample == the reference's own transform classes with pinned random states (F12)"""
+    g = load("f12_augment.npz")
+    for tag, shape in (("mr", (4, 1, 24, 20, 6)), ("xr", (4, 1, 28, 22))):
+        raw = np.abs(P.make_input("aug_" + tag, shape)) * 300.0 + 5.0
+        mean, std = g[tag + ":norm"]
+        for b, st in enumerate(g["states"]):
+            got = O.augment_sample(torch.from_numpy(raw[b].astype(np.float32)), tuple(st), float(mean), float(std))
+            assert got.shape == g[tag][b].shape
+            assert np.abs(got.numpy() - g[tag][b]).max() < 1e-6, (tag, b)
