@@ -297,6 +297,10 @@ int koaf_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* s
  * with x := dy is the backward.  (nn.Dropout / nn.Dropout2d on (N,C,1,1); streams differ from
  * torch's by construction -- SURVEY a10.)  */
 int koaf_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* nn.Dropout2d on an NHWC map x [N][HW][C] (_xrNmrMcP.py:62-72 with with_gap false): one draw per (image, channel),
+ * generator index n*C + c -- identical to koaf_dropout on the pooled [N][C] output.  Backward = same call on dy. */
+int koaf_dropout2d(const float* x, float* y, int32_t N, int32_t HW, int32_t C, float p, uint64_t seed,
+                   void* stream);
 /* out = a + b */
 int koaf_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* column sums of x [rows][C] -> out [C] (bias gradients); part: koaf_colsum_ws floats or NULL */

@@ -706,6 +706,18 @@ __global__ void __launch_bounds__(256) dropout_kernel(const float* __restrict__ 
     }
 }
 
+// nn.Dropout2d on an NHWC feature map: one Bernoulli draw per (image, channel), index n*C + c -- the same draw the
+// element-wise kernel makes on the (N, C) pooled output, so pooled and spatial encoders share their masks
+__global__ void __launch_bounds__(256) dropout2d_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                        int64_t hwc, int C, float p, float inv_keep, uint64_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) {
+        const int64_t idx = (i / hwc) * C + (i % C);
+        const uint64_t h = mix64(seed ^ mix64((uint64_t)idx));
+        const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+        y[i] = (u >= p) ? x[i] * inv_keep : 0.f;
+    }
+}
+
 __global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ p, float v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) p[i] = v;
 }
@@ -1036,6 +1048,14 @@ extern "C" int koaf_dropout(const float* x, float* y, int64_t n, float p, uint64
     KOAF_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "koaf_dropout: bad args");
     hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(EB), 0, STREAM, x, y, n, p, 1.f / (1.f - p), seed);
     return koaf_check_launch("koaf_dropout");
+}
+extern "C" int koaf_dropout2d(const float* x, float* y, int32_t N, int32_t HW, int32_t C, float p, uint64_t seed,
+                              void* stream) {
+    KOAF_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && p >= 0.f && p < 1.f, "koaf_dropout2d: bad args");
+    const int64_t n = (int64_t)N * HW * C;
+    hipLaunchKernelGGL(dropout2d_kernel, dim3(ew_grid(n)), dim3(EB), 0, STREAM, x, y, n, (int64_t)HW * C, C, p,
+                       1.f / (1.f - p), seed);
+    return koaf_check_launch("koaf_dropout2d");
 }
 extern "C" int koaf_fill(float* p, float value, int64_t n, void* stream) {
     KOAF_REQUIRE(p && n > 0, "koaf_fill: bad args");

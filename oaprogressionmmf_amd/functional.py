@@ -166,6 +166,25 @@ class DropoutFn(torch.autograd.Function):
         return ops.dropout(d, ctx.p, ctx.seed), None, None
 
 
+class Dropout2dFn(torch.autograd.Function):
+    """channel dropout on an (N, C, h, w) view of an NHWC buffer (the encoder output layout)"""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        N, C, h, w = x.shape
+        xc = x.permute(0, 2, 3, 1)
+        xc = xc if xc.is_contiguous() else xc.contiguous()
+        ctx.meta = (N, h * w, C, p, seed)
+        return ops.dropout2d(xc, N, h * w, C, p, seed).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, HW, C, p, seed = ctx.meta
+        d = dy.permute(0, 2, 3, 1)
+        d = d if d.is_contiguous() else d.contiguous()
+        return ops.dropout2d(d, N, HW, C, p, seed).permute(0, 3, 1, 2), None, None
+
+
 class AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -217,3 +236,10 @@ def dropout(x, p, training):
     if not training or p == 0.0:
         return x
     return DropoutFn.apply(x, float(p), _seed())
+
+
+def dropout2d(x, p, training):
+    """nn.Dropout2d on an (N, C, h, w) encoder output"""
+    if not training or p == 0.0:
+        return x
+    return Dropout2dFn.apply(x, float(p), _seed())

@@ -18,8 +18,8 @@ def build_trunk(arch, pretrained, with_gap):
 
 
 class KoafDropout2d(nn.Module):
-    """nn.Dropout2d on the (N,C,1,1) GAP'd encoder output (_xrNmrMcP.py:62-72) == per-(image,channel)
-    dropout; on the libkoaf counter-based generator."""
+    """nn.Dropout2d on the encoder output (_xrNmrMcP.py:62-72): one draw per (image, channel) on the libkoaf
+    counter-based generator -- element-wise on the pooled (N,C,1,1) output, koaf_dropout2d on a spatial one."""
 
     def __init__(self, p):
         super().__init__()
@@ -29,7 +29,7 @@ class KoafDropout2d(nn.Module):
         if not self.training or self.p == 0.0:
             return x
         if x.shape[2] != 1 or x.shape[3] != 1:
-            raise NotImplementedError("Dropout2d on a spatial (with_gap=false) encoder output is not built")
+            return KF.dropout2d(x, self.p, True)        # spatial (with_gap=false) output: whole channels dropped
         return KF.dropout(x, self.p, True)
 
     def extra_repr(self):

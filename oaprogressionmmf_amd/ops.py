@@ -424,6 +424,12 @@ def dropout(x, p, seed):
     return y
 
 
+def dropout2d(x, N, HW, C, p, seed):
+    y = torch.empty_like(x)
+    check(lib().koaf_dropout2d(_ptr(x), _ptr(y), N, HW, C, p, seed, _stream()), "dropout2d")
+    return y
+
+
 def add(a, b):
     out = torch.empty_like(a)
     check(lib().koaf_add(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "add")

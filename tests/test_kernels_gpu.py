@@ -390,3 +390,28 @@ def test_batch_augment_vs_reference(dev):
     assert out.shape == x.shape and torch.isfinite(out).all()
     with pytest.raises(ValueError):
         aug(x[:, 0])
+
+
+def test_dropout2d_channels(dev):
+    """koaf_dropout2d: whole (image, channel) planes are dropped or scaled by 1/(1-p); the same draws as the
+    element-wise generator makes on the pooled (N, C) tensor with the same seed; backward applies the same mask"""
+    from oaprogressionmmf_amd import functional as KF, ops
+    N, C, h, w, p = 6, 64, 3, 5, 0.3
+    x = (torch.rand(N, h, w, C, generator=G) + 0.5).to(dev)
+    seed = 12345
+    y = ops.dropout2d(x, N, h * w, C, p, seed)
+    ratio = (y / x).cpu()
+    per_nc = ratio.permute(0, 3, 1, 2).reshape(N, C, -1)
+    assert torch.all((per_nc - per_nc[:, :, :1]).abs() < 1e-6), "a channel plane is not uniformly kept / dropped"
+    keep = per_nc[:, :, 0]
+    assert torch.all((keep == 0) | ((keep - 1 / (1 - p)).abs() < 1e-5))
+    assert 0.15 < (keep == 0).float().mean().item() < 0.45
+    pooled = ops.dropout(torch.ones(N, C, device=dev), p, seed).cpu()
+    assert torch.equal((pooled == 0), (keep == 0))
+    # autograd path on the (N, C, h, w) view
+    xv = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    torch.manual_seed(0)
+    out = KF.dropout2d(xv, p, True)
+    out.sum().backward()
+    assert torch.equal((xv.grad == 0), (out == 0)) and out.shape == xv.shape
+    assert KF.dropout2d(xv, p, False) is xv

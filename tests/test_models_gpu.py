@@ -223,3 +223,36 @@ def test_stage_recompute_matches_stored_activations(dev):
                 assert torch.equal(b0[k], b1[k]), k
             for k in g0:
                 assert rel(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 1e-5, (arch, k)
+
+
+def test_spatial_encoder_output_with_dropout2d(dev):
+    """with_gap=false keeps the (h, w) grid of the last stage as tokens; Dropout2d then drops whole channels
+    (SURVEY 8f-4).  Eval forward (dropout off) matches the oracle; the train step with p > 0 runs, its loss and every
+    gradient are finite, and a second forward with the same torch seed reproduces the same masks."""
+    from oracle import koafusion_cpu as O
+    from oaprogressionmmf_amd.various import dict_losses, set_ultimate_seed
+    cfg = P.cfg_mr1(shape=(64, 64, 32), with_gap=False, depth=1, dropout=0.3)
+    B = 2
+    xs = [t(a) for a in P.model_inputs(cfg, B, 3)]
+    y = t(P.make_target("target", B, 3)).to(dev)
+    m = build(cfg, dev)
+    om = O.OracleModel(cfg, fill=P.fill_value)
+    m.eval()
+    with torch.no_grad():
+        le = m(*[x.to(dev) for x in xs])["main"]
+        lo = om(*xs, train=False)
+    assert rel(le.cpu().numpy(), lo.numpy()) < 2e-4
+    m.train()
+    loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
+    outs = []
+    for _ in range(2):
+        set_ultimate_seed()
+        m.zero_grad()
+        lg = m(*[x.to(dev) for x in xs])["main"]
+        loss = loss_fn(input=lg.squeeze(1), target=y.long().squeeze(1))
+        loss.backward()
+        assert torch.isfinite(loss)
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+        outs.append(lg.detach().clone())
+    assert torch.equal(outs[0], outs[1])
+    assert rel(outs[0].cpu().numpy(), le.cpu().numpy()) > 1e-3      # dropout did change the train-mode output
