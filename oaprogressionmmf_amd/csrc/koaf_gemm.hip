@@ -403,6 +403,49 @@ __device__ __forceinline__ v4i frag_load(const unsigned* P, int row0, int g, int
     }
 }
 
+// Row loop of the vector epilogue for a FULL tile without row map, specialised on what is fused (residual, BatchNorm-
+// backward mode, second BatchNorm) so that it is branch-free: the loads of four rows go out together before the first
+// is consumed (the generic loop below tests every row and ends up with one load in flight at a time, which held the
+// HBM-bound 1x1-dgrad epilogues at 2-3 TB/s).
+template <int BM, int BN, bool HAS_R, int MODE, bool HAS_C2>
+__device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs, int ldcs, float* Cp, int64_t ldc,
+                                              const float* Rp, int m0, int col, int c4, int rr, v4f bv, v4f mu, v4f is,
+                                              v4f ms, v4f mh, v4f mu2, v4f is2, v4f& q1, v4f& q2, v4f& q3) {
+    constexpr int C4 = BN / 4, RPP = 256 / C4, U = 4;
+    static_assert((BM / RPP) % U == 0, "rows per thread must be a multiple of the batch");
+#pragma unroll 1
+    for (int row = rr; row < BM; row += RPP * U) {
+        v4f rv[U], cv[U], yv[U], c2v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t orow = m0 + row + u * RPP;
+            if constexpr (HAS_R) rv[u] = *(const v4f*)(Rp + orow * p.ldr + col);
+            if constexpr (MODE != 0) cv[u] = *(const v4f*)(p.bnb_c + orow * ldc + col);
+            if constexpr (MODE == 1) yv[u] = *(const v4f*)(p.bnb_y + orow * ldc + col);
+            if constexpr (HAS_C2) c2v[u] = *(const v4f*)(p.bnb2_c + orow * ldc + col);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t orow = m0 + row + u * RPP;
+            v4f v = *(const v4f*)&Cs[(row + u * RPP) * ldcs + 4 * c4] + bv;
+            if constexpr (HAS_R) v += rv[u];
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = yv[u][j] > 0.f ? v[j] : 0.f;
+            } else if constexpr (MODE == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (cv[u][j] * ms[j] + mh[j]) > 0.f ? v[j] : 0.f;
+            }
+            if constexpr (MODE != 0) {
+                q1 += v;
+                q2 += v * ((cv[u] - mu) * is);
+                if constexpr (HAS_C2) q3 += v * ((c2v[u] - mu2) * is2);
+            }
+            *(v4f*)(Cp + orow * ldc + col) = v;
+        }
+    }
+}
+
 template <int BM, int BN, int AM, int BMD, bool TFA, bool TFB, bool VEC>
 __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -678,6 +721,22 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
                 if (p.bnb_mode == 2) { ms = *(const v4f*)(p.bnb_sc + col); mh = *(const v4f*)(p.bnb_sh + col); }
                 if (p.bnb2_c) { mu2 = *(const v4f*)(p.bnb2_mean + col); is2 = *(const v4f*)(p.bnb2_invstd + col); }
             }
+            const bool full = (m0 + BM <= p.M) && !p.cmap;
+            if (full) {
+                const bool hr = Rp != nullptr, h2 = bnb && p.bnb2_c != nullptr;
+                const int mode = bnb ? p.bnb_mode : 0;
+#define KOAF_EPI(R_, M_, C2_) epi_rows_full<BM, BN, R_, M_, C2_>(p, Cs, LDC_S, Cp, ldc, Rp, m0, col, c4, rr, bv, mu, is, \
+                                                                 ms, mh, mu2, is2, q1, q2, q3)
+                if (mode == 0) { if (hr) KOAF_EPI(true, 0, false); else KOAF_EPI(false, 0, false); }
+                else if (mode == 1) {
+                    if (hr) { if (h2) KOAF_EPI(true, 1, true); else KOAF_EPI(true, 1, false); }
+                    else { if (h2) KOAF_EPI(false, 1, true); else KOAF_EPI(false, 1, false); }
+                } else {
+                    if (hr) { if (h2) KOAF_EPI(true, 2, true); else KOAF_EPI(true, 2, false); }
+                    else { if (h2) KOAF_EPI(false, 2, true); else KOAF_EPI(false, 2, false); }
+                }
+#undef KOAF_EPI
+            } else
 #pragma unroll 4
             for (int row = rr; row < BM; row += RPP) {
                 const int grow = m0 + row;

@@ -58,8 +58,10 @@ class PTBatchAugment(object):
     def draw(self, B):
         out = []
         for _ in range(B):
-            p_rot, theta = random.random(), random.uniform(*self.theta_range)
-            p_gam, gamma = random.random(), random.uniform(*self.gamma_range)
+            # a transform that is not in the modality's list draws nothing (T2 maps have no gamma correction,
+            # validation has neither: _data_provider.py:304-309,341-360), so the host RNG stream stays the reference's
+            p_rot, theta = (random.random(), random.uniform(*self.theta_range)) if self.rotate_prob > 0 else (1.0, 0.0)
+            p_gam, gamma = (random.random(), random.uniform(*self.gamma_range)) if self.gamma_prob > 0 else (1.0, 1.0)
             out.append((p_rot, theta, p_gam, gamma))
         return out
 

@@ -97,7 +97,7 @@ def check_grads_vs_truth(mine, truth, e32, what, med_factor=2.0, max_factor=10.0
     return float(np.median(r)), float(r.max())
 
 
-def check_grads_branchy(mine, truth, smooth_keys, what, smooth_tol=1e-4, med_tol=2e-2, max_tol=0.1):
+def check_grads_branchy(mine, truth, smooth_keys, what, smooth_tol=1e-4, med_tol=2e-2, max_tol=0.1, noise=None):
     """Gradient bar for models WITHOUT a reference-recorded fp32 noise table (registry extensions).
     A float32 forward whose rounding differs from the float64 truth by ~1e-6 takes the other branch at the few
     ReLU inputs that close to zero (measured on resnet18 @160^2: 1-3 per forward, whatever the seed); every
@@ -105,7 +105,9 @@ def check_grads_branchy(mine, truth, smooth_keys, what, smooth_tol=1e-4, med_tol
     shows the same steps in the fixtures' e32 tables.  So: parameters not below any encoder ReLU (`smooth_keys`:
     heads, fusion transformers above the encoders, clinical embedding) must match to smooth_tol; encoder parameters
     must match to the branch-noise level (median med_tol, worst max_tol), which still fails on any plumbing error
-    (a lost path, a wrong 1/B, a transposed slice fold are O(1))."""
+    (a lost path, a wrong 1/B, a transposed slice fold are O(1)).  `noise` (optional): the oracle's own float32 error per
+    parameter on the same graph -- where ITS rounding already hit branch events (few slices -> small layers -> large
+    steps) the bar follows it: median <= 2x its median, worst tensor <= 10x its own."""
     import numpy as np
     errs = {k: rel(mine[k], tr) for k, tr in truth.items()}
     tight = {k: e for k, e in errs.items() if smooth_keys(k)}
@@ -116,6 +118,9 @@ def check_grads_branchy(mine, truth, smooth_keys, what, smooth_tol=1e-4, med_tol
     if loose:
         r = np.array(list(loose.values()))
         wl = max(loose, key=loose.get)
-        assert np.median(r) <= med_tol, f"{what}: median encoder-gradient error {np.median(r):.2e} > {med_tol}"
-        assert loose[wl] <= max_tol, f"{what}: {wl} off by {loose[wl]:.2e} (> {max_tol})"
+        med_bar = max(med_tol, 2 * float(np.median([noise[k] for k in loose]))) if noise else med_tol
+        assert np.median(r) <= med_bar, f"{what}: median encoder-gradient error {np.median(r):.2e} > {med_bar:.2e}"
+        over = {k: e / max(max_tol, 10 * noise[k] if noise else 0.0) for k, e in loose.items()}
+        wl = max(over, key=over.get)
+        assert over[wl] <= 1.0, f"{what}: {wl} off by {loose[wl]:.2e} (> {max_tol}, oracle fp32 noise {noise[wl] if noise else 0:.2e})"
     return max(tight.values()), (float(np.median(list(loose.values()))) if loose else 0.0)

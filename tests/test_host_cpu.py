@@ -209,3 +209,34 @@ def test_fused_adam_state_dict_is_torch_layout():
         mine.step()                       # CPU parameters: refused, no fallback
     with pytest.raises(ValueError):
         dict_optimizers["Adam"](ps[:2], lr=1.0).load_state_dict(sd)
+
+
+def test_batch_augment_draws_like_the_reference_transforms():
+    """host RNG bookkeeping of PTBatchAugment: per sample, rotation (p, theta) then gamma (p, gamma) from Python's
+    `random`, exactly the calls the reference's randomize() methods make in list order (oai/_dataset.py:316-321,
+    _pt.py:228-232,305-307); absent transforms draw nothing"""
+    import math
+    import random
+    from oaprogressionmmf_amd.preproc import PTBatchAugment
+    aug = PTBatchAugment(mean=0.5, std=0.2)
+    random.seed(7)
+    got = aug.draw(3)
+    random.seed(7)
+    lo, hi = math.radians(-15.), math.radians(15.)
+    want = []
+    for _ in range(3):
+        p1 = random.random(); th = random.uniform(lo, hi); p2 = random.random(); g = random.uniform(0.5, 2.0)
+        want.append((p1, th, p2, g))
+    assert got == want
+    t2 = PTBatchAugment(mean=0.259, std=0.345, gamma_prob=0.0)
+    random.seed(7)
+    a = t2.draw(2)
+    random.seed(7)
+    b = [(random.random(), random.uniform(lo, hi), 1.0, 1.0) for _ in range(2)]
+    assert a == b
+    random.seed(7)
+    s0 = random.getstate()
+    assert PTBatchAugment(mean=0., std=1., rotate_prob=0.0, gamma_prob=0.0).draw(4) == [(1.0, 0.0, 1.0, 1.0)] * 4
+    assert random.getstate() == s0
+    with pytest.raises(NotImplementedError):
+        PTBatchAugment(mean=0., std=1., clip_to_unit=True)
