@@ -67,7 +67,11 @@ typedef struct KoafGemm {
     float* C;
     int64_t ldc, cbs0, cbs1;
     float alpha;
-    int32_t _pad0;
+    int32_t prec;            /* 0: products carry every fp32 significand bit (3 bf16 planes per operand, forward);
+                              * 1: operands rounded to 16 significand bits (2 planes; products of those exact) --
+                              *    set by the library on data / weight GRADIENT contractions: relative error ~1e-5
+                              *    against the 1e-3 bar, 1.5x fewer matrix instructions.  KOAF_BWD_PRECISION=full
+                              *    in the environment forces 0 everywhere. */
     const float* bias;     /* [N] or NULL */
     const float* residual; /* [M][ldr] (+batch strides) or NULL */
     int64_t ldr, rbs0, rbs1;

@@ -60,7 +60,7 @@ class KoafGemm(ctypes.Structure):
         ("cbs0", ctypes.c_int64),
         ("cbs1", ctypes.c_int64),
         ("alpha", ctypes.c_float),
-        ("_pad0", ctypes.c_int32),
+        ("prec", ctypes.c_int32),
         ("bias", ctypes.c_void_p),
         ("residual", ctypes.c_void_p),
         ("ldr", ctypes.c_int64),

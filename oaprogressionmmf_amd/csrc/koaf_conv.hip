@@ -286,6 +286,7 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
                 const int nkh = khs < KH ? (KH - khs + 1) / 2 : 0, nkw = kws < KW ? (KW - kws + 1) / 2 : 0;
                 const int offy = (py + pad - khs) / 2, offx = (px + pad - kws) / 2;
                 zero_gemm(&g);
+                g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
                 g.A.ptr = dy; g.A.kind = 0; g.A.gather = 2;
                 g.A.H = OH; g.A.W = OW; g.A.C = Cout; g.A.CS = Cout;
                 g.A.PH = Hc; g.A.PW = Wc;
@@ -308,6 +309,7 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
         return KOAF_OK;
     }
     zero_gemm(&g);
+    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
     g.A.ptr = dy;
     g.A.kind = 0;
     g.B.ptr = w;
@@ -366,6 +368,7 @@ extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int
     KOAF_REQUIRE(p.splitk == 1 || slabs, "koaf_conv2d_wgrad: workspace required");
     KoafGemm g;
     zero_gemm(&g);
+    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
     g.A.ptr = dy; g.A.kind = 1; g.A.ld = Cout;
     g.B.ptr = x; g.B.kind = 1;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {
@@ -435,6 +438,7 @@ extern "C" int koaf_gconv3x3_dgrad(const float* dy, const float* wexp, float* dx
     KOAF_REQUIRE(M < (1ll << 31), "koaf_gconv3x3_dgrad: too many pixels");
     KoafGemm g;
     zero_gemm(&g);
+    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
     g.nb1 = C / 64;
     g.A.ptr = dy; g.A.kind = 0; g.A.gather = 2; g.A.bs1 = 64;
     g.A.H = OH; g.A.W = OW; g.A.C = 64; g.A.CS = C; g.A.PH = H; g.A.PW = W;
@@ -468,6 +472,7 @@ extern "C" int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp
         // one launch: the C/64 slabs are the batch dimension (split-K slabs laid out [slab][split][64][576])
         KoafGemm g;
         zero_gemm(&g);
+        g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
         g.A.ptr = dy; g.A.kind = 1; g.A.ld = C; g.A.bs1 = 64;
         g.B.ptr = x; g.B.kind = 1; g.B.gather = 1; g.B.bs1 = 64;
         g.B.H = H; g.B.W = W; g.B.C = 64; g.B.CS = C; g.B.PH = OH; g.B.PW = OW;
@@ -573,6 +578,7 @@ extern "C" int koaf_linear_dgrad(const float* dy, const float* w, const float* r
     KOAF_REQUIRE(dy && w && dx && M > 0 && N > 0 && K > 0, "koaf_linear_dgrad: bad args");
     KoafGemm g;
     zero_gemm(&g);
+    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
     g.A.ptr = dy; g.A.kind = 0; g.A.ld = N;
     g.B.ptr = w; g.B.kind = 1; g.B.ld = K;  // element (r = k_in, kk = n_out) at w + n_out*K + k_in
     g.M = M; g.N = K; g.K = N;
@@ -593,6 +599,7 @@ extern "C" int koaf_linear_wgrad(const float* dy, const float* x, float* dw, flo
     KOAF_REQUIRE(dy && x && dw && M > 0 && N > 0 && K > 0, "koaf_linear_wgrad: bad args");
     KoafGemm g;
     zero_gemm(&g);
+    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
     g.A.ptr = dy; g.A.kind = 1; g.A.ld = N;
     g.B.ptr = x; g.B.kind = 1; g.B.ld = K;
     g.M = N; g.N = K; g.K = M;
@@ -642,6 +649,7 @@ extern "C" int koaf_attention_bwd(const float* dout, const float* qkv, const flo
     int rc;
     // dV[j,dd] = sum_i P[i,j] dO[i,dd]
     zero_gemm(&g);
+    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
     g.nb0 = B; g.nb1 = h; g.bm = 64; g.bn = 64;
     g.A.ptr = attn; g.A.kind = 1; g.A.ld = n; g.A.bs0 = pb0; g.A.bs1 = pb1;
     g.B.ptr = dout; g.B.kind = 1; g.B.ld = hd; g.B.bs0 = n * hd; g.B.bs1 = d;
@@ -650,6 +658,7 @@ extern "C" int koaf_attention_bwd(const float* dout, const float* qkv, const flo
     if ((rc = koaf_gemm(&g, stream)) != KOAF_OK) return rc;
     // dP[i,j] = sum_dd dO[i,dd] V[j,dd]
     zero_gemm(&g);
+    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
     g.nb0 = B; g.nb1 = h; g.bm = 64; g.bn = 64;
     g.A.ptr = dout; g.A.kind = 0; g.A.ld = hd; g.A.bs0 = n * hd; g.A.bs1 = d;
     g.B.ptr = qkv + 2 * hd; g.B.kind = 0; g.B.ld = ld; g.B.bs0 = n * ld; g.B.bs1 = d;
@@ -660,6 +669,7 @@ extern "C" int koaf_attention_bwd(const float* dout, const float* qkv, const flo
     if ((rc = koaf_softmax_bwd_rows(ws, attn, (int64_t)B * h * n, n, scale, stream)) != KOAF_OK) return rc;
     // dQ[i,dd] = sum_j dS[i,j] K[j,dd]
     zero_gemm(&g);
+    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
     g.nb0 = B; g.nb1 = h; g.bm = 64; g.bn = 64;
     g.A.ptr = ws; g.A.kind = 0; g.A.ld = n; g.A.bs0 = pb0; g.A.bs1 = pb1;
     g.B.ptr = qkv + hd; g.B.kind = 1; g.B.ld = ld; g.B.bs0 = n * ld; g.B.bs1 = d;
@@ -668,6 +678,7 @@ extern "C" int koaf_attention_bwd(const float* dout, const float* qkv, const flo
     if ((rc = koaf_gemm(&g, stream)) != KOAF_OK) return rc;
     // dK[j,dd] = sum_i dS[i,j] Q[i,dd]
     zero_gemm(&g);
+    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
     g.nb0 = B; g.nb1 = h; g.bm = 64; g.bn = 64;
     g.A.ptr = ws; g.A.kind = 1; g.A.ld = n; g.A.bs0 = pb0; g.A.bs1 = pb1;
     g.B.ptr = qkv; g.B.kind = 1; g.B.ld = ld; g.B.bs0 = n * ld; g.B.bs1 = d;

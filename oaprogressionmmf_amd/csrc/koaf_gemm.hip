@@ -36,6 +36,9 @@ constexpr int LDK = BK + 4;
 #define KOAF_ISSUE_AT 0   // 0: next tile's loads go out at the top of the k-step (longest flight time);
 #endif                    // 1: between the MFMA groups
 
+#ifndef KOAF_BWD_TERMS
+#define KOAF_BWD_TERMS 4
+#endif
 #ifndef KOAF_XCD_SWIZZLE
 #define KOAF_XCD_SWIZZLE 1
 #endif
@@ -72,6 +75,22 @@ __device__ __forceinline__ void split3(const v4f x0, const v4f x1, v4i out[3]) {
 //                                                       ds_read_b64_tr_b16; k-row stride = 16 (mod 64) dwords)
 // Lane (r, h) of a 32x32x16 MFMA holds k = 16g + 8h + e (e = 0..7) of its row in both images.
 __host__ __device__ constexpr int plane_dwords(int rows, bool kc) { return kc ? rows * 20 : 32 * (rows / 2 + 16); }
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// four fp32 values -> two (hi, mid) pairs of dwords holding 4 packed bf16 each: hi by truncation (so x - hi is exact),
+// mid = the remainder rounded to nearest bf16.  hi + mid carries 16 significand bits of x, error <= 2^-17 |x|, zero mean.
+__device__ __forceinline__ void split2v(const v4f x, unsigned out[2][2]) {
+    float r1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r1[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & 0xffff0000u);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        out[0][d] = __builtin_amdgcn_perm(__float_as_uint(x[2 * d + 1]), __float_as_uint(x[2 * d]), 0x07060302u);
+        const bf16x2 m = {(__bf16)r1[2 * d], (__bf16)r1[2 * d + 1]};
+        out[1][d] = __builtin_bit_cast(unsigned, m);
+    }
+}
 
 // four fp32 values -> three (hi, mid, lo) pairs of dwords holding 4 packed bf16 each
 __device__ __forceinline__ void split3v(const v4f x, unsigned out[3][2]) {
@@ -342,30 +361,21 @@ struct TileLoader {
     }
 
 #if KOAF_SPLIT3 >= 2
+    template <int NPL>
     __device__ __forceinline__ void store(const Slot& s, float* Sf) const {
         unsigned* S = (unsigned*)Sf;
         constexpr int P = plane_dwords(ROWS, KC);
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            unsigned pl[3][2];
-            split3v(s.r[i], pl);
+            unsigned pl[NPL][2];
+            if constexpr (NPL == 3) split3v(s.r[i], pl); else split2v(s.r[i], pl);
             const int off = plane_off(i);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *(uint2*)&S[q * P + off] = make_uint2(pl[q][0], pl[q][1]);
-        }
-    }
-    // split already done (planes in registers): LDS stores only
-    __device__ __forceinline__ void store_planes(const unsigned (&pl)[NU][3][2], float* Sf) const {
-        unsigned* S = (unsigned*)Sf;
-        constexpr int P = plane_dwords(ROWS, KC);
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const int off = plane_off(i);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) *(uint2*)&S[q * P + off] = make_uint2(pl[i][q][0], pl[i][q][1]);
+            for (int q = 0; q < NPL; ++q) *(uint2*)&S[q * P + off] = make_uint2(pl[q][0], pl[q][1]);
         }
     }
 #else
+    template <int NPL>
     __device__ __forceinline__ void store(const Slot& s, float* S) const {
         const int t = threadIdx.x;
         if constexpr (KC) {
@@ -446,13 +456,15 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
     }
 }
 
-template <int BM, int BN, int AM, int BMD, bool TFA, bool TFB, bool VEC>
+// NPL = bf16 planes per operand: 3 = every significand bit (forward), 2 = operands rounded to 16 significand bits
+// (backward contractions, KoafGemm.prec == 1)
+template <int BM, int BN, int AM, int BMD, bool TFA, bool TFB, bool VEC, int NPL>
 __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr bool AKC = mode_is_kc(AM), BKC = mode_is_kc(BMD);
 #if KOAF_SPLIT3 == 2
     constexpr int A_PL = plane_dwords(BM, AKC), B_PL = plane_dwords(BN, BKC);
-    constexpr int A_ELEMS = 3 * A_PL, B_ELEMS = 3 * B_PL;
+    constexpr int A_ELEMS = NPL * A_PL, B_ELEMS = NPL * B_PL;
 #else
     constexpr int A_ELEMS = AKC ? BM * LDK : BK * BM;
     constexpr int B_ELEMS = BKC ? BN * LDK : BK * BN;
@@ -516,8 +528,8 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         lb.issue(lb.sa, p.B, Bp, kbeg, kend, z1);
         la.finish(la.sa);
         lb.finish(lb.sa);
-        la.store(la.sa, smem);
-        lb.store(lb.sa, smem + A_ELEMS);
+        la.template store<NPL>(la.sa, smem);
+        lb.template store<NPL>(lb.sa, smem + A_ELEMS);
     }
     __syncthreads();
     int cur = 0;
@@ -534,23 +546,28 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         for (int g = 0; g < 2; ++g) {
             const unsigned* Au = (const unsigned*)As;
             const unsigned* Bu = (const unsigned*)Bs;
-            v4i ap[TM][3], bp[3];
+            v4i ap[TM][NPL], bp[NPL];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) ap[i][q] = frag_load<BM, AKC>(Au + q * A_PL, wm * WM + 32 * i, g, lane);
+                for (int q = 0; q < NPL; ++q) ap[i][q] = frag_load<BM, AKC>(Au + q * A_PL, wm * WM + 32 * i, g, lane);
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) bp[q] = frag_load<BN, BKC>(Bu + q * B_PL, wn * WN + 32 * jn, g, lane);
+                for (int q = 0; q < NPL; ++q) bp[q] = frag_load<BN, BKC>(Bu + q * B_PL, wn * WN + 32 * jn, g, lane);
+                // piece products, smallest first.  3 planes: the six of weight >= 2^-16.  2 planes: all four (the exact
+                // product of the 16-bit operands), or without mid*mid when KOAF_BWD_TERMS == 3.
+                constexpr int NT = NPL == 3 ? 6 : KOAF_BWD_TERMS;
+                constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
+                constexpr int PA2[4] = {1, 1, 0, 0}, PB2[4] = {1, 0, 1, 0};
 #pragma unroll
-                for (int term = 0; term < 6; ++term) {
-                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-                    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+                for (int term = 0; term < NT; ++term) {
+                    const int pa = NPL == 3 ? PA3[term] : PA2[term + (4 - NT)];
+                    const int pb = NPL == 3 ? PB3[term] : PB2[term + (4 - NT)];
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[i][PA[term]]),
-                                                                             __builtin_bit_cast(bf16x8, bp[PB[term]]),
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[i][pa]),
+                                                                             __builtin_bit_cast(bf16x8, bp[pb]),
                                                                              acc[i][jn], 0, 0, 0);
                 }
             }
@@ -654,8 +671,8 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
                 float* An = smem + (cur ^ 1) * STAGE;
                 la.finish(la.sa);
                 lb.finish(lb.sa);
-                la.store(la.sa, An);
-                lb.store(lb.sa, An + A_ELEMS);
+                la.template store<NPL>(la.sa, An);
+                lb.template store<NPL>(lb.sa, An + A_ELEMS);
             }
             __syncthreads();
             cur ^= 1;
@@ -664,8 +681,8 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
             if (more) {
                 la.finish(la.sa);
                 lb.finish(lb.sa);
-                la.store(la.sa, smem);
-                lb.store(lb.sa, smem + A_ELEMS);
+                la.template store<NPL>(la.sa, smem);
+                lb.template store<NPL>(lb.sa, smem + A_ELEMS);
                 __syncthreads();
             }
         }
@@ -895,12 +912,12 @@ int operand_mode(const KoafOperand& o) {
 }
 
 #define KOAF_LAUNCH(AMODE, BMODE, TA, TB)                                                                        \
-    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC>), grid, dim3(256), 0, s, g);         \
+    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, NPL>), grid, dim3(256), 0, s, g);    \
     return koaf_check_launch("koaf_gemm")
 
 // the operand-mode pairs the library uses: conv fwd (KC|KC_G1 x KC), dgrad (KC x KM | KC_G2 x KM_G3),
 // wgrad (KM x KM|KM_G1), linear / attention (dense pairs).  tf only where a BatchNorm prologue exists.
-template <int BM, int BN, bool VEC>
+template <int BM, int BN, bool VEC, int NPL>
 int launch_modes(const KoafGemm& g, dim3 grid, hipStream_t s) {
     const int am = operand_mode(g.A), bm = operand_mode(g.B);
     const bool ta = g.A.tf != 0, tb = g.B.tf != 0;
@@ -939,6 +956,13 @@ extern "C" int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn) 
 }
 
 namespace {
+// KoafGemm.prec == 1 contractions (weight / data gradients) run on two bf16 planes per operand unless the environment
+// says KOAF_BWD_PRECISION=full (read once)
+bool reduced_backward() {
+    static const bool on = [] { const char* e = getenv("KOAF_BWD_PRECISION"); return !(e && e[0] == 'f'); }();
+    return on;
+}
+
 struct TilePlan { int bm, bn; bool vec; int m_split; int part_rows; };   // m_split > 0: mixed-height tiling
 
 bool gemm_vec_ok(const KoafGemm& g) {
@@ -1025,11 +1049,18 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
         if (tiles <= 0) return KOAF_OK;
         if (tiles >= (1ll << 31)) { koaf_set_error("koaf_gemm: grid too large"); return KOAF_EINVAL; }
         dim3 grid((unsigned)tiles, (unsigned)q.splitk, (unsigned)(q.nb0 * q.nb1));
-        if (!vec) return launch_modes<64, 64, false>(q, grid, s);
-        if (qbm == 128 && qbn == 128) return launch_modes<128, 128, true>(q, grid, s);
-        if (qbm == 128 && qbn == 64) return launch_modes<128, 64, true>(q, grid, s);
-        if (qbm == 64 && qbn == 128) return launch_modes<64, 128, true>(q, grid, s);
-        return launch_modes<64, 64, true>(q, grid, s);
+        if (q.prec == 1 && reduced_backward()) {
+            if (!vec) return launch_modes<64, 64, false, 2>(q, grid, s);
+            if (qbm == 128 && qbn == 128) return launch_modes<128, 128, true, 2>(q, grid, s);
+            if (qbm == 128 && qbn == 64) return launch_modes<128, 64, true, 2>(q, grid, s);
+            if (qbm == 64 && qbn == 128) return launch_modes<64, 128, true, 2>(q, grid, s);
+            return launch_modes<64, 64, true, 2>(q, grid, s);
+        }
+        if (!vec) return launch_modes<64, 64, false, 3>(q, grid, s);
+        if (qbm == 128 && qbn == 128) return launch_modes<128, 128, true, 3>(q, grid, s);
+        if (qbm == 128 && qbn == 64) return launch_modes<128, 64, true, 3>(q, grid, s);
+        if (qbm == 64 && qbn == 128) return launch_modes<64, 128, true, 3>(q, grid, s);
+        return launch_modes<64, 64, true, 3>(q, grid, s);
     };
     if (tp.m_split >= 0) {
         KoafGemm a = g, b = g;
