@@ -39,10 +39,13 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak, v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md, chip-level table)
-# The GEMM computes fp32 x fp32 products on the bf16 matrix pipe: each operand is cut exactly into three bf16 pieces
-# and six v_mfma_f32_32x32x16_bf16 carry the piece products of weight >= 2^-16 (koaf_gemm.hip, split3).  The bound
-# of that kernel is the dense bf16 MFMA peak (2.5 PFLOP/s, same table) divided by the six MFMAs per product.
-MFMA_SPLIT3_PEAK_TFLOPS = 2500.0 / 6
+# The GEMM computes fp32 x fp32 products on the bf16 matrix pipe (koaf_gemm.hip): forward contractions cut each operand
+# exactly into three bf16 pieces and issue the six piece products of weight >= 2^-16 as v_mfma_f32_32x32x16_bf16;
+# gradient contractions round the operands to 16 significand bits (two pieces) and issue all four products.  The bound of
+# a call is the dense bf16 MFMA peak (2.5 PFLOP/s, same table) divided by its MFMAs per product; the bound of the step's
+# mix is the FLOP-weighted harmonic mean over its calls.
+BF16_MFMA_PEAK_TFLOPS = 2500.0
+MFMA_PER_PRODUCT_FWD, MFMA_PER_PRODUCT_BWD = 6, 4
 
 
 def workload_cfg(name):
@@ -266,6 +269,15 @@ def main():
             for tag, (n, fl, ms) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
                 fh.write(f"{tag:48s} {n:4d} {ms:9.3f} {fl / 1e9:10.1f} {fl / ms / 1e9 if ms > 0 else 0:8.1f}\n")
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    full_bwd = os.environ.get("KOAF_BWD_PRECISION", "")[:1] == "f"
+
+    def call_peak(tag):
+        bwd = any(k in tag for k in ("dgrad", "wgrad", "attn_bwd")) and not full_bwd
+        return BF16_MFMA_PEAK_TFLOPS / (MFMA_PER_PRODUCT_BWD if bwd else MFMA_PER_PRODUCT_FWD)
+    bound_s = sum(fl / (call_peak(tag) * 1e12) for f, fl, ms, tag in prof if f == "gemm")
+    peak_mix = gemm_flop / bound_s / 1e12 if bound_s > 0 else BF16_MFMA_PEAK_TFLOPS / MFMA_PER_PRODUCT_FWD
+    bwd_share = sum(fl for f, fl, ms, tag in prof if f == "gemm" and any(k in tag for k in ("dgrad", "wgrad", "attn_bwd")))
+    bwd_share = bwd_share / gemm_flop if gemm_flop else 0.0
     # HBM-side bytes per launch of the dominant kernel cannot be counted from inside the process: they come from
     # the committed PMC summary of this same workload (profiles/README.md has the command and the corrections)
     traffic, traffic_src = None, None
@@ -300,12 +312,16 @@ def main():
                        "parallelism": f"dp{world}", "last_loss": round(lv, 6), "activation_recompute": bool(args.recompute),
                        "hbm_peak_gib": {"allocated": hbm_gb[0], "reserved": hbm_gb[1]}},
             **({"pinned_reference_model": pinned} if pinned else {}),
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(MFMA_SPLIT3_PEAK_TFLOPS, 1),
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_SPLIT3_PEAK_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak_mix, 1),
+                         "unit": "TFLOP/s", "frac": round(achieved / peak_mix, 4), "traffic": traffic,
                          "traffic_unit": "bytes per koaf_gemm_kernel launch (average)", "traffic_source": traffic_src,
                          "kernel": "koaf_gemm_kernel (implicit GEMM: conv fwd/dgrad/wgrad, linear, attention; fp32 in/out/"
-                                   "accumulate, products as 6 x v_mfma_f32_32x32x16_bf16 on an exact 3-way bf16 split)",
-                         "peak_is": "2.5 PFLOP/s dense bf16 MFMA / 6 MFMAs per fp32 product (fp32-equivalent TFLOP/s)",
+                                   "accumulate; products on v_mfma_f32_32x32x16_bf16 from bf16 pieces of the operands: "
+                                   "forward 3 pieces / 6 products (every significand bit), gradients 2 pieces / 4 products "
+                                   "(16 significand bits))",
+                         "peak_is": "2.5 PFLOP/s dense bf16 MFMA / MFMAs per product, FLOP-weighted harmonic mean over the "
+                                    f"step's calls ({100 * bwd_share:.0f} % of the FLOPs are gradient contractions at 625, "
+                                    "the rest at 416.7 TFLOP/s fp32-equivalent)",
                          "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
                          "achieved_over_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                          "launches_per_step": n_launch, "kernel_ms_per_step": round(gemm_ms, 2),

@@ -3,6 +3,7 @@
 // All are float4-vectorised along the channel (fastest) axis and sized for >= 8 blocks per CU.
 #include <stdarg.h>
 #include "koaf_common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -21,9 +22,14 @@ namespace {
 
 constexpr int EB = 256;  // elementwise block
 
+// grid cap of the grid-stride element-wise kernels, in blocks per CU (KOAF_EW_BLOCKS_PER_CU, default 32)
+inline int ew_blocks_per_cu() {
+    static const int v = [] { const char* e = getenv("KOAF_EW_BLOCKS_PER_CU"); int n = e ? atoi(e) : 32; return n < 1 ? 1 : n; }();
+    return v;
+}
 inline unsigned ew_grid(int64_t nvec) {
     int64_t b = cdiv64(nvec, EB);
-    if (b > 256 * 32) b = 256 * 32;
+    if (b > 256 * ew_blocks_per_cu()) b = 256 * ew_blocks_per_cu();
     if (b < 1) b = 1;
     return (unsigned)b;
 }
