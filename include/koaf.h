@@ -102,6 +102,10 @@ typedef struct KoafGemm {
     int32_t m_base, part_row0;
 } KoafGemm;
 
+/* Precision of the gradient contractions (KoafGemm.prec == 1) for this process: full != 0 -> every significand bit
+ * like the forward; 0 -> 16-bit operands (default); negative -> back to the environment (KOAF_BWD_PRECISION=full).
+ * Returns the previous setting (1 = full, 0 = 16-bit).  Not a per-stream state: set it between steps. */
+int koaf_set_backward_precision(int32_t full);
 int koaf_gemm(const KoafGemm* g, void* stream);
 /* block tile koaf_gemm picks for (M, N, batch) when bm = bn = 0 */
 int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn);

@@ -958,9 +958,10 @@ extern "C" int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn) 
 namespace {
 // KoafGemm.prec == 1 contractions (weight / data gradients) run on two bf16 planes per operand unless the environment
 // says KOAF_BWD_PRECISION=full (read once)
+int g_bwd_full = -1;     // -1: not set by koaf_set_backward_precision -> environment decides
 bool reduced_backward() {
-    static const bool on = [] { const char* e = getenv("KOAF_BWD_PRECISION"); return !(e && e[0] == 'f'); }();
-    return on;
+    static const bool env_on = [] { const char* e = getenv("KOAF_BWD_PRECISION"); return !(e && e[0] == 'f'); }();
+    return g_bwd_full < 0 ? env_on : (g_bwd_full == 0);
 }
 
 struct TilePlan { int bm, bn; bool vec; int m_split; int part_rows; };   // m_split > 0: mixed-height tiling
@@ -1009,6 +1010,12 @@ extern "C" int koaf_gemm_part_rows(const KoafGemm* gp) {
     if (g.nb1 < 1) g.nb1 = 1;
     if (g.splitk < 1) g.splitk = 1;
     return plan_tiles(g).part_rows;
+}
+
+extern "C" int koaf_set_backward_precision(int32_t full) {
+    const int prev = reduced_backward() ? 0 : 1;
+    g_bwd_full = full < 0 ? -1 : (full ? 1 : 0);
+    return prev;
 }
 
 extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {

@@ -307,6 +307,12 @@ def downscale2(x, B, R, Cc, S, fs):
 # ------------------------------------------------------------------------------------------------
 # transformer pieces
 # ------------------------------------------------------------------------------------------------
+def set_backward_precision(full):
+    """full=True: gradient contractions carry every significand bit; False: 16-bit operands (default); None: follow
+    KOAF_BWD_PRECISION.  Returns the previous setting (bool)."""
+    return bool(lib().koaf_set_backward_precision(-1 if full is None else int(bool(full))))
+
+
 def minmax(x, B):
     """per-sample (min, max) of a contiguous batch -> [B, 2]"""
     n = x.numel() // B
