@@ -35,6 +35,8 @@ class DataParallelRCCL(nn.Module):
         self._pending = None
         self._handles = []
         self._seen = []
+        self._streams = None       # per bucket: the HIP streams its gradients were delivered on this step
+        self._comm = None          # staging stream the early all-reduces are ordered on
 
     # -- setup -------------------------------------------------------------------------------------
     def arena(self):
@@ -71,6 +73,7 @@ class DataParallelRCCL(nn.Module):
         self._seen = []
         if self._plan is not None:
             self._pending = [set(b["need"]) for b in self._plan]
+            self._streams = [set() for _ in self._plan]
 
     def _on_ready(self, p):
         self._seen.append(p)
@@ -82,9 +85,28 @@ class DataParallelRCCL(nn.Module):
             return
         pend = self._pending[bi]
         pend.discard(pid)
+        if p.is_cuda:
+            self._streams[bi].add(torch.cuda.current_stream())
         if not pend:
-            b = self._plan[bi]
-            self._handles.append(dist.all_reduce(self._arena.G[b["lo"]:b["hi"]], group=self.pg, async_op=True))
+            self._launch(bi)
+
+    def _launch(self, bi):
+        """all-reduce of bucket bi.  The encoders run on several HIP streams ("lanes") and a 128 MB bucket can hold
+        gradients of two of them, delivered on different streams; the collective is therefore ordered behind EVERY
+        stream that delivered into the bucket, on a staging stream of its own so that no compute lane has to wait."""
+        b = self._plan[bi]
+        g = self._arena.G[b["lo"]:b["hi"]]
+        if not g.is_cuda:
+            self._handles.append(dist.all_reduce(g, group=self.pg, async_op=True))
+            return
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=g.device)
+        streams = self._streams[bi] if self._streams is not None else set()
+        streams = set(streams) | {torch.cuda.current_stream()}
+        for st in streams:
+            self._comm.wait_stream(st)
+        with torch.cuda.stream(self._comm):
+            self._handles.append(dist.all_reduce(g, group=self.pg, async_op=True))
 
     def _build_plan(self, params):
         a = self._arena
@@ -110,16 +132,16 @@ class DataParallelRCCL(nn.Module):
             # first step: learn which parameters receive gradients, reduce everything now
             params = [p for p in a.params if p.grad is not None]
             self._build_plan(params)
-            for b in self._plan:
-                self._handles.append(dist.all_reduce(a.G[b["lo"]:b["hi"]], group=self.pg, async_op=True))
+            self._streams = None
+            for bi in range(len(self._plan)):
+                self._launch(bi)
         else:
             # anything not launched from the hook (a parameter skipped this step) goes now
             for bi, pend in enumerate(self._pending):
                 if pend:
-                    b = self._plan[bi]
-                    self._handles.append(dist.all_reduce(a.G[b["lo"]:b["hi"]], group=self.pg, async_op=True))
+                    self._launch(bi)
         for h in self._handles:
-            h.wait()
+            h.wait()             # the caller's stream waits for the collectives (which ran behind the staging stream)
         self._handles = []
 
     # module protocol pass-throughs used by the train driver / checkpoint handler
