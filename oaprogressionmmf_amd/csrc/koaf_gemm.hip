@@ -36,6 +36,9 @@ constexpr int LDK = BK + 4;
 #define KOAF_ISSUE_AT 0   // 0: next tile's loads go out at the top of the k-step (longest flight time);
 #endif                    // 1: between the MFMA groups
 
+#ifndef KOAF_DB_BWD
+#define KOAF_DB_BWD 0     // 1: LDS double buffer for the two-plane (gradient) kernels (80 KB at 128x128): measured mixed (+8 % / -15 %), off
+#endif
 #ifndef KOAF_BWD_TERMS
 #define KOAF_BWD_TERMS 4
 #endif
@@ -473,7 +476,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     // LDS double buffering (one barrier per k-step) only where it does not cost a resident block: the 128x128
     // tile is register-limited to 2 blocks/CU either way; the rectangular tiles fit 3 blocks single-buffered
     // (27 KB) but only 2 double-buffered (55 KB), and the third block hides more than the saved barrier.
-    constexpr bool DB = KOAF_SPLIT3 == 2 ? false : (KOAF_DB_ALL ? true : (BM == BN));
+    constexpr bool DB = KOAF_SPLIT3 == 2 ? (KOAF_DB_BWD && NPL == 2) : (KOAF_DB_ALL ? true : (BM == BN));
     constexpr int NSTAGE = DB ? 2 : 1;
     constexpr int LDC_S = BN + 4;                                    // epilogue staging row (floats)
     constexpr int C_ELEMS = VEC ? BM * LDC_S : 0;
