@@ -1,0 +1,72 @@
+"""GPU: edge shapes through the registry models against the oracle -- batch 1, odd (non multiple-of-32) image sizes
+that leave ragged GEMM tiles and partial pooling windows, a single-slice volume, the 'cs' / 'rs' slice folds, and
+inputs handed over as non-contiguous views.  Forward / loss 2e-4; gradients under the branch-aware bar of
+common.check_grads_branchy."""
+import numpy as np
+import pytest
+import torch
+
+import procedural as P
+from common import check_grads_branchy, rel
+from test_models_gpu import build, t
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cfg, B, dev, seed=21, views=False):
+    from oracle import koafusion_cpu as O
+    from oaprogressionmmf_amd.various import dict_losses
+    xs = [t(a) for a in P.model_inputs(cfg, B, seed)]
+    y = t(P.make_target("target", B, seed))
+    m = build(cfg, dev)
+    o32 = O.OracleModel(cfg, fill=P.fill_value)
+    o64 = O.OracleModel(cfg, fill=P.fill_value, dtype=torch.float64)
+    xd = [x.to(dev) for x in xs]
+    if views:       # strided views: channel-expanded then sliced, and a transposed-back volume
+        xd = [torch.cat([x, x], 1)[:, 1:2] if x.ndim == 4 else x.transpose(2, 3).contiguous().transpose(2, 3) for x in xd]
+        assert any(not x.is_contiguous() for x in xd)
+    m.eval()
+    with torch.no_grad():
+        le = m(*xd)["main"]
+        lo = o32(*xs, train=False)
+    assert rel(le.cpu().numpy(), lo.numpy()) < 2e-4, "eval logits"
+    m.train()
+    loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
+    lg = m(*xd)["main"]
+    loss = loss_fn(input=lg.squeeze(1), target=y.to(dev).long().squeeze(1))
+    loss.backward()
+    lg32, _ = o32.train_step(xs, y, optimize=False)
+    lg64, loss64 = o64.train_step(xs, y, optimize=False)
+    assert rel(lg.detach().cpu().numpy(), lg32.numpy()) < 2e-4, "train logits"
+    assert abs(loss.item() - loss64.item()) < 2e-4 * max(1.0, abs(loss64.item()))
+    truth = {k: p.grad.numpy() for k, p in o64.named_parameters() if p.grad is not None}
+    noise = {k: rel(p.grad.numpy(), truth[k]) for k, p in o32.named_parameters() if p.grad is not None}
+    mine = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None}
+    assert sorted(mine) == sorted(truth)
+    head = ("_final.", "_agg.", "_agg_final.") if cfg["name"] == "XR1Cnn" else ("_agg.", "_agg_", "_agg_final.")
+    check_grads_branchy(mine, truth, lambda k: k.startswith(head), cfg["name"], noise=noise)
+
+
+def test_batch_of_one(dev):
+    _run(P.cfg_xr1cnn(arch="resnet18", size=160), 1, dev)
+    _run(P.cfg_xr1mr1(xr=(96, 96), mr=(64, 64, 3), depth=1), 1, dev)
+
+
+def test_odd_image_sizes(dev):
+    # pooled encoders accept any size: 150x170 radiographs, 70x90x3 volumes (ragged GEMM tiles, partial pool windows)
+    cfg = P.cfg_xr1cnn(arch="resnet34", size=160)
+    cfg = dict(cfg, input_size=[[150, 170]])
+    _run(cfg, 3, dev)
+    cfg = P.cfg_mr1(shape=(64, 64, 32), depth=1)
+    cfg = dict(cfg, input_size=[[70, 90, 3]], agg=dict(cfg["agg"]))
+    _run(cfg, 2, dev)
+
+
+def test_single_slice_and_other_folds(dev):
+    _run(P.cfg_mr1(shape=(96, 96, 32), depth=1), 2, dev)
+    for view in ("cs", "rs"):
+        _run(P.cfg_mr1(shape=(32, 64, 64), dims_view=view, depth=1), 2, dev)
+
+
+def test_non_contiguous_inputs(dev):
+    _run(P.cfg_xr1mr1(xr=(96, 96), mr=(64, 64, 4), depth=1), 2, dev, views=True)
