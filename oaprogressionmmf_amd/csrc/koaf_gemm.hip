@@ -949,9 +949,11 @@ extern "C" int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn) 
     if (b_m == 0) b_m = (g->M >= 128) ? 128 : 64;
     if (g->bm == 0 || g->bn == 0) {
         auto tiles = [&](int m, int n) { return cdiv64(g->M, m) * cdiv64(g->N, n) * batch; };
-        // fill the 256 CUs: shrink the tile while the grid is under ~2 blocks per CU
-        if (g->bm == 0 && tiles(b_m, b_n) < 512 && b_m == 128) b_m = 64;
-        if (g->bn == 0 && tiles(b_m, b_n) < 512 && b_n == 128) b_n = 64;
+        // fill the 256 CUs: shrink the tile while the grid is under `fill` blocks (KOAF_TILE_FILL, default 384 = 1.5 per CU:
+        // a single 78 %-full round of 128x128 tiles beats two rounds of the 1.25x costlier 64-row tiles; measured 512 / 384 / 256)
+        static const int64_t fill = [] { const char* e = getenv("KOAF_TILE_FILL"); return (int64_t)(e ? atoi(e) : 384); }();
+        if (g->bm == 0 && tiles(b_m, b_n) < fill && b_m == 128) b_m = 64;
+        if (g->bn == 0 && tiles(b_m, b_n) < fill && b_n == 128) b_n = 64;
     }
     *bm = b_m;
     *bn = b_n;
