@@ -2,6 +2,7 @@
 // pieces that are not GEMM-shaped: the 1-channel 7x7 stem and the grouped-conv weight expansion.
 #include <string.h>
 #include "koaf_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -538,11 +539,19 @@ extern "C" int koaf_stem_unfold_dw(const float* dw1t, float* dw, void* stream) {
 // ================================================================================================
 // split-K plan for a linear layer with few rows: the 64x64-tile grid of M x N is only a few hundred blocks with
 // K/32 serial k-steps each (latency-bound at ~1 block per CU); splitting K 2-8 ways fills the chip.
+static int linear_tile(int M, int N) {
+    // 128x128 tiles (half the loader / split work per FLOP of 64x64) once both dimensions offer a few of them
+    static const int forced = [] { const char* e = getenv("KOAF_LIN_TILE"); return e ? atoi(e) : 0; }();
+    if (forced == 64 || forced == 128) return forced;
+    return (M >= 512 && N >= 512) ? 128 : 64;
+}
 static int linear_splitk(int M, int N, int K) {
     if ((N & 3) || K < 512) return 1;
-    const int64_t tiles = cdiv64(M, 64) * cdiv64(N, 64);
-    if (tiles >= 1024) return 1;
-    int sk = (int)(1024 / tiles);
+    const int t = linear_tile(M, N);
+    const int64_t tiles = cdiv64(M, t) * cdiv64(N, t);
+    const int64_t want = t == 128 ? 512 : 1024;
+    if (tiles >= want) return 1;
+    int sk = (int)(want / tiles);
     if (sk > 8) sk = 8;
     while (sk > 1 && K / sk < 256) --sk;
     return sk;
@@ -562,7 +571,7 @@ extern "C" int koaf_linear_fwd(const float* x, const float* w, const float* b, c
     g.M = M; g.N = N; g.K = K;
     const int sk = ws ? linear_splitk(M, N, K) : 1;
     if (sk > 1) {
-        g.splitk = sk; g.bm = 64; g.bn = 64;
+        g.splitk = sk; g.bm = g.bn = linear_tile(M, N);
         g.C = ws; g.ldc = N;
         int rc = koaf_gemm(&g, stream);
         if (rc != KOAF_OK) return rc;
@@ -584,7 +593,7 @@ extern "C" int koaf_linear_dgrad(const float* dy, const float* w, const float* r
     g.M = M; g.N = K; g.K = N;
     const int sk = ws ? linear_splitk(M, K, N) : 1;
     if (sk > 1) {
-        g.splitk = sk; g.bm = 64; g.bn = 64;
+        g.splitk = sk; g.bm = g.bn = linear_tile(M, K);
         g.C = ws; g.ldc = K;
         int rc = koaf_gemm(&g, stream);
         if (rc != KOAF_OK) return rc;
