@@ -13,8 +13,25 @@ def _rng(key, salt=0):
     return np.random.default_rng(zlib.crc32(key.encode()) + 1000003 * salt)
 
 
+_FILL_CACHE, _FILL_BYTES, _FILL_CAP = {}, [0], 6 << 30
+
+
 def fill_value(key, shape, is_int=False):
-    """Deterministic value for state_dict entry `key` (numpy array, float32 or int64)."""
+    """Deterministic value for state_dict entry `key` (numpy array, float32 or int64).  The generated arrays are cached
+    (the product model and the float32 / float64 oracles of one test ask for the same ones); callers get a copy."""
+    ck = (key, tuple(shape), bool(is_int))
+    hit = _FILL_CACHE.get(ck)
+    if hit is None:
+        hit = _fill_value(key, shape, is_int)
+        if _FILL_BYTES[0] + hit.nbytes > _FILL_CAP:
+            _FILL_CACHE.clear()
+            _FILL_BYTES[0] = 0
+        _FILL_CACHE[ck] = hit
+        _FILL_BYTES[0] += hit.nbytes
+    return hit.copy()
+
+
+def _fill_value(key, shape, is_int=False):
     shape = tuple(shape)
     if is_int or key.endswith("num_batches_tracked"):
         return np.zeros(shape, dtype=np.int64)

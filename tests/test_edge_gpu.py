@@ -63,9 +63,11 @@ def test_odd_image_sizes(dev):
 
 
 def test_single_slice_and_other_folds(dev):
-    _run(P.cfg_mr1(shape=(96, 96, 32), depth=1), 2, dev)
-    for view in ("cs", "rs"):
-        _run(P.cfg_mr1(shape=(32, 64, 64), dims_view=view, depth=1), 2, dev)
+    cfg = P.cfg_mr1(shape=(96, 96, 32), depth=1)
+    _run(dict(cfg, input_size=[[96, 96, 1]]), 3, dev)           # one slice per volume: a single image token + cls
+    for view, shape in (("cs", (12, 64, 48)), ("rs", (48, 10, 64))):
+        cfg = P.cfg_mr1(shape=(32, 64, 64), dims_view=view, depth=1)
+        _run(dict(cfg, input_size=[list(shape)]), 2, dev)
 
 
 def test_non_contiguous_inputs(dev):

@@ -18,7 +18,7 @@ CASES = {
     "XR1C1Cnn": lambda: (P.cfg_xr1c1(arch="resnet18", size=160), 4),
     "XR1C1Cnn_x50": lambda: (P.cfg_xr1c1(size=160), 3),
     "MR1C1CnnTrf": lambda: (P.cfg_mr1c1(mr=(96, 96, 6), depth=1), 2),
-    "XR1MR3C1CnnTrf": lambda: (P.cfg_xr1mr3c1(xr=(160, 160), mr1=(96, 96, 6), mr2=(96, 96, 4), mr3=(64, 64, 5),
+    "XR1MR3C1CnnTrf": lambda: (P.cfg_xr1mr3c1(xr=(96, 96), mr1=(64, 64, 4), mr2=(64, 64, 3), mr3=(32, 32, 5),
                                               depth=1), 2),
 }
 
