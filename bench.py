@@ -32,7 +32,9 @@ import sys
 import time
 from pathlib import Path
 
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL on this pool (already exported there)
+
+import torch  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
