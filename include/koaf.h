@@ -6,7 +6,7 @@
  *   koafusion/models/_torchvision.py:118-138,141-246   (conv / BatchNorm2d / ReLU / MaxPool / GAP)
  *   koafusion/models/_core_trf.py:118-205               (Linear / LayerNorm / GELU / attention)
  *   koafusion/various/_losses.py:89-108                 (focal softmax-CE)
- *   koafusion/preproc/_pt.py:175-200                    (F.interpolate x0.5 downscale)
+ *   koafusion/preproc/_pt.py:75-345                     (F.interpolate x0.5 downscale; the per-sample tensor transforms)
  *   torch.optim.Adam via koafusion/various/_optimizers.py:47-52
  * Each entry point below names the reference call site it replaces.  All pointers are DEVICE
  * pointers to fp32 (unless stated), all tensors are dense; activations are NHWC ("(n,h,w,c)",
@@ -31,7 +31,10 @@ const char* koaf_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Generic MFMA GEMM  C[M,N] = alpha * sum_k A(m,k) B(n,k)  (+bias[n]) (+residual[m,n])
- * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain).
+ * fp32 in / fp32 out / fp32 accumulate.  Products are formed on the bf16 matrix pipe from exact bf16 pieces of the
+ * fp32 operands (v_mfma_f32_32x32x16_bf16): prec 0 = three pieces per operand, every significand bit, error at fp32
+ * rounding level; prec 1 = two pieces, operands rounded to 16 significand bits (see KoafGemm.prec).  An Inf operand
+ * yields NaN; NaN stays NaN.
  * Each operand is either K-contiguous ("KC": element (r,k) at ptr + r*ld + k) or K-major
  * ("KM": element (r,k) at ptr + k*ld + r).  Operands can be gathered on the fly from an NHWC
  * tensor (implicit-GEMM convolution) and transformed on load with relu(sc[c]*x+sh[c]) -- the
