@@ -21,7 +21,7 @@ Workloads:
                     (default per-GPU batch 2; batch 8 needs --recompute).
   xr1cnn / xr1c1    BASELINE configs 1 / 2 (XR1Cnn B=4; extension XR1C1Cnn = XR + clinical MLP head, B=32) @350^2.
   mr1 / mr1c1       BASELINE config 3: MR1CnnTrf B=4 @160x160x64; extension MR1C1CnnTrf (DESS + clinical) B=4 @384x384x160.
-The JSON line carries `roofline` for the dominant kernel (the fp32 MFMA GEMM, timed live with events on the
+The JSON line carries `roofline` for the dominant kernel (the MFMA GEMM, timed live with events on the
 launch stream over one extra instrumented step) and `cpu_baseline` (the oracle = CPU port of the same step,
 timed on this box's host cores on a bounded sample).
 """

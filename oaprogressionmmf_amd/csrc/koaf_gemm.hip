@@ -11,7 +11,9 @@
 // against float64 the result is as accurate as the fp32-MFMA path (KOAF_SPLIT3 == 0, kept for comparison) and
 // rocBLAS sgemm (scripts/gemm_accuracy.py).  Six 8-pass MFMAs replace eight 16-pass fp32 MFMAs per 16 k: the
 // matrix-pipe bound rises from 157 to 2500/6 = 417 TFLOP/s fp32-equivalent.  Inf operands become NaN (inf - inf
-// in the split); NaN stays NaN.
+// in the split); NaN stays NaN.  Gradient contractions (KoafGemm.prec == 1, template NPL = 2) keep two pieces -- hi by
+// truncation, mid = the remainder rounded to nearest, i.e. the operand rounded to 16 significand bits -- and issue all
+// four piece products: ~7e-6 relative error, four MFMAs instead of six, two LDS planes.
 //
 // Block = 256 threads = 4 waves (2x2), block tile BM x BN x 32, wave tile (BM/2) x (BN/2) built from 32x32 MFMA
 // tiles; 2 blocks per CU.  Operand tiles are staged global -> registers (fused BN+ReLU prologue, zero fill) ->
@@ -112,7 +114,7 @@ __device__ __forceinline__ void split3v(const v4f x, unsigned out[3][2]) {
 }
 
 // operand access modes (compile-time: the loaders are straight-line code, so hipcc can schedule their
-// address arithmetic into the shadows of the 64-cycle fp32 MFMAs)
+// address arithmetic into the shadows of the MFMAs)
 enum { M_KC = 0,     // K-contiguous rows, dense
        M_KC_G1 = 1,  // K-contiguous, conv forward gather (NHWC source)
        M_KC_G2 = 2,  // K-contiguous, transposed-conv (dgrad) gather
