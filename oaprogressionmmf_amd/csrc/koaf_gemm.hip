@@ -30,7 +30,7 @@
 namespace {
 
 constexpr int BK = 32;
-constexpr int LDK = BK + 4;
+[[maybe_unused]] constexpr int LDK = BK + 4;   // fp32 LDS row of the KOAF_SPLIT3 < 2 builds
 #ifndef KOAF_DB_ALL
 #define KOAF_DB_ALL 0
 #endif
