@@ -240,3 +240,31 @@ def test_batch_augment_draws_like_the_reference_transforms():
     assert random.getstate() == s0
     with pytest.raises(NotImplementedError):
         PTBatchAugment(mean=0., std=1., clip_to_unit=True)
+
+
+def test_bench_workloads_are_constructible():
+    """bench.py's workload table: every name yields a config the registry accepts (constructed on the CPU, nothing
+    computed), has an algorithmic-FLOP entry, and -- where a CPU baseline is taken -- one the oracle can state"""
+    import importlib.util
+    from oracle import koafusion_cpu as O
+    from oaprogressionmmf_amd.config import ConfigDict
+    from oaprogressionmmf_amd.models import dict_models
+    spec = importlib.util.spec_from_file_location("koaf_bench", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    names = ("native3", "native", "syn", "syn3", "xr1cnn", "xr1c1", "mr1", "mr1c1")
+    for name in names:
+        cfg, b = bench.workload_cfg(name)
+        assert b >= 1 and bench.algorithmic_train_gflop_per_sample(name) > 0
+        shapes = cfg.pop("_tensor_shapes", None)
+        if name not in ("syn", "syn3", "mr1c1", "native3", "native"):        # (the big ones: ~0.4-0.6 G parameters each)
+            m = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None)
+            spec_o, _ = O.model_spec(cfg)
+            assert sorted(k for k, _ in m.state_dict().items()) == sorted(k for k, _, _ in spec_o)
+        if shapes is not None:
+            assert len(shapes) == len(cfg["input_size"])
+        ins = P.model_inputs(dict(cfg, input_size=[[8, 8] if len(s) == 2 else ([8, 8, 2] if len(s) == 3 else s)
+                                                  for s in cfg["input_size"]]), 1)
+        assert len(ins) == len(cfg["input_size"])
+    with pytest.raises(SystemExit):
+        bench.workload_cfg("nope")
