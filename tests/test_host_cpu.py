@@ -280,7 +280,8 @@ def test_model_config_groups_load():
     for n in names:
         cfg = load_model_config(n)
         assert cfg["name"] in dict_models and len(cfg["input_size"]) == len(cfg["downscale"])
-        if "num_slices" in cfg["agg"]:
-            assert len(cfg["agg"]["num_slices"]) == len(cfg["input_size"])
+        ns = cfg["agg"].get("num_slices") if hasattr(cfg["agg"], "get") else None
+        if isinstance(ns, (list, tuple)):
+            assert len(ns) == len(cfg["input_size"])
     m = dict_models["XR1C1Cnn"](config=load_model_config("xr1c1_cnn"), path_weights=None)
     assert m.vs["agg_in_len"] == 4096
