@@ -14,7 +14,7 @@ inline int conv_out(int H, int K, int s, int p) { return (H + 2 * p - K) / s + 1
 struct WgradPlan { int bm, bn, splitk; };
 inline WgradPlan wgrad_plan(int M, int N, int64_t K, int ctap, int batch) {
     WgradPlan p;
-    p.bn = (N >= 128 && (ctap % 128) == 0) ? 128 : 64;
+    p.bn = (N >= 128 && (ctap % 4) == 0) ? 128 : 64;      // (a B tile may span filter taps)
     p.bm = (M >= 128) ? 128 : 64;
     int64_t tiles = cdiv64(M, p.bm) * cdiv64(N, p.bn) * batch;
     int64_t sk = 1024 / tiles;

@@ -189,7 +189,8 @@ struct TileLoader {
             for (int j = 0; j < 4; ++j) cvm |= ((col + j) < R ? 1u : 0u) << j;
             cc = col;
             if constexpr (MODE == M_KM_G1) {
-                const int tap = r0 / op.C;
+                // this thread's own filter tap (its 4 columns lie in one tap: C % 4 == 0), so a tile may span taps
+                const int tap = col / op.C;
                 cc = col - tap * op.C;
                 kh_ = tap / op.KW;
                 kw_ = tap - kh_ * op.KW;
@@ -945,8 +946,8 @@ extern "C" int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn) 
     const int64_t batch = (int64_t)g->nb0 * g->nb1 * (g->splitk > 0 ? g->splitk : 1);
     if (b_n == 0) {
         b_n = (g->N >= 128) ? 128 : 64;
-        // a gathered K-major B tile must stay inside one filter tap
-        if (g->B.kind == 1 && g->B.gather == 1 && (g->B.C % b_n) != 0) b_n = 64;
+        // (a gathered K-major B tile may span filter taps: every thread derives the tap of its own 4 columns)
+        if (g->B.kind == 1 && g->B.gather == 1 && (g->B.C % 64) != 0) b_n = 64;
     }
     if (b_m == 0) b_m = (g->M >= 128) ? 128 : 64;
     if (g->bm == 0 || g->bn == 0) {
@@ -1052,7 +1053,7 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     KOAF_REQUIRE((tp.bm == 64 || tp.bm == 128) && (tp.bn == 64 || tp.bn == 128), "koaf_gemm: tile must be 64|128");
     if (g.A.gather || g.B.gather) KOAF_REQUIRE(vec, "koaf_gemm: gathered operands need aligned, C%%32==0 tensors");
     if (g.B.kind == 1 && g.B.gather == 1)
-        KOAF_REQUIRE(g.B.C % tp.bn == 0, "koaf_gemm: wgrad tile (%d) must divide channels per tap (%d)", tp.bn, g.B.C);
+        KOAF_REQUIRE(g.B.C % 4 == 0, "koaf_gemm: gathered K-major operand needs channels per tap (%d) %% 4 == 0", g.B.C);
     KOAF_REQUIRE(!g.cmap || vec, "koaf_gemm: row map needs the vector epilogue");
     KOAF_REQUIRE(!g.bnb_mode || vec, "koaf_gemm: fused BN-backward needs the vector epilogue");
     hipStream_t s = (hipStream_t)stream;
