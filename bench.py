@@ -21,6 +21,8 @@ Workloads:
                     (default per-GPU batch 2; batch 8 needs --recompute).
   xr1cnn / xr1c1    BASELINE configs 1 / 2 (XR1Cnn B=4; extension XR1C1Cnn = XR + clinical MLP head, B=32) @350^2.
   mr1 / mr1c1       BASELINE config 3: MR1CnnTrf B=4 @160x160x64; extension MR1C1CnnTrf (DESS + clinical) B=4 @384x384x160.
+  eval3             inference pass of the native3 model (eval() mode, no autograd: run.predict_batch = forward + softmax),
+                    the evaluation regime of koafusion/run/eval_prog_fus.py; `value` = knees/s scored.
 The JSON line carries `roofline` for the dominant kernel (the MFMA GEMM, timed live with events on the
 launch stream over one extra instrumented step) and `cpu_baseline` (the oracle = CPU port of the same step,
 timed on this box's host cores on a bounded sample).
@@ -61,7 +63,7 @@ def workload_cfg(name):
         cfg = P.cfg_full(xr=(320, 320), mr1=(320, 320, 160), mr2=(320, 320, 160), dropout=0.1)
         cfg["_tensor_shapes"] = [[310, 310], [384, 384, 160], [384, 384, 160], [16]]
         return cfg, 2
-    if name == "native3":
+    if name in ("native3", "eval3"):
         return P.cfg_xr1mr3c1(dropout=0.1), 8
     if name == "syn3":
         cfg = P.cfg_xr1mr3c1(xr=(320, 320), mr1=(320, 320, 160), mr2=(320, 320, 160), mr3=(320, 320, 160), dropout=0.1)
@@ -85,6 +87,7 @@ def algorithmic_train_gflop_per_sample(name):
     # (ResNet-50 4.1705 GFLOP/slice @160^2, 24.02 @384^2; ResNeXt-50 20.877 @350^2, 16.84 @310^2; FeaT 0.2097/token)
     return {"native": 1280.0, "xr1cnn": 62.1, "mr1": 3 * (64 * 4.1705 + 65 * 0.2097),
             "native3": 1280.0 + 3 * (32 * 4.1705 + 64 * 0.2097),
+            "eval3": (1280.0 + 11.3) / 3 + (32 * 4.1705 + 64 * 0.2097),
             "syn": 3 * (16.84 + 320 * 24.02 + 641 * 0.2097),
             "syn3": 3 * (16.84 + 480 * 24.02 + 963 * 0.2097),
             "xr1c1": 62.1 + 3 * 2 * (9 * 2048 + 2048 * 512) / 1e9,
@@ -95,8 +98,8 @@ def cpu_baseline(cfg, workload):
     """The oracle (CPU port of the same train step) on this box's host cores; bounded sample."""
     import procedural as P
     from oracle import koafusion_cpu as O
-    if workload in ("syn", "syn3", "mr1c1"):
-        return None     # minutes per sample on a host CPU: outside the bounded-sample budget
+    if workload in ("syn", "syn3", "mr1c1", "eval3"):
+        return None     # minutes per sample on a host CPU (eval3: no train step to compare): outside the bounded sample
     B = 1
     n = min(len(os.sched_getaffinity(0)), 64)
     torch.set_num_threads(n)
@@ -195,6 +198,14 @@ def main():
         xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(shapes_cfg, B, seed=1234 + rank)]
         y = torch.from_numpy(P.make_target("target", B, seed=1234 + rank)).to(dev)
         model.train()
+        if name == "eval3":
+            from oaprogressionmmf_amd.run import predict_batch
+            model.eval()
+
+            def step_eval():
+                logits, proba = predict_batch(model, xs)
+                return float(proba[0, 0].item())       # the driver's per-batch host read (argmax / softmax go to the CPU)
+            return cfg, B, step_eval
 
         def step():
             opt.zero_grad()
@@ -294,11 +305,14 @@ def main():
     if rank == 0:
         value = world * B * args.steps / dt
         out = {
-            "metric": "knees/sec full XR+MRI+clin fusion train step",
+            "metric": ("knees/sec full XR+MRI+clin fusion inference pass" if args.workload == "eval3"
+                       else "knees/sec full XR+MRI+clin fusion train step"),
             "value": round(value, 3), "unit": "knees/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {cfg['name']} train step (fwd+FocalLoss+bwd+Adam), "
+            "config": {"workload": f"{args.workload}: {cfg['name']} "
+                                   + ("inference pass (forward + softmax), " if args.workload == "eval3"
+                                      else "train step (fwd+FocalLoss+bwd+Adam), ") +
                                    f"per-GPU batch {B}, global batch {world * B}, "
                                    + {"native": "XR 1x350x350 + DESS 160x160x64 + T2 160x160x25 + 9 clinical; random-init weights",
                                       "native3": "XR 1x350x350 + DESS 160x160x64 + TSE 160x160x32 + T2 160x160x25 + 9 clinical "
@@ -306,6 +320,7 @@ def main():
                                                  "XR1MR2C1CnnTrf); random-init weights",
                                       "syn3": "BASELINE synthetic shapes XR 1x310x310 + 3 x MRI 1x160x384x384 + 9 clinical; "
                                               "random-init weights",
+                                      "eval3": "INFERENCE pass (forward + softmax, eval mode) on the native3 shapes; random-init weights",
                                       "xr1c1": "BASELINE config 2: XR 1x350x350 + 9 clinical, early-fusion MLP head; random-init weights",
                                       "mr1c1": "BASELINE config 3: SAG-3D-DESS 1x160x384x384 + 9 clinical; random-init weights",
                                       "syn": "BASELINE synthetic shapes XR 1x310x310 + 2 x MRI 1x160x384x384 + 9 clinical "

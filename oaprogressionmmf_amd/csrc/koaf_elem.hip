@@ -352,23 +352,26 @@ __global__ void __launch_bounds__(64) minmax_final_kernel(const float* __restric
     if (threadIdx.x == 0) { mm[2 * b] = lo; mm[2 * b + 1] = hi; }
 }
 
-// one thread per (sample, row, column); the S slices of that position share the four bilinear source positions
+// One thread per V consecutive slices of one (sample, row, column): the slice index is the fastest-varying one in
+// memory, so consecutive lanes read consecutive addresses (V = 4 when S % 4 == 0, else 1; radiographs: S = 1, lanes run
+// along the columns).  The four bilinear source positions depend on (row, column) only and are recomputed per lane.
+template <int V>
 __global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                       const float* __restrict__ mm, const float* __restrict__ prm,
                                                       int B, int R, int C, int S, float mean, float stdv) {
-    const int64_t total = (int64_t)B * R * C;
+    const int SV = S / V;
+    const int64_t total = (int64_t)B * R * C * SV;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const int r = (int)((i / C) % R);
-        const int b = (int)(i / ((int64_t)R * C));
+        const int sv = (int)(i % SV);
+        const int64_t pix = i / SV;
+        const int c = (int)(pix % C);
+        const int r = (int)((pix / C) % R);
+        const int b = (int)(pix / ((int64_t)R * C));
         const float mn = mm[2 * b], den = mm[2 * b + 1] - mn;
         const float cs = prm[4 * b], sn = prm[4 * b + 1], ex = prm[4 * b + 2];
         const bool rot = prm[4 * b + 3] != 0.f;
-        const float* xb = x + (int64_t)b * R * C * S;
-        float* yo = y + i * S;
-        int off[4] = {0, 0, 0, 0};
-        float w[4] = {1.f, 0.f, 0.f, 0.f};
-        bool ok[4] = {true, false, false, false};
+        const float* xb = x + (int64_t)b * R * C * S + V * sv;
+        float v[V];
         if (rot) {
             // F.affine_grid(theta, align_corners=False) then F.grid_sample(bilinear, zeros, align_corners=False)
             const float xn = (2.f * c + 1.f) / C - 1.f, yn = (2.f * r + 1.f) / R - 1.f;
@@ -377,29 +380,41 @@ __global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ 
             const float fx = floorf(ix), fy = floorf(iy);
             const int x0 = (int)fx, y0 = (int)fy;
             const float tx = ix - fx, ty = iy - fy;
-            w[0] = (1.f - tx) * (1.f - ty); w[1] = tx * (1.f - ty); w[2] = (1.f - tx) * ty; w[3] = tx * ty;
+            const float w[4] = {(1.f - tx) * (1.f - ty), tx * (1.f - ty), (1.f - tx) * ty, tx * ty};
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[j] = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
-                ok[k] = (unsigned)xx < (unsigned)C && (unsigned)yy < (unsigned)R;
-                off[k] = ok[k] ? (yy * C + xx) * S : 0;
+                if ((unsigned)xx < (unsigned)C && (unsigned)yy < (unsigned)R) {
+                    const float* src = xb + (int64_t)(yy * C + xx) * S;
+                    if constexpr (V == 4) {
+                        const v4f q = *(const v4f*)src;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += ((q[j] - mn) / den) * w[k];
+                    } else {
+                        v[0] += ((src[0] - mn) / den) * w[k];
+                    }
+                }
             }
         } else {
-            off[0] = (r * C + c) * S;
-        }
-        for (int s = 0; s < S; ++s) {
-            float v;
-            if (rot) {
-                v = 0.f;
+            const float* src = xb + (int64_t)(r * C + c) * S;
+            if constexpr (V == 4) {
+                const v4f q = *(const v4f*)src;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (ok[k]) v += ((xb[off[k] + s] - mn) / den) * w[k];
+                for (int j = 0; j < 4; ++j) v[j] = (q[j] - mn) / den;
             } else {
-                v = (xb[off[0] + s] - mn) / den;
+                v[0] = (src[0] - mn) / den;
             }
-            if (ex != 0.f) v = powf(v, ex);
-            yo[s] = (v - mean) / stdv;
         }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            if (ex != 0.f) v[j] = powf(v[j], ex);
+            v[j] = (v[j] - mean) / stdv;
+        }
+        float* dst = y + pix * S + V * sv;
+        if constexpr (V == 4) *(v4f*)dst = (v4f){v[0], v[1], v[2], v[3]};
+        else dst[0] = v[0];
     }
 }
 
@@ -982,8 +997,12 @@ extern "C" int koaf_augment(const float* x, float* y, const float* mm, const flo
                             int32_t C, int32_t S, float mean, float stdv, void* stream) {
     KOAF_REQUIRE(x && y && mm && params && B > 0 && R > 0 && C > 0 && S > 0, "koaf_augment: bad args");
     KOAF_REQUIRE((int64_t)R * C * S < (1ll << 31), "koaf_augment: sample too large");
-    const int64_t total = (int64_t)B * R * C;
-    hipLaunchKernelGGL(augment_kernel, dim3(ew_grid(total)), dim3(EB), 0, STREAM, x, y, mm, params, B, R, C, S, mean, stdv);
+    const bool v4 = (S % 4 == 0) && al16(x) && al16(y);
+    const int64_t total = (int64_t)B * R * C * (v4 ? S / 4 : S);
+    if (v4)
+        hipLaunchKernelGGL(augment_kernel<4>, dim3(ew_grid(total)), dim3(EB), 0, STREAM, x, y, mm, params, B, R, C, S, mean, stdv);
+    else
+        hipLaunchKernelGGL(augment_kernel<1>, dim3(ew_grid(total)), dim3(EB), 0, STREAM, x, y, mm, params, B, R, C, S, mean, stdv);
     return koaf_check_launch("koaf_augment");
 }
 
