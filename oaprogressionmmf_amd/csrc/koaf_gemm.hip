@@ -84,7 +84,7 @@ __host__ __device__ constexpr int plane_dwords(int rows, bool kc) { return kc ? 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // four fp32 values -> two (hi, mid) pairs of dwords holding 4 packed bf16 each: hi by truncation (so x - hi is exact),
-// mid = the remainder rounded to nearest bf16.  hi + mid carries 16 significand bits of x, error <= 2^-17 |x|, zero mean.
+// mid = the remainder rounded to nearest bf16.  hi + mid carries (at least) 16 significand bits of x: error <= 2^-16 |x|, zero mean.
 __device__ __forceinline__ void split2v(const v4f x, unsigned out[2][2]) {
     float r1[4];
 #pragma unroll
