@@ -7,7 +7,7 @@
 // bits: every operand value is cut by truncation into three bf16 pieces hi + mid + lo that together hold all 24
 // significand bits (exact), and of the nine piece products the six of relative weight >= 2^-16
 // (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) are issued as v_mfma_f32_32x32x16_bf16 (each product exact,
-// fp32 accumulate); the three dropped ones are <= 2^-23 of the product, i.e. at fp32 rounding level.  Measured
+// fp32 accumulate); the three dropped ones are < 2^-21 of the product (2^-24 typically), i.e. at fp32 rounding level.  Measured
 // against float64 the result is as accurate as the fp32-MFMA path (KOAF_SPLIT3 == 0, kept for comparison) and
 // rocBLAS sgemm (scripts/gemm_accuracy.py).  Six 8-pass MFMAs replace eight 16-pass fp32 MFMAs per 16 k: the
 // matrix-pipe bound rises from 157 to 2500/6 = 417 TFLOP/s fp32-equivalent.  Inf operands become NaN (inf - inf
@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         // fp32 x fp32 on the bf16 matrix pipe: every operand value is cut (by truncation, exactly) into three bf16
         // pieces hi + mid + lo = all 24 significand bits; of the nine piece products the six of relative weight
         // >= 2^-16 go through v_mfma_f32_32x32x16_bf16 (each product exact, fp32 accumulate), the three dropped ones
-        // are <= 2^-23 of the product.  Six 8-pass MFMAs replace eight 16-pass fp32 MFMAs per 16 k: 2.67x the rate.
+        // are < 2^-21 of the product.  Six 8-pass MFMAs replace eight 16-pass fp32 MFMAs per 16 k: 2.67x the rate.
 #pragma unroll
         for (int kq = 0; kq < 2; ++kq) {
             v4f a[TM][2], b[2];
