@@ -16,7 +16,7 @@ void koaf_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* koaf_last_error(void) { return g_err; }
-extern "C" int koaf_version(void) { return 100; }
+extern "C" int koaf_version(void) { return 110; }   // 1.1: KoafGemm.prec, bn *_ws arguments, input-pipeline entry points
 
 namespace {
 
