@@ -14,7 +14,8 @@ Workloads:
                     batch 8": the registry extension XR1MR3C1CnnTrf (the reference's XR1MR2C1CnnTrf pattern with a third
                     MRI slot) at the reference's native sizes: XR 1x350x350 (ResNeXt-50), DESS 160x160x64, TSE 160x160x32,
                     T2 160x160x25 (ResNet-50 slice-wise), 9 clinical variables, 4 x FeaT(depth 4, 8 heads, width 2048).
-                    The same run also times `native` and reports it under "pinned_reference_model".
+                    The same run also times `native` and reports it under "pinned_reference_model", and (1 GPU) the same model
+                    on BASELINE's synthetic tensor shapes at batch 8 under "baseline_synthetic_shapes".
   native            XR1MR2C1CnnTrf exactly as runner.sh:341-363 (the reference's biggest registered model, the
                     reference-pinned 2-MRI mapping of config 4): XR 350^2 + DESS 160x160x64 + T2 160x160x25 + clinical; B=8.
   syn / syn3        BASELINE's synthetic tensor shapes (XR 1x310x310, MRI 1x160x384x384) through the 2-MRI / 3-MRI model
@@ -133,6 +134,7 @@ def main():
     ap.add_argument("--workload", default="native3")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = workload default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-syn", action="store_true", help="skip the BASELINE-synthetic-shapes addendum of the default run")
     ap.add_argument("--breakdown", default="", help="write a per-shape table of the instrumented step to this file")
     ap.add_argument("--recompute", action="store_true",
                     help="activation recompute in the encoders (keeps stage inputs + BatchNorm statistics only; blocks rebuilt one at a time); "
@@ -181,12 +183,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def make_job(name, batch):
+    def make_job(name, batch, recompute=None):
         """model + optimizer + resident synthetic batch of one workload -> (cfg, B, step)"""
         cfg, bdef = workload_cfg(name)
         B = batch or bdef
         model = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None).to(dev)
-        if args.recompute:
+        if args.recompute if recompute is None else recompute:
             from oaprogressionmmf_amd.models import KoafTrunk
             for m in model.modules():
                 if isinstance(m, KoafTrunk):
@@ -345,6 +347,38 @@ def main():
                          "algorithmic_gflop_per_step": round(gemm_flop / 1e9, 1),
                          "step_gflop_per_sample_survey": algorithmic_train_gflop_per_sample(args.workload)},
         }
+        if world == 1 and args.workload == "native3" and not args.batch and not args.recompute and not args.no_syn:
+            # the same model and batch on BASELINE.json's synthetic tensor shapes (XR 1x310x310, MRI 1x160x384x384): the
+            # activations of a batch of 8 need activation recompute to fit (142 GB); 1 warm-up + 2 timed steps
+            try:
+                del step
+                import gc
+                gc.collect()
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                _common.USE_LANES, _encoder.USE_SIDE_STREAM = not args.serial, not args.serial
+                cfg_s, B_s, step_s = make_job("syn3", 8, recompute=True)
+                torch.cuda.reset_peak_memory_stats()
+                step_s()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    lv_s = step_s()
+                torch.cuda.synchronize()
+                dts = (time.perf_counter() - t0) / 2
+                out["baseline_synthetic_shapes"] = {
+                    "workload": "syn3: same model, per-GPU batch 8, XR 1x310x310 + 3 x MRI 1x160x384x384 + 9 clinical, "
+                                "activation recompute (block-granular)",
+                    "value": round(B_s / dts, 3), "unit": "knees/s", "ms_per_step": round(dts * 1e3, 1), "steps": 2, "warmup": 1,
+                    "last_loss": round(lv_s, 6),
+                    "step_gflop_per_sample_survey": round(algorithmic_train_gflop_per_sample("syn3"), 1),
+                    "hbm_peak_gib": {"allocated": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                                     "reserved": round(torch.cuda.max_memory_reserved() / 2**30, 1)}}
+                del step_s
+                gc.collect()
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
+                out["baseline_synthetic_shapes"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(cfg, args.workload)
             if cb is not None:
