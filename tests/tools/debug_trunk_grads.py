@@ -1,7 +1,7 @@
 """debug: per-parameter gradient error of a KoafTrunk vs the oracle, last layers first"""
 import sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np, torch
 import procedural as P
