@@ -539,17 +539,21 @@ extern "C" int koaf_stem_unfold_dw(const float* dw1t, float* dw, void* stream) {
 // ================================================================================================
 // split-K plan for a linear layer with few rows: the 64x64-tile grid of M x N is only a few hundred blocks with
 // K/32 serial k-steps each (latency-bound at ~1 block per CU); splitting K 2-8 ways fills the chip.
-static int linear_tile(int M, int N) {
-    // 128x128 tiles (half the loader / split work per FLOP of 64x64) once both dimensions offer a few of them
+struct LinTile { int bm, bn; };
+static LinTile linear_tile(int M, int N) {
+    // 128x128 tiles (half the loader / split work per FLOP of 64x64) once both dimensions offer a few of them; with
+    // few rows (200-256 token rows of the per-MRI aggregators) 64x128: the wide N still halves the A traffic per FLOP
     static const int forced = [] { const char* e = getenv("KOAF_LIN_TILE"); return e ? atoi(e) : 0; }();
-    if (forced == 64 || forced == 128) return forced;
-    return (M >= 512 && N >= 512) ? 128 : 64;
+    if (forced == 64 || forced == 128) return {forced, forced};
+    if (M >= 512 && N >= 512) return {128, 128};
+    if (forced == 1 || N < 1024) return {64, 64};
+    return {64, 128};
 }
 static int linear_splitk(int M, int N, int K) {
     if ((N & 3) || K < 512) return 1;
-    const int t = linear_tile(M, N);
-    const int64_t tiles = cdiv64(M, t) * cdiv64(N, t);
-    const int64_t want = t == 128 ? 512 : 1024;
+    const LinTile t = linear_tile(M, N);
+    const int64_t tiles = cdiv64(M, t.bm) * cdiv64(N, t.bn);
+    const int64_t want = t.bm == 128 ? 512 : (t.bn == 128 ? 768 : 1024);
     if (tiles >= want) return 1;
     int sk = (int)(want / tiles);
     if (sk > 8) sk = 8;
@@ -571,7 +575,7 @@ extern "C" int koaf_linear_fwd(const float* x, const float* w, const float* b, c
     g.M = M; g.N = N; g.K = K;
     const int sk = ws ? linear_splitk(M, N, K) : 1;
     if (sk > 1) {
-        g.splitk = sk; g.bm = g.bn = linear_tile(M, N);
+        g.splitk = sk; g.bm = linear_tile(M, N).bm; g.bn = linear_tile(M, N).bn;
         g.C = ws; g.ldc = N;
         int rc = koaf_gemm(&g, stream);
         if (rc != KOAF_OK) return rc;
@@ -593,7 +597,7 @@ extern "C" int koaf_linear_dgrad(const float* dy, const float* w, const float* r
     g.M = M; g.N = K; g.K = N;
     const int sk = ws ? linear_splitk(M, K, N) : 1;
     if (sk > 1) {
-        g.splitk = sk; g.bm = g.bn = linear_tile(M, K);
+        g.splitk = sk; g.bm = linear_tile(M, K).bm; g.bn = linear_tile(M, K).bn;
         g.C = ws; g.ldc = K;
         int rc = koaf_gemm(&g, stream);
         if (rc != KOAF_OK) return rc;
