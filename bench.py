@@ -314,6 +314,10 @@ def main():
             "value": round(value, 3), "unit": "knees/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "arithmetic": "fp32 tensors and accumulation everywhere; contractions form each fp32 x fp32 product from exact bf16 "
+                          "pieces of the operands on the bf16 MFMA (forward: all 24 significand bits, error at fp32 rounding "
+                          "level; gradient contractions: operands rounded to 16 significand bits, ~7e-6 relative); "
+                          "KOAF_BWD_PRECISION=full makes the gradients exact too",
             "config": {"workload": f"{args.workload}: {cfg['name']} "
                                    + ("inference pass (forward + softmax), " if args.workload == "eval3"
                                       else "train step (fwd+FocalLoss+bwd+Adam), ") +
