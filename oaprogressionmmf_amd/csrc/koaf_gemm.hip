@@ -966,6 +966,12 @@ extern "C" int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn) 
 namespace {
 // KoafGemm.prec == 1 contractions (weight / data gradients) run on two bf16 planes per operand unless the environment
 // says KOAF_BWD_PRECISION=full (read once)
+// KOAF_FWD_PRECISION=16 (opt-in, not the shipped mode): forward contractions on two pieces as well
+bool reduced_forward() {
+    static const bool on = [] { const char* e = getenv("KOAF_FWD_PRECISION"); return e && e[0] == '1' && e[1] == '6'; }();
+    return on;
+}
+
 int g_bwd_full = -1;     // -1: not set by koaf_set_backward_precision -> environment decides
 bool reduced_backward() {
     static const bool env_on = [] { const char* e = getenv("KOAF_BWD_PRECISION"); return !(e && e[0] == 'f'); }();
@@ -1064,7 +1070,7 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
         if (tiles <= 0) return KOAF_OK;
         if (tiles >= (1ll << 31)) { koaf_set_error("koaf_gemm: grid too large"); return KOAF_EINVAL; }
         dim3 grid((unsigned)tiles, (unsigned)q.splitk, (unsigned)(q.nb0 * q.nb1));
-        if (q.prec == 1 && reduced_backward()) {
+        if ((q.prec == 1 && reduced_backward()) || (q.prec == 0 && reduced_forward())) {
             if (!vec) return launch_modes<64, 64, false, 2>(q, grid, s);
             if (qbm == 128 && qbn == 128) return launch_modes<128, 128, true, 2>(q, grid, s);
             if (qbm == 128 && qbn == 64) return launch_modes<128, 64, true, 2>(q, grid, s);
