@@ -103,6 +103,10 @@ typedef struct KoafGemm {
     /* row-space origin of this launch (mixed-height tiling: one GEMM = a 128-row-tile launch over rows
        [0, M1) + a 64-row-tile launch over [M1, M)); partial-statistics rows continue at part_row0 */
     int32_t m_base, part_row0;
+    /* per-column shift k[N] (+ stats_bs per batch index) of the statistics: stats rows hold sum (v - k) and
+       sum (v - k)^2 (NULL: k = 0).  With k near the column mean -- the BatchNorm's running mean -- the variance
+       E[(v-k)^2] - E[v-k]^2 keeps its digits when |mean| >> std. */
+    const float* stats_shift;
 } KoafGemm;
 
 /* Precision of the gradient contractions (KoafGemm.prec == 1) for this process: full != 0 -> every significand bit
@@ -126,11 +130,12 @@ int koaf_slab_reduce_epilogue(const float* slabs, int32_t nslab, int32_t M, int3
  * x [N,H,W,Cin], w packed [Cout,KH,KW,Cin] (the memory of a channels_last (Cout,Cin,KH,KW)
  * parameter), y [N,OH,OW,Cout].  in_sc/in_sh (nullable): fused BatchNorm+ReLU of the producer
  * applied to x on load.  stats (nullable): per-M-tile column sums / sums of squares of y for the
- * following BatchNorm (train mode), *stats_rows rows of [2][Cout].  */
+ * following BatchNorm (train mode), *stats_rows rows of [2][Cout], summed about stats_shift[Cout] (nullable = 0; pass
+ * that BatchNorm's running_mean and hand the same pointer to koaf_bn_finalize).  */
 int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W,
                     int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                     const float* in_sc, const float* in_sh, float* stats, int32_t* stats_rows,
-                    void* stream);
+                    const float* stats_shift, void* stream);
 /* rows of the stats buffer koaf_conv2d_fwd writes for M output pixels */
 int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout);
 /* dx [N,H,W,Cin] = conv_transpose(dy [N,OH,OW,Cout], w) (+residual: the other branch's gradient);
@@ -174,7 +179,7 @@ int koaf_gconv_expand_w(const float* w, float* wexp, int32_t C, int32_t groups, 
 int koaf_gconv_compress_dw(const float* dwexp, float* dw, int32_t C, int32_t groups, void* stream);
 int koaf_gconv3x3_fwd(const float* x, const float* wexp, float* y, int32_t N, int32_t H, int32_t W,
                       int32_t C, int32_t stride, const float* in_sc, const float* in_sh,
-                      float* stats, int32_t* stats_rows, void* stream);
+                      float* stats, int32_t* stats_rows, const float* stats_shift, void* stream);
 int koaf_gconv3x3_dgrad(const float* dy, const float* wexp, float* dx, int32_t N, int32_t H,
                         int32_t W, int32_t C, int32_t stride, void* stream);
 int64_t koaf_gconv3x3_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride);
@@ -196,9 +201,10 @@ int koaf_stem_unfold_dw(const float* dw1t, float* dw, void* stream);
 
 /* ---- BatchNorm2d (nn.BatchNorm2d; _torchvision.py:172,121-131) ------------------------------- */
 /* per-block column sums / sums of squares of x [rows][C] -> part [*part_rows][2][C]
- * (koaf_colpart_rows(rows, C) rows); for producers without a GEMM epilogue (stem). */
+ * (koaf_colpart_rows(rows, C) rows), summed about shift[C] (nullable = 0); for producers without a GEMM epilogue
+ * (stem). */
 int koaf_colstats(const float* x, int64_t rows, int32_t C, float* part, int32_t* part_rows,
-                  void* stream);
+                  const float* shift, void* stream);
 int32_t koaf_colpart_rows(int64_t rows, int32_t C);
 /* Bytes of the fp64 workspace `ws` the two finalisations below use to spread a long list of partial rows over
  * the chip (two-stage, fixed-order reduction); 0 = not needed for this row count.  ws may always be NULL
@@ -206,12 +212,14 @@ int32_t koaf_colpart_rows(int64_t rows, int32_t C);
 int64_t koaf_bn_reduce_ws(int32_t rows, int32_t C);
 /* stats [rows][2][C] -> mean, invstd, sc = gamma*invstd, sh = beta - mean*sc; train: updates
  * running_mean/var (momentum, unbiased var) and ++num_batches_tracked (int64).  eval (train==0):
- * stats ignored, uses running stats.  */
+ * stats ignored, uses running stats.  shift (nullable): the per-channel shift k the statistics were summed about
+ * (KoafGemm.stats_shift / koaf_colstats): mean = k + E[x-k], var = E[(x-k)^2] - E[x-k]^2; it may alias running_mean
+ * (read before the update).  */
 int koaf_bn_finalize(const float* stats, int32_t rows, int32_t C, int64_t count,
                      const float* gamma, const float* beta, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
                      int32_t train, float* mean, float* invstd, float* sc, float* sh,
-                     double* ws, void* stream);
+                     const float* shift, double* ws, void* stream);
 /* y = relu(sc*c + sh + identity-term); identity-term = idt (materialised) or idsc*idt+idsh
  * (downsample branch BN folded).  Bottleneck tail, _torchvision.py:132-136.  */
 int koaf_bn_add_relu(const float* c, const float* sc, const float* sh, const float* idt,

@@ -91,6 +91,7 @@ class KoafGemm(ctypes.Structure):
         ("bnb_part", ctypes.c_void_p),
         ("m_base", ctypes.c_int32),
         ("part_row0", ctypes.c_int32),
+        ("stats_shift", ctypes.c_void_p),
     ]
 
 

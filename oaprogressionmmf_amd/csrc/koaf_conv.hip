@@ -208,7 +208,8 @@ __global__ void __launch_bounds__(256) gconv_compress_kernel(const float* __rest
 // ================================================================================================
 extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W, int32_t Cin,
                                int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, const float* in_sc,
-                               const float* in_sh, float* stats, int32_t* stats_rows, void* stream) {
+                               const float* in_sh, float* stats, int32_t* stats_rows, const float* stats_shift,
+                               void* stream) {
     KOAF_REQUIRE(x && w && y && N > 0 && Cin % 32 == 0 && Cout % 4 == 0, "koaf_conv2d_fwd: bad args (Cin=%d Cout=%d)",
                  Cin, Cout);
     KOAF_REQUIRE((in_sc == nullptr) == (in_sh == nullptr), "koaf_conv2d_fwd: in_sc/in_sh come together");
@@ -235,6 +236,7 @@ extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t
     g.M = (int)M; g.N = Cout; g.K = KH * KW * Cin;
     g.C = y; g.ldc = Cout;
     g.stats = stats;
+    g.stats_shift = stats ? stats_shift : nullptr;
     if (stats_rows) *stats_rows = koaf_gemm_part_rows(&g);
     return koaf_gemm(&g, stream);
 }
@@ -409,7 +411,7 @@ extern "C" int koaf_gconv_compress_dw(const float* dwexp, float* dw, int32_t C, 
 
 extern "C" int koaf_gconv3x3_fwd(const float* x, const float* wexp, float* y, int32_t N, int32_t H, int32_t W,
                                  int32_t C, int32_t stride, const float* in_sc, const float* in_sh, float* stats,
-                                 int32_t* stats_rows, void* stream) {
+                                 int32_t* stats_rows, const float* stats_shift, void* stream) {
     KOAF_REQUIRE(x && wexp && y && N > 0 && C % 64 == 0, "koaf_gconv3x3_fwd: bad args");
     const int OH = conv_out(H, 3, stride, 1), OW = conv_out(W, 3, stride, 1);
     const int64_t M = (int64_t)N * OH * OW;
@@ -425,6 +427,7 @@ extern "C" int koaf_gconv3x3_fwd(const float* x, const float* wexp, float* y, in
     g.M = (int)M; g.N = 64; g.K = 576;
     g.C = y; g.ldc = C; g.cbs1 = 64;
     g.stats = stats; g.stats_ld = C; g.stats_bs = 64;
+    g.stats_shift = stats ? stats_shift : nullptr;
     g.bn = 64; g.bm = 128;
     if (stats_rows) *stats_rows = (int)cdiv64(M, g.bm);
     g.A.tf_bs = 64;

@@ -84,14 +84,17 @@ __device__ __forceinline__ void col_block_reduce(v4f (&s)[NS], float* part, int 
 }
 
 __global__ void __launch_bounds__(256) colstats_kernel(const float* __restrict__ x, int64_t rows, int C,
-                                                       ColGeom g, float* __restrict__ part, int sq) {
+                                                       ColGeom g, float* __restrict__ part, int sq,
+                                                       const float* __restrict__ shift) {
     const int t = threadIdx.x, cvx = t % g.CV, ry = t / g.CV;
     const int c0 = blockIdx.y * g.CW;
     const int64_t rbeg = (int64_t)blockIdx.x * g.rpb;
     const int64_t rend = min(rows, rbeg + (int64_t)g.rpb);
     v4f s[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    v4f k = {0, 0, 0, 0};
+    if (shift) k = *(const v4f*)&shift[c0 + 4 * cvx];       // sums about the shift (see KoafGemm.stats_shift)
     for (int64_t r = rbeg + ry; r < rend; r += g.RP) {
-        v4f v = *(const v4f*)&x[r * C + c0 + 4 * cvx];
+        v4f v = *(const v4f*)&x[r * C + c0 + 4 * cvx] - k;
         s[0] += v;
         s[1] += v * v;
     }
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const T* __restrict__
                                                            const float* __restrict__ beta, float* running_mean,
                                                            float* running_var, int64_t* nbt, float momentum,
                                                            float eps, int train, float* mean, float* invstd,
-                                                           float* sc, float* sh) {
+                                                           float* sc, float* sh, const float* __restrict__ shift) {
     __shared__ double red[2][16][64];
     const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
@@ -196,9 +199,10 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const T* __restrict__
         if (train) {
             double s1 = 0.0, s2 = 0.0;
             for (int j = 0; j < 16; ++j) { s1 += red[0][j][cx]; s2 += red[1][j][cx]; }
-            double dm = s1 * inv_count;
+            double dm = s1 * inv_count;                 // mean of (x - k)
             double dv = s2 * inv_count - dm * dm;
             if (dv < 0.0) dv = 0.0;
+            if (shift) dm += (double)shift[c];          // (read before running_mean, possibly the same buffer, is updated)
             m = (float)dm;
             var = (float)dv;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
@@ -855,7 +859,7 @@ static int part_reduce(const float* src, int rows, int C, int nsum, int i1, doub
 extern "C" int koaf_bn_finalize(const float* stats, int32_t rows, int32_t C, int64_t count, const float* gamma,
                                 const float* beta, float* running_mean, float* running_var,
                                 int64_t* num_batches_tracked, float momentum, float eps, int32_t train, float* mean,
-                                float* invstd, float* sc, float* sh, double* ws, void* stream) {
+                                float* invstd, float* sc, float* sh, const float* shift, double* ws, void* stream) {
     KOAF_REQUIRE(C > 0 && mean && invstd && sc && sh && running_mean && running_var, "koaf_bn_finalize: bad args");
     KOAF_REQUIRE(!train || (stats && rows > 0 && count > 0), "koaf_bn_finalize: train mode needs stats");
     const double inv = train ? 1.0 / (double)count : 0.0;
@@ -864,11 +868,11 @@ extern "C" int koaf_bn_finalize(const float* stats, int32_t rows, int32_t C, int
     if (S)
         hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, ws, S, C, inv, unbias,
                            gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, train, mean,
-                           invstd, sc, sh);
+                           invstd, sc, sh, train ? shift : nullptr);
     else
         hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, stats, rows, C, inv,
                            unbias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, train,
-                           mean, invstd, sc, sh);
+                           mean, invstd, sc, sh, train ? shift : nullptr);
     return koaf_check_launch("koaf_bn_finalize");
 }
 
@@ -887,11 +891,12 @@ extern "C" int koaf_bn_relu(const float* c, const float* sc, const float* sh, fl
     return koaf_bn_add_relu(c, sc, sh, nullptr, nullptr, nullptr, y, rows, C, stream);
 }
 
-extern "C" int koaf_colstats(const float* x, int64_t rows, int32_t C, float* part, int32_t* part_rows, void* stream) {
+extern "C" int koaf_colstats(const float* x, int64_t rows, int32_t C, float* part, int32_t* part_rows,
+                             const float* shift, void* stream) {
     ColGeom g;
     KOAF_REQUIRE(x && part && part_rows && rows > 0, "koaf_colstats: bad args");
     KOAF_REQUIRE(col_geom(rows, C, 1024, &g), "koaf_colstats: unsupported C=%d", C);
-    hipLaunchKernelGGL(colstats_kernel, dim3(g.nblk, g.nchunk), dim3(256), 0, STREAM, x, rows, C, g, part, 1);
+    hipLaunchKernelGGL(colstats_kernel, dim3(g.nblk, g.nchunk), dim3(256), 0, STREAM, x, rows, C, g, part, 1, shift);
     *part_rows = g.nblk;
     return koaf_check_launch("koaf_colstats");
 }
@@ -1093,7 +1098,7 @@ extern "C" int koaf_colsum(const float* x, float* out, int32_t rows, int32_t C, 
     ColGeom g;
     if (part && al16(x) && col_geom(rows, C, 256, &g)) {
         hipLaunchKernelGGL(colstats_kernel, dim3(g.nblk, g.nchunk), dim3(256), 0, STREAM, x, (int64_t)rows, C, g, part,
-                           0);
+                           0, (const float*)nullptr);
         hipLaunchKernelGGL(colfinal_kernel<1>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, part, g.nblk, C, out,
                            (float*)nullptr);
     } else {

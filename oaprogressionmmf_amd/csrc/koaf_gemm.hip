@@ -708,9 +708,15 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     const float* Rp = (p.residual && !slab) ? p.residual + z0 * p.rbs0 + z1 * p.rbs1 : nullptr;
     const float* bias = slab ? nullptr : p.bias;
     const bool do_stats = (p.stats != nullptr) && !slab;
-    float s1[TN], s2[TN];
+    float s1[TN], s2[TN], kshift[TN];
 #pragma unroll
-    for (int jn = 0; jn < TN; ++jn) s1[jn] = s2[jn] = 0.f;
+    for (int jn = 0; jn < TN; ++jn) {
+        s1[jn] = s2[jn] = 0.f;
+        // statistics are summed about a per-column shift (the BatchNorm's running mean): sum (v - k), sum (v - k)^2
+        // lose nothing to cancellation when |mean| >> std, which sum v^2 - (sum v)^2 / n does
+        const int scol = n0 + wn * WN + 32 * jn + r;
+        kshift[jn] = (do_stats && p.stats_shift && scol < p.N) ? p.stats_shift[(int64_t)blockIdx.z * p.stats_bs + scol] : 0.f;
+    }
 
     if constexpr (VEC) {
         // stage the accumulator tile through LDS so global stores (and residual / bias loads) are
@@ -723,8 +729,8 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float v = p.alpha * acc[i][jn][e];
-                    s1[jn] += v;
-                    s2[jn] += v * v;
+                    s1[jn] += v - kshift[jn];
+                    s2[jn] += (v - kshift[jn]) * (v - kshift[jn]);
                     Cs[(wm * WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC_S + wn * WN + 32 * jn + r] = v;
                 }
         __syncthreads();
@@ -824,8 +830,8 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
                 float v = p.alpha * acc[i][jn][e];
-                s1[jn] += v;
-                s2[jn] += v * v;
+                s1[jn] += v - kshift[jn];
+                s2[jn] += (v - kshift[jn]) * (v - kshift[jn]);
                 if (cok && row < p.M) {
                     v += bv;
                     if (Rp) v += Rp[(int64_t)row * p.ldr + col];
@@ -850,8 +856,16 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         __syncthreads();
         if (t < BN && (n0 + t) < p.N) {
             float* st = p.stats + (int64_t)(p.part_row0 + tm) * 2 * p.stats_ld + (int64_t)blockIdx.z * p.stats_bs;
-            st[n0 + t] = red[0 * BN + t] + red[2 * BN + t];
-            st[p.stats_ld + n0 + t] = red[1 * BN + t] + red[3 * BN + t];
+            float a1 = red[0 * BN + t] + red[2 * BN + t], a2 = red[1 * BN + t] + red[3 * BN + t];
+            if (p.stats_shift) {
+                // rows of the tile past M were accumulated as zeros: each put (0 - k) and k^2 into the shifted sums
+                const float k = p.stats_shift[(int64_t)blockIdx.z * p.stats_bs + n0 + t];
+                const int ninv = max(0, m0 + BM - p.M);
+                a1 += (float)ninv * k;
+                a2 -= (float)ninv * k * k;
+            }
+            st[n0 + t] = a1;
+            st[p.stats_ld + n0 + t] = a2;
         }
     }
 }

@@ -38,19 +38,26 @@ class _Rec:
             setattr(self, k, None)
 
 
-def _conv_fwd(x, conv, N, H, W, in_saved, train):
+def _stat_shift(bn, train):
+    """statistics of a train-mode BatchNorm input are summed about its running mean (see KoafGemm.stats_shift)"""
+    return bn.running_mean if (train and bn is not None and bn.running_mean is not None) else None
+
+
+def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None):
+    """bn: the BatchNorm that consumes this conv's output statistics"""
     w = packed_weight(conv.weight)
     cin, cout = conv.in_channels, conv.out_channels
     k, s, p, g = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.groups
     sc, sh = (in_saved[2], in_saved[3]) if in_saved is not None else (None, None)
     wexp = None
+    shift = _stat_shift(bn, train)
     if g == 1:
-        y, part = ops.conv2d_fwd(x, w, N, H, W, cin, cout, k, k, s, p, sc, sh, stats=train)
+        y, part = ops.conv2d_fwd(x, w, N, H, W, cin, cout, k, k, s, p, sc, sh, stats=train, shift=shift)
     else:
         if k != 3 or p != 1 or cin != cout:
             raise NotImplementedError("grouped convolution other than the ResNeXt 3x3 is not built")
         wexp = ops.gconv_expand_w(w, cin, g)
-        y, part = ops.gconv3x3_fwd(x, wexp, N, H, W, cin, s, sc, sh, stats=train)
+        y, part = ops.gconv3x3_fwd(x, wexp, N, H, W, cin, s, sc, sh, stats=train, shift=shift)
     return y, part, ops.conv_out(H, k, s, p), ops.conv_out(W, k, s, p), wexp
 
 
@@ -60,7 +67,7 @@ def _bn_fin(bn, part, count):
         raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not built")
     return ops.bn_finalize(part if train else None, bn.num_features, count, bn.weight.detach(), bn.bias.detach(),
                            bn.running_mean, bn.running_var, bn.num_batches_tracked if train else None, bn.momentum,
-                           bn.eps, train)
+                           bn.eps, train, shift=_stat_shift(bn, train))
 
 
 _LANES = {}
@@ -219,25 +226,25 @@ def _block_fwd(blk, y, N, Hc, Wc, train, given):
         return given[idx] if given is not None else _bn_fin(bn, part, count)
     if isinstance(blk, Bottleneck):
         r.kind = "bottleneck"
-        r.c1, part, _, _, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, want)
+        r.c1, part, _, _, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, want, blk.bn1)
         r.s1 = fin(blk.bn1, part, N * Hc * Wc, 0)
-        r.c2, part, OH, OW, r.wexp = _conv_fwd(r.c1, blk.conv2, N, Hc, Wc, r.s1, want)
+        r.c2, part, OH, OW, r.wexp = _conv_fwd(r.c1, blk.conv2, N, Hc, Wc, r.s1, want, blk.bn2)
         r.s2 = fin(blk.bn2, part, N * OH * OW, 1)
-        r.c3, part, _, _, _ = _conv_fwd(r.c2, blk.conv3, N, OH, OW, r.s2, want)
+        r.c3, part, _, _, _ = _conv_fwd(r.c2, blk.conv3, N, OH, OW, r.s2, want, blk.bn3)
         r.s3 = fin(blk.bn3, part, N * OH * OW, 2)
         last_c, last_s, cout = r.c3, r.s3, blk.conv3.out_channels
     elif isinstance(blk, BasicBlock):
         r.kind = "basic"
-        r.c1, part, OH, OW, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, want)
+        r.c1, part, OH, OW, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, want, blk.bn1)
         r.s1 = fin(blk.bn1, part, N * OH * OW, 0)
-        r.c2, part, _, _, _ = _conv_fwd(r.c1, blk.conv2, N, OH, OW, r.s1, want)
+        r.c2, part, _, _, _ = _conv_fwd(r.c1, blk.conv2, N, OH, OW, r.s1, want, blk.bn2)
         r.s2 = fin(blk.bn2, part, N * OH * OW, 1)
         last_c, last_s, cout = r.c2, r.s2, blk.conv2.out_channels
     else:
         raise TypeError(f"unsupported block {type(blk)}")
     rows_o = N * OH * OW
     if blk.downsample is not None:
-        r.cd, part, _, _, _ = _conv_fwd(y, blk.downsample[0], N, Hc, Wc, None, want)
+        r.cd, part, _, _, _ = _conv_fwd(y, blk.downsample[0], N, Hc, Wc, None, want, blk.downsample[1])
         r.sd = fin(blk.downsample[1], part, rows_o, 3)
         r.y = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=r.cd, idsaved=r.sd)
     else:
@@ -262,7 +269,7 @@ class EncoderFn(torch.autograd.Function):
         w1t = ops.stem_fold_w(packed_weight(conv1.weight))
         c0 = ops.stem_fwd(x, w1t, N, H, W)
         H1, W1 = c0.shape[1], c0.shape[2]
-        part = ops.colstats(c0, N * H1 * W1, 64) if train else None
+        part = ops.colstats(c0, N * H1 * W1, 64, shift=_stat_shift(bn1, train)) if train else None
         s0 = _bn_fin(bn1, part, N * H1 * W1)
         y, am = ops.maxpool_fwd(c0, s0, N, H1, W1, 64)
         Hc, Wc = y.shape[1], y.shape[2]

@@ -60,9 +60,9 @@ def conv_out(h, k, s, p):
 # ------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------
-def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, stats=False):
+def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, stats=False, shift=None):
     """x [N,H,W,Cin] (any view with that memory), w packed [Cout,KH,KW,Cin] -> y [N,OH,OW,Cout],
-    (part, rows) per-tile column statistics if stats."""
+    (part, rows) per-tile column statistics if stats, summed about `shift` [Cout] (hand the same tensor to bn_finalize)."""
     L = lib()
     OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
     y = _empty((N, OH, OW, Cout), x)
@@ -72,7 +72,8 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
         part = _empty((nrows, 2, Cout), x)
     e0 = _prof_begin()
     check(L.koaf_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
-                            _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _stream()), "conv2d_fwd")
+                            _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _ptr(shift) if stats else None, _stream()),
+          "conv2d_fwd")
     _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin, f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}")
     if stats:
         part = part[:rows.value]
@@ -132,7 +133,7 @@ def gconv_compress_dw(dwexp, dw, C, groups):
     return dw
 
 
-def gconv3x3_fwd(x, wexp, N, H, W, C, stride, in_sc=None, in_sh=None, stats=False):
+def gconv3x3_fwd(x, wexp, N, H, W, C, stride, in_sc=None, in_sh=None, stats=False, shift=None):
     L = lib()
     OH, OW = conv_out(H, 3, stride, 1), conv_out(W, 3, stride, 1)
     y = _empty((N, OH, OW, C), x)
@@ -141,7 +142,7 @@ def gconv3x3_fwd(x, wexp, N, H, W, C, stride, in_sc=None, in_sh=None, stats=Fals
         part = _empty(((N * OH * OW + 127) // 128, 2, C), x)
     e0 = _prof_begin()
     check(L.koaf_gconv3x3_fwd(_ptr(x), _ptr(wexp), _ptr(y), N, H, W, C, stride, _ptr(in_sc), _ptr(in_sh), _ptr(part),
-                              ctypes.addressof(rows), _stream()), "gconv3x3_fwd")
+                              ctypes.addressof(rows), _ptr(shift) if stats else None, _stream()), "gconv3x3_fwd")
     _prof_end(e0, "gemm", 2.0 * N * OH * OW * C * 9 * (C // 32), f"gconv_fwd s{stride} C{C} px{N*OH*OW}")   # algorithmic (32 groups)
     return y, part
 
@@ -193,11 +194,11 @@ def stem_wgrad(dy, x, dw, N, H, W):
 # ------------------------------------------------------------------------------------------------
 # batch norm
 # ------------------------------------------------------------------------------------------------
-def colstats(x, rows, C):
+def colstats(x, rows, C, shift=None):
     L = lib()
     part = _empty((L.koaf_colpart_rows(rows, C), 2, C), x)
     r = _i32(0)
-    check(L.koaf_colstats(_ptr(x), rows, C, _ptr(part), ctypes.addressof(r), _stream()), "colstats")
+    check(L.koaf_colstats(_ptr(x), rows, C, _ptr(part), ctypes.addressof(r), _ptr(shift), _stream()), "colstats")
     return part
 
 
@@ -207,14 +208,16 @@ def _reduce_ws(rows, C, like):
     return torch.empty(n // 8, dtype=torch.float64, device=like.device) if n else None
 
 
-def bn_finalize(part, C, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, train):
-    """-> saved [4][C] = mean, invstd, sc, sh"""
+def bn_finalize(part, C, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, train, shift=None):
+    """-> saved [4][C] = mean, invstd, sc, sh.  shift = the tensor the statistics in `part` were summed about (it may be
+    running_mean itself: the kernel reads it before updating)"""
     saved = _empty((4, C), gamma if gamma is not None else running_mean)
     rows = part.shape[0] if part is not None else 0
     ws = _reduce_ws(rows, C, saved) if train else None
     check(lib().koaf_bn_finalize(_ptr(part), rows, C, count, _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                  _ptr(running_var), _ptr(nbt), momentum, eps, 1 if train else 0, _ptr(saved[0]),
-                                 _ptr(saved[1]), _ptr(saved[2]), _ptr(saved[3]), _ptr(ws), _stream()), "bn_finalize")
+                                 _ptr(saved[1]), _ptr(saved[2]), _ptr(saved[3]), _ptr(shift) if train else None, _ptr(ws),
+                                 _stream()), "bn_finalize")
     return saved
 
 

@@ -461,3 +461,33 @@ print("ERR", r1, r2)
         errs[mode] = [float(v) for v in line[0].split()[1:]]
     assert max(errs["full"]) < 4e-6, errs
     assert 2e-6 < max(errs["default"]) < BWD, errs
+
+
+def test_shifted_batchnorm_statistics(dev):
+    """BatchNorm batch statistics of a conv output whose channel means are hundreds of standard deviations away from
+    zero: summed about a shift near the mean (the running mean, KoafGemm.stats_shift) the variance keeps fp32-level
+    accuracy; unshifted, E[x^2] - mean^2 loses most of its digits.  Ragged last tile and a 3x3 gather included."""
+    from oaprogressionmmf_amd import ops
+    N, H, W, Cin, Cout = 3, 19, 17, 64, 64
+    x = torch.rand(N, Cin, H, W, generator=G) * 0.02 + 1.0                 # nearly constant, positive input
+    w = rnd(Cout, Cin, 3, 3, scale=0.01) + 0.05                            # weights with a common positive part
+    y_ref = F.conv2d(x.double(), w.double(), padding=1)
+    mean_ref = y_ref.mean((0, 2, 3))
+    var_ref = y_ref.var((0, 2, 3), unbiased=False)
+    assert (mean_ref.abs() / var_ref.sqrt()).median() > 3                  # (border pixels keep the std from vanishing)
+    rows = N * H * W
+    xd, wp = nhwc(x).to(dev), packw(w).to(dev)
+    gamma, beta = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+    errs = {}
+    for tag, shift in (("none", None), ("near", (mean_ref * 0.98).float().to(dev))):
+        y, part = ops.conv2d_fwd(xd, wp, N, H, W, Cin, Cout, 3, 3, 1, 1, stats=True, shift=shift)
+        rm = shift.clone() if shift is not None else torch.zeros(Cout, device=dev)
+        rv, nbt = torch.ones(Cout, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+        saved = ops.bn_finalize(part, Cout, rows, gamma, beta, rm, rv, nbt, 0.1, 1e-5, True, shift=rm if shift is not None else None)
+        mean, invstd = saved[0].double().cpu(), saved[1].double().cpu()
+        errs[tag] = (rel_err(mean, mean_ref), rel_err(invstd, 1.0 / torch.sqrt(var_ref + 1e-5)))
+        # the running mean is updated from its old value (which doubled as the shift): 0.9 * old + 0.1 * batch mean
+        want_rm = 0.9 * (shift.double().cpu() if shift is not None else torch.zeros(Cout).double()) + 0.1 * mean_ref
+        assert rel_err(rm, want_rm) < 1e-6
+    assert errs["near"][0] < 1e-6 and errs["near"][1] < 2e-6, errs
+    assert errs["near"][1] <= errs["none"][1], errs

@@ -237,7 +237,7 @@ def _recompute_cases(dev, dict_fes, KoafTrunk):
 def test_spatial_encoder_output_with_dropout2d(dev):
     """with_gap=false keeps the (h, w) grid of the last stage as tokens; Dropout2d then drops whole channels
     (SURVEY 8f-4).  Eval forward (dropout off) matches the oracle; the train step with p > 0 runs, its loss and every
-    gradient are finite, and a second forward with the same torch seed reproduces the same masks."""
+    gradient are finite, and a second forward with the same torch seed reproduces the same masks (outputs equal to 1e-5)."""
     from oracle import koafusion_cpu as O
     from oaprogressionmmf_amd.various import dict_losses, set_ultimate_seed
     cfg = P.cfg_mr1(shape=(64, 64, 32), with_gap=False, depth=1, dropout=0.3)
@@ -263,5 +263,7 @@ def test_spatial_encoder_output_with_dropout2d(dev):
         assert torch.isfinite(loss)
         assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
         outs.append(lg.detach().clone())
-    assert torch.equal(outs[0], outs[1])
+    # same masks both times; last-bit differences only: the batch statistics are summed about the running mean, which
+    # the first pass has updated (KoafGemm.stats_shift)
+    assert rel(outs[1].cpu().numpy(), outs[0].cpu().numpy()) < 1e-5
     assert rel(outs[0].cpu().numpy(), le.cpu().numpy()) > 1e-3      # dropout did change the train-mode output

@@ -52,11 +52,10 @@ def _worker(rank, world, port, q):
             xs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in P.model_inputs(cfg, B, 50 + r)]
             return xs, torch.from_numpy(P.make_target("target", B, 50 + r)).to(dev)
         # reference: both ranks' batches on a model of its own, loss scaled by 1/world, no exchange
-        ref = make()
         parts = []
         for r in range(world):
-            ref.zero_grad()
-            xs, y = batch(r)
+            ref = make()       # fresh BatchNorm buffers per batch, like each rank's replica (the batch statistics are
+            xs, y = batch(r)   # summed about the running mean, so its value shows in the last bits)
             (loss_fn(ref(*xs)["main"].squeeze(1), y.long().squeeze(1)) / world).backward()
             parts.append({k: p.grad.detach().clone() for k, p in ref.named_parameters() if p.grad is not None})
         want = {k: parts[0][k] + parts[1][k] for k in parts[0]}
@@ -64,7 +63,11 @@ def _worker(rank, world, port, q):
         ddp = DataParallelRCCL(make(), bucket_elems=4 * 1024 * 1024)
         xs, y = batch(rank)
         bad = {}
+        buf0 = {k: b.detach().clone() for k, b in ddp.module.named_buffers()}
         for step in range(3):          # step 0 learns the plan; steps 1, 2 launch from the delivery hooks
+            with torch.no_grad():      # same BatchNorm buffers (= statistics shift) as the reference at every step
+                for k, b in ddp.module.named_buffers():
+                    b.copy_(buf0[k])
             ddp.module.zero_grad()
             loss = loss_fn(ddp(*xs)["main"].squeeze(1), y.long().squeeze(1))
             ddp.scale_loss(loss).backward()
