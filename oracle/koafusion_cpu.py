@@ -11,6 +11,11 @@ tests/test_oracle_golden.py.  Third-party arithmetic (conv, batch_norm, layer_no
 interpolate, Adam) is PyTorch's CPU backend here as in the reference (torch 2.10.0 here vs the reference's
 pin torch==2.5.1, env_base.yml:14 -- version skew recorded in every fixture).
 
+Blocks with a different status, marked where they start: the three registry EXTENSIONS (XR1C1Cnn, MR1C1CnnTrf,
+XR1MR3C1CnnTrf: compositions of pinned blocks, no reference class exists to pin the composition against), the
+evaluation-regime helpers (the reference module is not importable here; pinned against the published statement sequence
+run with the reference's own library calls) and the input pipeline (pinned by fixture F12 from the reference's classes).
+
 Each function cites the reference lines it restates.
 """
 import math
