@@ -2,6 +2,7 @@
 path.  The drivers themselves (hydra, data loaders, tensorboard, metrics) stay the reference's."""
 from ._steps import downscale_inputs, train_step, predict_batch
 from ._eval import eval_epoch, ensemble_eval_foldw, InferenceTimer
+from ._graph import GraphedPredictor
 
 __all__ = ["downscale_inputs", "train_step", "predict_batch", "eval_epoch", "ensemble_eval_foldw",
-           "InferenceTimer"]
+           "InferenceTimer", "GraphedPredictor"]
