@@ -14,7 +14,9 @@ pin torch==2.5.1, env_base.yml:14 -- version skew recorded in every fixture).
 Blocks with a different status, marked where they start: the three registry EXTENSIONS (XR1C1Cnn, MR1C1CnnTrf,
 XR1MR3C1CnnTrf: compositions of pinned blocks, no reference class exists to pin the composition against), the
 evaluation-regime helpers (the reference module is not importable here; pinned against the published statement sequence
-run with the reference's own library calls) and the input pipeline (pinned by fixture F12 from the reference's classes).
+run with the reference's own library calls), the explanation regime (modal ablation: captum is a third-party dependency
+absent from /root/reference -- its FeatureAblation rule for the reference's call is restated and pinned on the reference
+MODEL's logits with each modality zeroed, fixture F13) and the input pipeline (pinned by fixture F12 from the reference's classes).
 
 Each function cites the reference lines it restates.
 """
@@ -603,4 +605,66 @@ def ensemble_foldw(raw_foldw):
     s = s / np.sum(s, axis=-1, keepdims=True) if m.size else s
     out["predict_proba"] = s.tolist()
     out["predict"] = np.argmax(s, axis=-1).tolist() if m.size else []
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Explanation regime.  PIN STATUS: captum (env_base.yml, un-vendored) and the driver module are not
+# importable here; modal_ablation is pinned by fixture F13 (reference model forwards + the restated rule),
+# ensemble_explain_foldw by the published statement sequence run with pandas (tests/test_explain_cpu.py).
+# ---------------------------------------------------------------------------------------------------------
+def modal_ablation(forward, xs, target):
+    """The attribution koafusion/run/eval_prog_fus.py:441-455 obtains from captum.attr.FeatureAblation (captum is
+    not under /root/reference; pinned `captum` in env_base.yml): feature_mask gives input m the single feature id
+    m, baselines=None ablates to zeros, perturbations_per_eval=1, target selects one output column per sample.
+    captum's published rule for that call: attr(feature) = f(x)[target] - f(x with the feature at its baseline)
+    [target], written to every element the feature's mask covers -- so the reference's per-input mean over elements
+    (:452-454) is that difference.  `forward(*xs)` -> (B, classes) logits; returns (B, M) fp32."""
+    tgt = torch.as_tensor(target).long().reshape(-1, 1)
+    with torch.no_grad():
+        base = forward(*xs).reshape(xs[0].shape[0], -1)
+        if tgt.shape[0] == 1 and base.shape[0] > 1:
+            tgt = tgt.expand(base.shape[0], 1)
+        base = base.gather(1, tgt)
+        cols = []
+        for m in range(len(xs)):
+            ablated = [torch.zeros_like(x) if j == m else x for j, x in enumerate(xs)]
+            cols.append(base - forward(*ablated).reshape(base.shape[0], -1).gather(1, tgt))
+    return torch.cat(cols, dim=1)
+
+
+def ablation_percent(attrs):
+    """koafusion/run/eval_prog_fus.py:456-459"""
+    import numpy as np
+    t = torch.as_tensor(attrs, dtype=torch.float32)
+    t = t / torch.sum(torch.abs(t), dim=1, keepdim=True)
+    return np.round(np.abs(t.numpy()) * 100., decimals=3)
+
+
+def ensemble_explain_foldw(raw_foldw):
+    """koafusion/run/eval_prog_fus.py:481-512 without pandas: inner 1:1 join on exam_knee_id, `target` and
+    `modal_names` kept from the first fold, per-fold attrs / per-cent columns, modal_abl_percent = mean over folds
+    of the per-cent rows divided by its row sum."""
+    import numpy as np
+    folds = list(raw_foldw.keys())
+    first = raw_foldw[folds[0]]
+    index = []
+    for k in folds:
+        ids = list(raw_foldw[k]["exam_knee_id"])
+        if len(set(ids)) != len(ids):
+            raise ValueError("Merge keys are not unique")
+        index.append({e: i for i, e in enumerate(ids)})
+    keep = [e for e in first["exam_knee_id"] if all(e in ix for ix in index)]
+    out = dict(exam_knee_id=keep, target=[first["target"][index[0][e]] for e in keep],
+               modal_names=[first["modal_names"][index[0][e]] for e in keep])
+    per = []
+    for k, ix in zip(folds, index):
+        out[f"modal_abl_attrs__{k}"] = [raw_foldw[k]["modal_abl_attrs"][ix[e]] for e in keep]
+        out[f"modal_abl_percent__{k}"] = [raw_foldw[k]["modal_abl_percent"][ix[e]] for e in keep]
+        per.append(out[f"modal_abl_percent__{k}"])
+    if not keep:
+        out["modal_abl_percent"] = []
+        return out
+    t = np.mean(np.asarray(per, dtype=np.float64).transpose(1, 0, 2), axis=1)
+    out["modal_abl_percent"] = (t / np.sum(t, axis=1, keepdims=True)).tolist()
     return out

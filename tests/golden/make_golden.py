@@ -350,6 +350,35 @@ def case_f12_augment(preproc, **_):
     print("  wrote f12_augment.npz")
 
 
+def case_f13_modal_abl(km, **_):
+    """Explain regime (eval_prog_fus.py:410-479).  captum is absent here, so its FeatureAblation rule for the
+    reference's call (one feature id per input, zero baselines, one perturbation per evaluation) is applied by hand
+    to the REFERENCE model's own forwards: attr[b, m] = f(x)[b, y_b] - f(x, modality m zeroed)[b, y_b]."""
+    t0 = time.time()
+    cfg = P.cfg_full(xr=(160, 160), mr1=(96, 96, 6), mr2=(96, 96, 5), depth=1)
+    cfg["output_type"] = "main"                      # the tensor-returning mode the reference keeps for captum
+    B, seed = 3, 77
+    torch.manual_seed(0)
+    model = km.dict_models[cfg["name"]](config=Cfg(cfg), path_weights=None)
+    P.fill_state_dict(model.state_dict())
+    model.eval()
+    xs = [t(a) for a in P.model_inputs(cfg, B, seed)]
+    y = t(P.make_target("target", B, seed))
+    logits = []
+    with torch.no_grad():
+        logits.append(model(*xs).reshape(B, -1))
+        for m in range(len(xs)):
+            logits.append(model(*[torch.zeros_like(x) if j == m else x for j, x in enumerate(xs)]).reshape(B, -1))
+    sel = [lg.gather(1, y.long()) for lg in logits]
+    attrs = torch.cat([sel[0] - s for s in sel[1:]], dim=1)
+    pc = attrs / torch.sum(torch.abs(attrs), dim=1, keepdim=True)
+    percent = np.round(np.abs(pc.numpy()) * 100., decimals=3)
+    np.savez_compressed(HERE / "f13_modal_abl.npz", B=np.int64(B), seed=np.int64(seed),
+                        cfg_json=np.array(json.dumps(cfg)), torch_version=np.array(torch.__version__),
+                        logits=torch.stack(logits).numpy(), target=y.numpy(), attrs=attrs.numpy(), percent=percent)
+    print(f"  wrote f13_modal_abl.npz in {time.time() - t0:.1f}s; attrs=\n{attrs.numpy()}\npercent=\n{percent}")
+
+
 def case_f9_sched(optims, **_):
     p = [torch.nn.Parameter(torch.zeros(1))]
     tab = {}
@@ -401,7 +430,7 @@ def case_f11_bookkeeping(km, losses, **_):
 CASES = {
     "f1": case_f1_attention_feat, "f2": case_f2_bottleneck, "f3": case_f3_trunk, "f4": case_f4_xr1cnn,
     "f5": case_f5_mr, "f6": case_f6_full, "f7": case_f7_focal, "f8": case_f8_interp, "f9": case_f9_sched,
-    "f11": case_f11_bookkeeping, "f12": case_f12_augment,
+    "f11": case_f11_bookkeeping, "f12": case_f12_augment, "f13": case_f13_modal_abl,
 }
 
 

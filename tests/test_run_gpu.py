@@ -180,3 +180,38 @@ def test_graphed_predictor_replays_the_inference_pass(dev):
         gp(*[x[:1] for x in xs0])
     with pytest.raises(TypeError):
         gp(xs0[0])
+
+
+def test_explain_epoch_modal_ablation(dev):
+    """explain regime (eval_prog_fus.py:410-479): the M + 1 HIP forwards per batch reproduce fixture F13 (the imported
+    reference model's logits with each modality zeroed) and the oracle's accumulators; ragged loader (2 + 1: the
+    single-sample batch exercises the squeezed-target case); output_type "main" (the tensor-returning captum mode)"""
+    import json
+    from pathlib import Path
+    from oracle import koafusion_cpu as O
+    from oaprogressionmmf_amd.run import explain_epoch, ensemble_explain_foldw
+    g = np.load(Path(__file__).resolve().parent / "golden" / "f13_modal_abl.npz")
+    cfg, B, seed = json.loads(str(g["cfg_json"])), int(g["B"]), int(g["seed"])
+    assert cfg["output_type"] == "main"
+    xs = [t(a) for a in P.model_inputs(cfg, B, seed)]
+    y = t(P.make_target("target", B, seed))
+    loader = [{**{f"image__{m}": x[lo:hi] for m, x in zip(MODALS, xs)}, "target": y[lo:hi],
+               ("-", "exam_knee_id"): [f"k{j}" for j in range(lo, hi)]} for lo, hi in ((0, 2), (2, 3))]
+    m = build(cfg, dev).eval()
+    acc = explain_epoch(m, loader, MODALS)
+    assert list(acc.keys()) == ["exam_knee_id", "target", "modal_names", "modal_abl_attrs", "modal_abl_percent"]
+    assert acc["exam_knee_id"] == ["k0", "k1", "k2"] and acc["target"] == g["target"].tolist()
+    assert acc["modal_names"] == [list(MODALS)] * 3
+    attrs = np.asarray(acc["modal_abl_attrs"])
+    scale = max(1.0, np.abs(g["logits"]).max())
+    assert attrs.shape == (3, 4)
+    assert np.abs(attrs - g["attrs"]).max() < 1e-3 * scale * 0.05, (attrs, g["attrs"])     # 5e-5 of the logit scale
+    assert np.abs(np.asarray(acc["modal_abl_percent"]) - g["percent"]).max() < 0.05        # per-cent points
+    np.testing.assert_allclose(np.asarray(acc["modal_abl_percent"]).sum(1), 100.0, atol=2e-3)
+    # host arithmetic on the product's own attributions is exact
+    np.testing.assert_array_equal(np.asarray(acc["modal_abl_percent"], dtype=np.float32),
+                                  O.ablation_percent(np.asarray(acc["modal_abl_attrs"], dtype=np.float32)))
+    ens = ensemble_explain_foldw({0: acc, 1: acc})
+    np.testing.assert_allclose(np.asarray(ens["modal_abl_percent"]) * 100.0, acc["modal_abl_percent"], atol=2e-3)
+    with pytest.raises(ValueError):
+        explain_epoch(m, loader, MODALS, explain_fn="grad_cam")
