@@ -285,6 +285,13 @@ def case_f5_mr(km, losses, **_):
     run_model_case(km, losses, P.cfg_mr2(), 2, "f5_mr2.npz")
     run_model_case(km, losses, P.cfg_xr1mr1(), 2, "f5_xr1mr1.npz")
     run_model_case(km, losses, P.cfg_xr1mr2(), 2, "f5_xr1mr2.npz")
+    case_f5_nogap(km, losses)
+
+
+def case_f5_nogap(km, losses, **_):
+    """with_gap: false -- the (h, w) grid of the last stage stays as tokens (_mrN_cnn_trf.py:32-40, _xr1mrN.py:64-81)"""
+    run_model_case(km, losses, P.cfg_mr1(shape=(64, 96, 32), with_gap=False, depth=1), 1, "f5_mr1_nogap.npz")
+    run_model_case(km, losses, P.cfg_xr1mr1(xr=(96, 96), mr=(64, 64, 32), with_gap=False), 1, "f5_xr1mr1_nogap.npz")
 
 
 def case_f6_full(km, losses, **_):
@@ -429,7 +436,7 @@ def case_f11_bookkeeping(km, losses, **_):
 
 CASES = {
     "f1": case_f1_attention_feat, "f2": case_f2_bottleneck, "f3": case_f3_trunk, "f4": case_f4_xr1cnn,
-    "f5": case_f5_mr, "f6": case_f6_full, "f7": case_f7_focal, "f8": case_f8_interp, "f9": case_f9_sched,
+    "f5": case_f5_mr, "f5g": case_f5_nogap, "f6": case_f6_full, "f7": case_f7_focal, "f8": case_f8_interp, "f9": case_f9_sched,
     "f11": case_f11_bookkeeping, "f12": case_f12_augment, "f13": case_f13_modal_abl,
 }
 

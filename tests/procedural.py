@@ -125,11 +125,11 @@ def cfg_mr2(shape0=(160, 160, 8), shape1=(160, 160, 6), depth=1):
                 output_type="dict", pretrained=False, path_pretrained=None, restore_weights=False, debug=False)
 
 
-def cfg_xr1mr1(xr=(160, 160), mr=(160, 160, 6), depth=1, xr_arch="resnext50_32x4d"):
+def cfg_xr1mr1(xr=(160, 160), mr=(160, 160, 6), depth=1, xr_arch="resnext50_32x4d", with_gap=True):
     return dict(name="XR1MR1CnnTrf", input_size=[list(xr), list(mr)], downscale=False, input_channels=1,
                 output_channels=2,
-                fe=dict(xr=dict(arch=xr_arch, pretrained=False, with_gap=True, dropout=0.0),
-                        mr=dict(arch="resnet50", pretrained=False, with_gap=True, dropout=0.0)),
+                fe=dict(xr=dict(arch=xr_arch, pretrained=False, with_gap=with_gap, dropout=0.0),
+                        mr=dict(arch="resnet50", pretrained=False, with_gap=with_gap, dropout=0.0)),
                 agg=dict(num_slices=[1, mr[2]], depth=depth, heads=8, emb_dropout=0.0, mlp_dim=2048, mlp_dropout=0.0),
                 output_type="dict", pretrained=False, path_pretrained=None, restore_weights=False, debug=False)
 

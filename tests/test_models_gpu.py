@@ -98,7 +98,7 @@ def run_case(fname, dev, adam_steps=0):
 
 @pytest.mark.parametrize("fname", ["f4_xr1cnn_r18_160.npz", "f4_xr1cnn_350.npz", "f4_xr1cnn_310.npz", "f5_mr1_cs.npz",
                                    "f5_mr1_rs.npz", "f5_mr2.npz", "f5_xr1mr1.npz", "f5_xr1mr2.npz",
-                                   "f5_mr1_rc_s64.npz"])
+                                   "f5_mr1_rc_s64.npz", "f5_mr1_nogap.npz", "f5_xr1mr1_nogap.npz"])
 def test_models_vs_reference(dev, fname):
     run_case(fname, dev)
 

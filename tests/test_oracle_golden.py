@@ -76,7 +76,8 @@ def compare_case(out, gold, gtol=2e-4):
 
 
 SMALL = ["f4_xr1cnn_350.npz", "f4_xr1cnn_310.npz", "f4_xr1cnn_r18_160.npz", "f5_mr1_cs.npz", "f5_mr1_rs.npz",
-         "f5_mr2.npz", "f5_xr1mr1.npz", "f5_xr1mr2.npz", "f5_mr1_rc_s64.npz"]
+         "f5_mr2.npz", "f5_xr1mr1.npz", "f5_xr1mr2.npz", "f5_mr1_rc_s64.npz", "f5_mr1_nogap.npz",
+         "f5_xr1mr1_nogap.npz"]
 
 
 @pytest.mark.parametrize("fname", SMALL)
