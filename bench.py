@@ -154,9 +154,13 @@ def main():
     backend = os.environ.get("KOAF_DIST_BACKEND", "nccl")
     if os.environ.get("KOAF_ONE_DEVICE"):
         local = 0
-    if world > 1:
+    # KOAF_DIST_REHEARSAL=1: a world of ONE still builds the RCCL process group and runs every collective of the N>1
+    # path (parameter broadcast, bucketed gradient all-reduce, barrier, MAX over ranks) -- what a 1-GPU box can rehearse.
+    dist_on = world > 1 or bool(os.environ.get("KOAF_DIST_REHEARSAL"))
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -181,7 +185,7 @@ def main():
         _e.USE_SIDE_STREAM = False
         _c.USE_LANES = False
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -195,7 +199,7 @@ def main():
             for m in model.modules():
                 if isinstance(m, KoafTrunk):
                     m.recompute = args.recompute_mode if args.recompute_mode == "block" else True
-        ddp = DataParallelRCCL(model)
+        ddp = DataParallelRCCL(model, exchange_always=dist_on)
         loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
         opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4)
         shapes_cfg = dict(cfg, input_size=cfg.pop("_tensor_shapes")) if "_tensor_shapes" in cfg else cfg
@@ -233,7 +237,7 @@ def main():
             lv = step()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             dt = float(tt.item())
@@ -390,7 +394,7 @@ def main():
             if cb is not None:
                 out["cpu_baseline"] = cb
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

@@ -23,13 +23,16 @@ BUCKET_ELEMS = 32 * 1024 * 1024   # 128 MB of fp32 per all-reduce (xGMI ring is 
 
 
 class DataParallelRCCL(nn.Module):
-    def __init__(self, module: nn.Module, process_group=None, bucket_elems=BUCKET_ELEMS, overlap=True):
+    def __init__(self, module: nn.Module, process_group=None, bucket_elems=BUCKET_ELEMS, overlap=True,
+                 exchange_always=False):
         super().__init__()
         self.module = module
         self.pg = process_group
         self.bucket_elems = bucket_elems
         self.overlap = overlap
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
+        # exchange_always: run the collectives even in a world of one (RCCL rehearsal on a 1-GPU box; a no-op sum)
+        self._active = self.world > 1 or (exchange_always and dist.is_initialized())
         self._arena = None
         self._plan = None          # list of buckets: dict(lo, hi, need=set(param ids))
         self._pending = None
@@ -45,7 +48,7 @@ class DataParallelRCCL(nn.Module):
             self._arena = a
             self._plan = None
             a.ready_hook = self._on_ready
-            if self.world > 1:
+            if self._active:
                 self.broadcast_parameters()
         return a
 
@@ -77,7 +80,7 @@ class DataParallelRCCL(nn.Module):
 
     def _on_ready(self, p):
         self._seen.append(p)
-        if self.world == 1 or self._plan is None or not self.overlap:
+        if not self._active or self._plan is None or not self.overlap:
             return
         pid = id(p)
         bi = self._where.get(pid)
@@ -125,7 +128,7 @@ class DataParallelRCCL(nn.Module):
 
     def reduce_gradients(self):
         """Call after backward(): finishes (or, on the first step, performs) the gradient all-reduce."""
-        if self.world == 1:
+        if not self._active:
             return
         a = self._arena
         if self._plan is None or not self.overlap:

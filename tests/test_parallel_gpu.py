@@ -1,4 +1,9 @@
-"""GPU, world_size 2 on ONE device (gloo moves the buckets; the driver's real runs use RCCL): the data-parallel
+"""(second test) RCCL itself, world of ONE: the box has one GPU and RCCL refuses two ranks on a device, so the nccl code
+path -- process group with device_id, broadcast of the parameter arena, async all-reduce of arena slices on the
+staging stream, handle.wait() on the compute stream -- is rehearsed with `exchange_always=True`; summing over one rank
+must leave the train step bit-identical to the exchange-free one.
+
+(first test) GPU, world_size 2 on ONE device (gloo moves the buckets; the driver's real runs use RCCL): the data-parallel
 train step of a model whose encoders run on separate HIP streams.  The early (overlapped) all-reduce of a gradient
 bucket must be ordered behind every stream that wrote into it -- a bucket can hold gradients of two encoders.  With
 deterministic kernels and two ranks the reduced gradient must equal, bit for bit, 0.5*g(rank 0 batch) + 0.5*g(rank 1
@@ -100,3 +105,64 @@ def test_two_ranks_overlapped_allreduce_is_exact(dev):
         assert err is None, f"rank {rank}:\n{err}"
         assert nb >= 8, f"only {nb} buckets: the plan does not straddle encoders"
         assert all(len(v) == 0 for v in bad.values()), f"rank {rank}: gradients differ from the exchange-free sum: {bad}"
+
+
+def _rccl_worker(port, q):
+    import sys
+    from pathlib import Path
+    here = Path(__file__).resolve().parent
+    sys.path.insert(0, str(here))
+    sys.path.insert(0, str(here.parent))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import numpy as np
+        import procedural as P
+        from oaprogressionmmf_amd.config import ConfigDict
+        from oaprogressionmmf_amd.models import dict_models
+        from oaprogressionmmf_amd.parallel import DataParallelRCCL
+        from oaprogressionmmf_amd.run import train_step
+        from oaprogressionmmf_amd.various import dict_losses, dict_optimizers
+        dev = torch.device("cuda:0")
+        cfg = P.cfg_xr1mr2(xr=(96, 96), mr1=(64, 64, 3), mr2=(64, 64, 2), depth=1)
+        loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
+        xs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in P.model_inputs(cfg, 2, 60)]
+        y = torch.from_numpy(P.make_target("target", 2, 60)).to(dev)
+
+        def run(wrap):
+            m = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None)
+            P.fill_state_dict(m.state_dict())
+            m = m.to(dev).train()
+            model = DataParallelRCCL(m, bucket_elems=4 * 1024 * 1024, exchange_always=True) if wrap else m
+            opt = dict_optimizers["Adam"](m.parameters(), lr=1e-4, weight_decay=1e-4)
+            losses = [float(train_step(model, loss_fn, opt, xs, y)[1]) for _ in range(3)]
+            torch.cuda.synchronize()
+            return losses, {k: v.detach().clone() for k, v in m.state_dict().items()}, model
+        l0, sd0, _ = run(False)
+        l1, sd1, ddp = run(True)
+        bad = [k for k in sd0 if not torch.equal(sd0[k], sd1[k])]
+        t = torch.ones(1024, device=dev)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        q.put((None, l0, l1, bad, len(ddp._plan), dist.get_backend(), float(t.sum())))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((traceback.format_exc(), None, None, None, 0, None, 0.0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world_of_one_exchange_is_a_noop(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    err, l0, l1, bad, nb, backend, s = q.get(timeout=600)
+    p.join(timeout=120)
+    assert err is None, err
+    assert backend == "nccl" and s == 1024.0
+    assert nb >= 8, f"only {nb} buckets went through RCCL"
+    assert l0 == l1, (l0, l1)
+    assert bad == [], f"state after 3 steps differs with the RCCL exchange in the loop: {bad[:5]}"
