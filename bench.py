@@ -179,7 +179,7 @@ def main():
     from oaprogressionmmf_amd.parallel import DataParallelRCCL
     from oaprogressionmmf_amd.various import dict_losses, dict_optimizers, set_ultimate_seed
 
-    set_ultimate_seed()
+    set_ultimate_seed(777 + 16 * rank)   # distinct dropout streams per rank; rank 0's parameters are broadcast
     if args.serial:
         from oaprogressionmmf_amd.models import _common as _c, _encoder as _e
         _e.USE_SIDE_STREAM = False
