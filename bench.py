@@ -50,6 +50,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak, v_mfma_f32_32x32
 # a call is the dense bf16 MFMA peak (2.5 PFLOP/s, same table) divided by its MFMAs per product; the bound of the step's
 # mix is the FLOP-weighted harmonic mean over its calls.
 BF16_MFMA_PEAK_TFLOPS = 2500.0
+HBM_PEAK_TBPS = 8.0
 MFMA_PER_PRODUCT_FWD, MFMA_PER_PRODUCT_BWD = 6, 4
 
 
@@ -274,27 +275,39 @@ def main():
     ops.PROFILE = []
     step()
     torch.cuda.synchronize()
-    prof = [(f, fl, e0.elapsed_time(e1), tag) for f, fl, e0, e1, tag in ops.PROFILE]
+    prof_b = [(f, fl, e0.elapsed_time(e1), tag, nb) for f, fl, e0, e1, tag, nb in ops.PROFILE]
+    prof = [p[:4] for p in prof_b]
     ops.PROFILE = None
     gemm_ms = sum(ms for f, fl, ms, tag in prof if f == "gemm")
     gemm_flop = sum(fl for f, fl, ms, tag in prof if f == "gemm")
     n_launch = sum(1 for f, *_ in prof if f == "gemm")
-    if args.breakdown and rank == 0:
-        agg = {}
-        for f, fl, ms, tag in prof:
-            a = agg.setdefault(tag, [0, 0.0, 0.0])
-            a[0] += 1; a[1] += fl; a[2] += ms
-        with open(args.breakdown, "w") as fh:
-            fh.write(f"# per-shape GEMM-family calls of one train step ({args.workload}, batch {B}); ms from events on the launch stream\n")
-            fh.write(f"{'call':48s} {'n':>4s} {'ms':>9s} {'GFLOP':>10s} {'TFLOP/s':>8s}\n")
-            for tag, (n, fl, ms) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
-                fh.write(f"{tag:48s} {n:4d} {ms:9.3f} {fl / 1e9:10.1f} {fl / ms / 1e9 if ms > 0 else 0:8.1f}\n")
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     full_bwd = os.environ.get("KOAF_BWD_PRECISION", "")[:1] == "f"
 
     def call_peak(tag):
         bwd = any(k in tag for k in ("dgrad", "wgrad", "attn_bwd")) and not full_bwd
         return BF16_MFMA_PEAK_TFLOPS / (MFMA_PER_PRODUCT_BWD if bwd else MFMA_PER_PRODUCT_FWD)
+
+    def call_floor_ms(fl, tag, nb):
+        """roofline time of one call: the larger of its matrix-pipe time and the time to move each operand once"""
+        return max(fl / (call_peak(tag) * 1e12), nb / (HBM_PEAK_TBPS * 1e12)) * 1e3
+    floor_ms = sum(call_floor_ms(fl, tag, nb) for f, fl, ms, tag, nb in prof_b if f == "gemm")
+    hbm_ms = sum(ms for f, fl, ms, tag, nb in prof_b
+                 if f == "gemm" and nb / (HBM_PEAK_TBPS * 1e12) > fl / (call_peak(tag) * 1e12))
+    if args.breakdown and rank == 0:
+        agg = {}
+        for f, fl, ms, tag, nb in prof_b:
+            a = agg.setdefault(tag, [0, 0.0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += fl; a[2] += ms; a[3] += nb; a[4] += call_floor_ms(fl, tag, nb)
+        with open(args.breakdown, "w") as fh:
+            fh.write(f"# per-shape GEMM-family calls of one train step ({args.workload}, batch {B}); ms from events on the launch stream;\n"
+                     f"# MB = algorithmic HBM bytes (every operand once); floor = max(FLOP / matrix-pipe bound of the call, bytes / "
+                     f"{HBM_PEAK_TBPS:g} TB/s); bound = which term of the floor is larger\n")
+            fh.write(f"{'call':48s} {'n':>4s} {'ms':>9s} {'GFLOP':>10s} {'TFLOP/s':>8s} {'MB':>9s} {'TB/s':>6s} {'floor ms':>9s} {'bound':>5s}\n")
+            for tag, (n, fl, ms, nb, flo) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+                bound = "hbm" if nb / (HBM_PEAK_TBPS * 1e12) > fl / (call_peak(tag) * 1e12) else "mfma"
+                fh.write(f"{tag:48s} {n:4d} {ms:9.3f} {fl / 1e9:10.1f} {fl / ms / 1e9 if ms > 0 else 0:8.1f} {nb / 1e6:9.1f} "
+                         f"{nb / ms / 1e9 if ms > 0 else 0:6.2f} {flo:9.3f} {bound:>5s}\n")
     bound_s = sum(fl / (call_peak(tag) * 1e12) for f, fl, ms, tag in prof if f == "gemm")
     peak_mix = gemm_flop / bound_s / 1e12 if bound_s > 0 else BF16_MFMA_PEAK_TFLOPS / MFMA_PER_PRODUCT_FWD
     bwd_share = sum(fl for f, fl, ms, tag in prof if f == "gemm" and any(k in tag for k in ("dgrad", "wgrad", "attn_bwd")))
@@ -353,6 +366,11 @@ def main():
                                     "the rest at 416.7 TFLOP/s fp32-equivalent)",
                          "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
                          "achieved_over_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                         "floor_ms_per_step": round(floor_ms, 2), "frac_of_floor": round(floor_ms / gemm_ms, 4) if gemm_ms > 0 else None,
+                         "hbm_bound_share_of_kernel_ms": round(hbm_ms / gemm_ms, 4) if gemm_ms > 0 else None,
+                         "floor_is": "sum over the step's calls of max(FLOP / matrix-pipe bound of the call, algorithmic bytes / 8 TB/s): "
+                                     "SURVEY 8(d)'s attainable = min(MFMA peak, AI x HBM) applied per call; frac_of_floor = floor / "
+                                     "measured kernel time; `frac` above stays the plain achieved / matrix-pipe peak",
                          "launches_per_step": n_launch, "kernel_ms_per_step": round(gemm_ms, 2),
                          "algorithmic_gflop_per_step": round(gemm_flop / 1e9, 1),
                          "step_gflop_per_sample_survey": algorithmic_train_gflop_per_sample(args.workload)},

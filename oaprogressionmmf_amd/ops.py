@@ -27,12 +27,13 @@ def _prof_begin():
     return e
 
 
-def _prof_end(e0, family, flops, tag=""):
+def _prof_end(e0, family, flops, tag="", elems=0):
+    """elems: fp32 elements the call must move through HBM if every operand travels exactly once (its algorithmic bytes / 4)"""
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    PROFILE.append((family, flops, e0, e1, tag))
+    PROFILE.append((family, flops, e0, e1, tag, 4.0 * elems))
 
 
 def _ptr(t):
@@ -74,7 +75,8 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     check(L.koaf_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
                             _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _ptr(shift) if stats else None, _stream()),
           "conv2d_fwd")
-    _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin, f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}")
+    _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin, f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}",
+              N * H * W * Cin + Cout * KH * KW * Cin + N * OH * OW * Cout)
     if stats:
         part = part[:rows.value]
     return y, part
@@ -88,11 +90,13 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, 
     dx = _empty((N, H, W, Cin), dy)
     fl = 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin
     tag = f"conv_dgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}"
+    el = N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout + Cout * KH * KW * Cin + N * H * W * Cin
+    el += N * H * W * Cin if residual is not None else 0
     if bnb is None:
         e0 = _prof_begin()
         check(L.koaf_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
                                   _ptr(residual), _stream()), "conv2d_dgrad")
-        _prof_end(e0, "gemm", fl, tag)
+        _prof_end(e0, "gemm", fl, tag, el)
         return dx
     sv, sv2 = bnb["saved"], bnb.get("saved2")
     kb = KoafBnb(mode=bnb["mode"], c=_ptr(bnb["c"]), y=_ptr(bnb.get("y")), sc=_ptr(sv[2]), sh=_ptr(sv[3]),
@@ -105,7 +109,8 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, 
     check(L.koaf_conv2d_dgrad_bnb(_ptr(dy), _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
                                   _ptr(residual), ctypes.byref(kb), _ptr(part), ctypes.addressof(rows), _stream()),
           "conv2d_dgrad_bnb")
-    _prof_end(e0, "gemm", fl, tag + " +bnb")
+    el += N * H * W * Cin * (1 + (bnb.get("y") is not None) + (bnb.get("c2") is not None))
+    _prof_end(e0, "gemm", fl, tag + " +bnb", el)
     return dx, part[:rows.value]
 
 
@@ -118,7 +123,8 @@ def conv2d_wgrad(dy, x, dw, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None,
     check(L.koaf_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
                               _ptr(in_sh), _ptr(slabs), _stream()), "conv2d_wgrad")
     _prof_end(e0, "gemm", 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin,
-              f"conv_wgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}")
+              f"conv_wgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}",
+              N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout + N * H * W * Cin + Cout * KH * KW * Cin)
     return dw
 
 
@@ -143,7 +149,8 @@ def gconv3x3_fwd(x, wexp, N, H, W, C, stride, in_sc=None, in_sh=None, stats=Fals
     e0 = _prof_begin()
     check(L.koaf_gconv3x3_fwd(_ptr(x), _ptr(wexp), _ptr(y), N, H, W, C, stride, _ptr(in_sc), _ptr(in_sh), _ptr(part),
                               ctypes.addressof(rows), _ptr(shift) if stats else None, _stream()), "gconv3x3_fwd")
-    _prof_end(e0, "gemm", 2.0 * N * OH * OW * C * 9 * (C // 32), f"gconv_fwd s{stride} C{C} px{N*OH*OW}")   # algorithmic (32 groups)
+    _prof_end(e0, "gemm", 2.0 * N * OH * OW * C * 9 * (C // 32), f"gconv_fwd s{stride} C{C} px{N*OH*OW}",   # algorithmic (32 groups)
+              N * H * W * C + N * OH * OW * C + 9 * C * (C // 32))
     return y, part
 
 
@@ -152,7 +159,8 @@ def gconv3x3_dgrad(dy, wexp, N, H, W, C, stride):
     e0 = _prof_begin()
     check(lib().koaf_gconv3x3_dgrad(_ptr(dy), _ptr(wexp), _ptr(dx), N, H, W, C, stride, _stream()), "gconv3x3_dgrad")
     _prof_end(e0, "gemm", 2.0 * N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C * 9 * (C // 32),
-              f"gconv_dgrad s{stride} C{C} px{N*H*W}")
+              f"gconv_dgrad s{stride} C{C} px{N*H*W}",
+              N * H * W * C + N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C + 9 * C * (C // 32))
     return dx
 
 
@@ -165,7 +173,8 @@ def gconv3x3_wgrad(dy, x, N, H, W, C, stride, in_sc=None, in_sh=None):
     check(L.koaf_gconv3x3_wgrad(_ptr(dy), _ptr(x), _ptr(dwexp), N, H, W, C, stride, _ptr(in_sc), _ptr(in_sh),
                                 _ptr(slabs), _stream()), "gconv3x3_wgrad")
     _prof_end(e0, "gemm", 2.0 * N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C * 9 * (C // 32),
-              f"gconv_wgrad s{stride} C{C} px{N*H*W}")
+              f"gconv_wgrad s{stride} C{C} px{N*H*W}",
+              N * H * W * C + N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C + 9 * C * (C // 32))
     return dwexp
 
 
@@ -339,7 +348,8 @@ def linear_fwd(x, w, b, M, N, K, residual=None):
     e0 = _prof_begin()
     check(L.koaf_linear_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(residual), _ptr(y), _ptr(ws), M, N, K, _stream()),
           "linear_fwd")
-    _prof_end(e0, "gemm", 2.0 * M * N * K, f"linear_fwd M{M} N{N} K{K}")
+    _prof_end(e0, "gemm", 2.0 * M * N * K, f"linear_fwd M{M} N{N} K{K}",
+              M * K + N * K + M * N * (2 if residual is not None else 1))
     return y
 
 
@@ -351,7 +361,8 @@ def linear_dgrad(dy, w, M, N, K, residual=None):
     e0 = _prof_begin()
     check(L.koaf_linear_dgrad(_ptr(dy), _ptr(w), _ptr(residual), _ptr(dx), _ptr(ws), M, N, K, _stream()),
           "linear_dgrad")
-    _prof_end(e0, "gemm", 2.0 * M * N * K, f"linear_dgrad M{M} N{N} K{K}")
+    _prof_end(e0, "gemm", 2.0 * M * N * K, f"linear_dgrad M{M} N{N} K{K}",
+              M * N + N * K + M * K * (2 if residual is not None else 1))
     return dx
 
 
@@ -363,7 +374,7 @@ def linear_wgrad(dy, x, dw, db, M, N, K):
         ws = _empty((n,), dy) if n > 0 else None
     e0 = _prof_begin()
     check(L.koaf_linear_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(ws), M, N, K, _stream()), "linear_wgrad")
-    _prof_end(e0, "gemm", 2.0 * M * N * K, f"linear_wgrad M{M} N{N} K{K}")
+    _prof_end(e0, "gemm", 2.0 * M * N * K, f"linear_wgrad M{M} N{N} K{K}", M * N + M * K + N * K)
 
 
 def layernorm_fwd(x, gamma, beta, rows, D, eps):
@@ -389,7 +400,7 @@ def attention_fwd(qkv, B, n, h, d, scale):
     out = _empty((B, n, h * d), qkv)
     e0 = _prof_begin()
     check(lib().koaf_attention_fwd(_ptr(qkv), _ptr(attn), _ptr(out), B, n, h, d, scale, _stream()), "attention_fwd")
-    _prof_end(e0, "gemm", 4.0 * B * h * n * n * d, f"attn_fwd B{B} n{n}")
+    _prof_end(e0, "gemm", 4.0 * B * h * n * n * d, f"attn_fwd B{B} n{n}", B * n * h * d * 4 + B * h * n * n)
     return out, attn
 
 
@@ -399,7 +410,7 @@ def attention_bwd(dout, qkv, attn, B, n, h, d, scale):
     e0 = _prof_begin()
     check(lib().koaf_attention_bwd(_ptr(dout), _ptr(qkv), _ptr(attn), _ptr(dqkv), _ptr(ws), B, n, h, d, scale,
                                    _stream()), "attention_bwd")
-    _prof_end(e0, "gemm", 8.0 * B * h * n * n * d, f"attn_bwd B{B} n{n}")
+    _prof_end(e0, "gemm", 8.0 * B * h * n * n * d, f"attn_bwd B{B} n{n}", B * n * h * d * 7 + B * h * n * n)
     return dqkv
 
 
