@@ -1,0 +1,141 @@
+"""GPU: BASELINE.json's full sizes, where the CPU oracle needs minutes per sample -- checked through properties that do
+not depend on the size (the oracle-compared cases run at reduced sizes in the other files):
+
+ * eval mode, native sizes, batch 8 (BASELINE config 4: XR 350^2 + DESS 160x160x64 + TSE 160x160x32 + T2 160x160x25 + clinical):
+   every sample's logits equal the logits of that sample run alone, and a permuted batch gives the permuted logits --
+   no cross-sample leakage through tile edges, slice folding or the token bookkeeping at the real grid sizes;
+ * train mode, same batch: the step is deterministic (two runs from the same state: bit-identical gradients) and the
+   backward pass is linear in the loss scale (loss x 2 -> every gradient exactly x 2: powers of two commute with every
+   rounding in the path, including the bf16 splits of the gradient contractions);
+ * BASELINE's synthetic tensor shapes (XR 310^2, three MRI of 160 slices x 384^2): sample independence in eval at batch 2,
+   and one train step with activation recompute against the same step without it."""
+import numpy as np
+import pytest
+import torch
+
+import procedural as P
+from common import rel
+
+pytestmark = pytest.mark.gpu
+
+_CACHE = {}
+
+
+def _model(tag, cfg, dev):
+    if tag not in _CACHE:
+        from oaprogressionmmf_amd.config import ConfigDict
+        from oaprogressionmmf_amd.models import dict_models
+        _CACHE.clear()                                   # one full-size model resident at a time
+        torch.cuda.empty_cache()
+        torch.manual_seed(5)
+        _CACHE[tag] = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None).to(dev)
+    return _CACHE[tag]
+
+
+def _inputs(cfg, B, dev, seed, shapes=None):
+    c = dict(cfg, input_size=shapes) if shapes else cfg
+    return [torch.from_numpy(a).to(dev) for a in P.model_inputs(c, B, seed)]
+
+
+def _independence(m, xs, tol):
+    m.eval()
+    B = xs[0].shape[0]
+    with torch.no_grad():
+        full = m(*xs)["main"].reshape(B, -1).clone()
+        singles = torch.cat([m(*[x[i:i + 1] for x in xs])["main"].reshape(1, -1) for i in range(B)])
+        perm = torch.arange(B - 1, -1, -1, device=xs[0].device)
+        rev = m(*[x[perm].contiguous() for x in xs])["main"].reshape(B, -1)
+    assert torch.isfinite(full).all()
+    scale = float(full.abs().max())
+    assert float((full - singles).abs().max()) <= tol * scale, (full, singles)
+    assert float((full - rev[perm]).abs().max()) <= tol * scale
+    assert float((full[0] - full[1]).abs().max()) > 10 * tol * scale, "samples indistinguishable: the check is vacuous"
+
+
+def test_native_batch8_eval_samples_are_independent(dev):
+    cfg = P.cfg_xr1mr3c1(dropout=0.0)
+    _independence(_model("native3", cfg, dev), _inputs(cfg, 8, dev, 1234), 2e-5)
+
+
+def test_native_batch8_train_step_is_deterministic_and_linear_in_the_loss(dev):
+    from oaprogressionmmf_amd.various import dict_losses
+    cfg = P.cfg_xr1mr3c1(dropout=0.0)                    # dropout masks are drawn per call: off for this property
+    m = _model("native3", cfg, dev)
+    xs = _inputs(cfg, 8, dev, 1234)
+    y = torch.from_numpy(P.make_target("target", 8, 1234)).to(dev)
+    loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
+    buf0 = {k: b.detach().clone() for k, b in m.named_buffers()}
+
+    def run(scale):
+        with torch.no_grad():
+            for k, b in m.named_buffers():
+                b.copy_(buf0[k])                        # same BatchNorm state (statistics are summed about the running mean)
+        m.train()
+        m.zero_grad()
+        loss = loss_fn(input=m(*xs)["main"].squeeze(1), target=y.long().squeeze(1))
+        (loss * scale).backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    l1, g1 = run(1.0)
+    l1b, g1b = run(1.0)
+    l2, g2 = run(2.0)
+    assert l1 == l1b == l2 and np.isfinite(l1)
+    assert len(g1) > 600
+    bad = [k for k in g1 if not torch.equal(g1[k], g1b[k])]
+    assert not bad, f"{len(bad)} gradients differ between two identical steps, e.g. {bad[:3]}"
+    bad = [k for k in g1 if not torch.equal(g1[k] * 2.0, g2[k])]
+    assert not bad, f"{len(bad)} gradients are not exactly doubled by a doubled loss, e.g. {bad[:3]}"
+    assert sum(float(g.abs().sum()) for g in g1.values()) > 0
+
+
+SYN_SHAPES = [[310, 310], [384, 384, 160], [384, 384, 160], [384, 384, 160], [16]]
+
+
+def _syn_cfg():
+    return P.cfg_xr1mr3c1(xr=(320, 320), mr1=(320, 320, 160), mr2=(320, 320, 160), mr3=(320, 320, 160), dropout=0.0)
+
+
+def test_baseline_synthetic_shapes_eval_samples_are_independent(dev):
+    cfg = _syn_cfg()
+    _independence(_model("syn3", cfg, dev), _inputs(cfg, 2, dev, 77, SYN_SHAPES), 2e-5)
+
+
+def test_baseline_synthetic_shapes_recompute_matches_stored_activations(dev):
+    from oaprogressionmmf_amd import ops
+    from oaprogressionmmf_amd.models import KoafTrunk
+    from oaprogressionmmf_amd.various import dict_losses
+    cfg = _syn_cfg()
+    m = _model("syn3", cfg, dev)
+    xs = _inputs(cfg, 1, dev, 78, SYN_SHAPES)
+    y = torch.from_numpy(P.make_target("target", 1, 78)).to(dev)
+    loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
+    buf0 = {k: b.detach().clone() for k, b in m.named_buffers()}
+    trunks = [t for t in m.modules() if isinstance(t, KoafTrunk)]
+    assert len(trunks) == 4
+
+    def run(recompute):
+        for t in trunks:
+            t.recompute = recompute
+        with torch.no_grad():
+            for k, b in m.named_buffers():
+                b.copy_(buf0[k])
+        m.train()
+        m.zero_grad()
+        torch.cuda.reset_peak_memory_stats()
+        loss = loss_fn(input=m(*xs)["main"].squeeze(1), target=y.long().squeeze(1))
+        loss.backward()
+        torch.cuda.synchronize()
+        return (float(loss.detach()), torch.cuda.max_memory_allocated(),
+                {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    prev = ops.set_backward_precision(True)              # recomputed activations are the same bits; at full gradient
+    try:                                                 # precision the only difference left is the summation order
+        l0, mem0, g0 = run(False)
+        l1, mem1, g1 = run(True)
+    finally:
+        ops.set_backward_precision(bool(prev))
+        for t in trunks:
+            t.recompute = False
+    assert l0 == l1
+    assert mem1 < 0.6 * mem0, (mem0, mem1)               # the point of recompute at these sizes
+    worst = max(rel(g1[k].cpu().numpy(), g0[k].cpu().numpy()) for k in g0)
+    assert worst < 1e-4, worst
