@@ -148,6 +148,15 @@ struct TileLoader {
     // KM state
     int col, cc, kh_, kw_;
     unsigned cvm;      // column-valid bits
+    // Running decomposition of k.  issue() is called for k0 = kbeg, kbeg + BK, ... in order, so the filter tap of a
+    // k-tile (u_*: wave-uniform) and the source pixel of every k row of a gathered K-major tile (g_*: per unit) are
+    // carried from one call to the next by adds and single carries instead of being re-derived by integer divisions
+    // and 64-bit multiplies -- those were a third of the vector instructions of the weight-gradient kernels.
+    int u_tap, u_coff, u_kh, u_kw;
+    v4i gsx, gsy;
+    v4l goff;
+    int g_cs, g_bs, g_pws, g_phs, g_sxlim, g_sylim;
+    int64_t g_d0, g_d1, g_d2;
 
     __device__ __forceinline__ void init(const KoafOperand& op, int r0, int R, int z1) {
         const int t = threadIdx.x;
@@ -209,6 +218,49 @@ struct TileLoader {
         }
     }
 
+    // Position the running k decomposition at k0 (the only place that divides); call once before the first issue().
+    __device__ __forceinline__ void seek(const KoafOperand& op, int k0) {
+        u_tap = u_coff = u_kh = u_kw = 0;
+        gsx = gsy = (v4i){0, 0, 0, 0};
+        goff = (v4l){0, 0, 0, 0};
+        g_cs = g_bs = g_pws = g_phs = g_sxlim = g_sylim = 0;
+        g_d0 = g_d1 = g_d2 = 0;
+        if constexpr (MODE == M_KC_G1 || MODE == M_KC_G2 || MODE == M_KM_G3) {
+            u_tap = k0 / op.C;
+            u_coff = k0 - u_tap * op.C;
+            u_kh = u_tap / op.KW;
+            u_kw = u_tap - u_kh * op.KW;
+        }
+        if constexpr (MODE == M_KM_G1) {
+            constexpr int CV = ROWS / 4;
+            constexpr int RP = 256 / CV;
+            const int ppi = op.PH * op.PW;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const int k = k0 + (int)threadIdx.x / CV + RP * i;
+                const int n = k / ppi;
+                const int rem = k - n * ppi;
+                const int py = rem / op.PW;
+                const int px = rem - py * op.PW;
+                gsy[i] = py * op.stride - op.pad + kh_;
+                gsx[i] = px * op.stride - op.pad_w + kw_;
+                goff[i] = ((int64_t)(n * op.H + gsy[i]) * op.W + gsx[i]) * op.CS + cc;
+            }
+            // one k-step = BK rows further: BK = a * ppi + b * PW + c  (c < PW, b < PH: single carries below)
+            const int a = BK / ppi, r = BK - a * ppi, b = r / op.PW, c = r - b * op.PW;
+            const int64_t wcs = (int64_t)op.W * op.CS, hwcs = (int64_t)op.H * wcs;
+            g_cs = c * op.stride;
+            g_bs = b * op.stride;
+            g_pws = op.PW * op.stride;
+            g_phs = op.PH * op.stride;
+            g_sxlim = g_pws - op.pad_w + kw_;      // px == PW  <=>  sx == sxlim
+            g_sylim = g_phs - op.pad + kh_;
+            g_d0 = a * hwcs + g_bs * wcs + (int64_t)g_cs * op.CS;
+            g_d1 = (int64_t)op.stride * wcs - (int64_t)g_pws * op.CS;    // px wraps: next pixel row
+            g_d2 = hwcs - g_phs * wcs;                                   // py wraps: next image
+        }
+    }
+
     // Issue the global loads of the k-tile [k0, k0+32): nothing here consumes a loaded value, so the
     // s_waitcnt lands in finish(), after the MFMAs of the tile currently in LDS.
     __device__ __forceinline__ void issue(Slot& s, const KoafOperand& op, const float* ptr, int k0, int kend, int z1) {
@@ -219,14 +271,19 @@ struct TileLoader {
             const bool kok = kk < kend;
             int ch = kk, coff = k0;
             if constexpr (MODE != M_KC) {
-                // a 32-wide k chunk lies inside one filter tap (C % 32 == 0)
-                const int tap = k0 / op.C;
-                coff = k0 - tap * op.C;
+                // a 32-wide k chunk lies inside one filter tap (C % 32 == 0); (tap, coff, kh, kw) of this k0 are carried
+                const int tap = u_tap;
+                coff = u_coff;
                 ch = coff + 4 * (t & 7);
+                const int kh = u_kh, kw = u_kw;
+                u_coff += BK;
+                if (u_coff >= op.C) {
+                    u_coff -= op.C;
+                    ++u_tap;
+                    if (++u_kw == op.KW) { u_kw = 0; ++u_kh; }
+                }
                 if (tap != tap_cur) {          // wave-uniform: new tap -> new source pixel / bounds for every unit
                     tap_cur = tap;
-                    const int kh = tap / op.KW;
-                    const int kw = tap - kh * op.KW;
                     tvm = 0;
 #pragma unroll
                     for (int i = 0; i < NU; ++i) {
@@ -299,8 +356,15 @@ struct TileLoader {
             constexpr int CV = ROWS / 4;
             constexpr int RP = 256 / CV;
             const int kr0 = t / CV;
-            int tap3 = 0, c03 = 0;
-            if constexpr (MODE == M_KM_G3) { tap3 = k0 / op.C; c03 = k0 - tap3 * op.C; }
+            int c03 = 0, th3 = 0, tw3 = 0;
+            if constexpr (MODE == M_KM_G3) {
+                c03 = u_coff; th3 = u_kh; tw3 = u_kw;
+                u_coff += BK;
+                if (u_coff >= op.C) {
+                    u_coff -= op.C;
+                    if (++u_kw == op.KW) { u_kw = 0; ++u_kh; }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 const int k = k0 + kr0 + RP * i;
@@ -310,18 +374,21 @@ struct TileLoader {
                     off = (int64_t)k * op.ld + col;
                 } else if constexpr (MODE == M_KM_G3) {
                     // tapped weights: k = (tap, ck), tap = th*KW + tw; element at ck*ld + th*tap_stride_h + tw*tap_stride + col
-                    const int th3 = tap3 / op.KW, tw3 = tap3 - th3 * op.KW;
                     off = (int64_t)(c03 + kr0 + RP * i) * op.ld + th3 * op.tap_stride_h + tw3 * op.tap_stride + col;
                 } else {
-                    const int ppi = op.PH * op.PW;
-                    const int n = k / ppi;
-                    const int rem = k - n * ppi;
-                    const int py = rem / op.PW;
-                    const int px = rem - py * op.PW;
-                    const int sy = py * op.stride - op.pad + kh_;
-                    const int sx = px * op.stride - op.pad_w + kw_;
+                    const int sy = gsy[i], sx = gsx[i];
                     ok = ok && (unsigned)sy < (unsigned)op.H && (unsigned)sx < (unsigned)op.W;
-                    off = ((int64_t)(n * op.H + sy) * op.W + sx) * op.CS + cc;
+                    off = goff[i];
+                    // advance this unit's source pixel by BK rows of k
+                    int nsx = sx + g_cs;
+                    const bool c1 = nsx >= g_sxlim;
+                    nsx -= c1 ? g_pws : 0;
+                    int nsy = sy + g_bs + (c1 ? op.stride : 0);
+                    const bool c2 = nsy >= g_sylim;
+                    nsy -= c2 ? g_phs : 0;
+                    gsx[i] = nsx;
+                    gsy[i] = nsy;
+                    goff[i] = off + g_d0 + (c1 ? g_d1 : (int64_t)0) + (c2 ? g_d2 : (int64_t)0);
                 }
                 if (VEC) {
                     ok = ok && (cvm & 1u);
@@ -515,6 +582,8 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     TileLoader<BN, BMD, TFB, VEC> lb;
     la.init(p.A, m0, p.M, z1);
     lb.init(p.B, n0, p.N, z1);
+    la.seek(p.A, kbeg);
+    lb.seek(p.B, kbeg);
 
     v16f acc[TM][TN];
 #pragma unroll
