@@ -31,7 +31,7 @@ class Tiny(nn.Module):
         return x
 
 
-def _worker(rank, world, port, overlap, q):
+def _worker(rank, world, port, overlap, q, always=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -39,7 +39,8 @@ def _worker(rank, world, port, overlap, q):
         from oaprogressionmmf_amd.parallel import DataParallelRCCL
         torch.manual_seed(100 + rank)          # ranks start from DIFFERENT weights: broadcast must fix that
         m = Tiny()
-        ddp = DataParallelRCCL(m, bucket_elems=1024, overlap=overlap)
+        ddp = DataParallelRCCL(m, bucket_elems=1024, overlap=overlap, exchange_always=always)
+        assert ddp._active == (world > 1 or always)
         a = ddp.arena()
         ref_w = [p.detach().clone() for p in m.parameters()]
         gathered = [torch.zeros_like(a.P) for _ in range(world)]
@@ -88,6 +89,23 @@ def test_gradient_exchange_gloo_world2(overlap):
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_world_of_one_exchange_rehearsal():
+    """exchange_always=True: a single rank still broadcasts, plans buckets and all-reduces (the 1-GPU RCCL rehearsal mode);
+    without it a world of one does no collective at all (no plan is ever built)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), True, q, True))
+    p.start()
+    rank, msg = q.get(timeout=180)
+    p.join(timeout=60)
+    assert msg == "ok", msg
+    from oaprogressionmmf_amd.parallel import DataParallelRCCL
+    ddp = DataParallelRCCL(Tiny())                 # no process group: plain single process
+    assert ddp.world == 1 and not ddp._active
+    ddp.reduce_gradients()
+    assert ddp._plan is None
 
 
 def test_arena_views_and_adam_ranges():
