@@ -26,15 +26,14 @@ extern "C" {
 #define KOAF_EINVAL (-1)
 #define KOAF_ELAUNCH (-2)
 
-int koaf_version(void);          /* 100 * major + 10 * minor: 110 = this header */
+int koaf_version(void);          /* 100 * major + 10 * minor: 130 = this header */
 const char* koaf_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Generic MFMA GEMM  C[M,N] = alpha * sum_k A(m,k) B(n,k)  (+bias[n]) (+residual[m,n])
  * fp32 in / fp32 out / fp32 accumulate.  Products are formed on the bf16 matrix pipe from exact bf16 pieces of the
- * fp32 operands (v_mfma_f32_32x32x16_bf16): prec 0 = three pieces per operand, every significand bit, error at fp32
- * rounding level; prec 1 = two pieces, operands rounded to 16 significand bits (see KoafGemm.prec).  An Inf operand
- * yields NaN; NaN stays NaN.
+ * fp32 operands (KoafGemm.fmt: three bf16 pieces / six products, or two scaled fp16 pieces / three products): error at
+ * fp32 rounding level either way.  An Inf operand yields NaN; NaN stays NaN.
  * Each operand is either K-contiguous ("KC": element (r,k) at ptr + r*ld + k) or K-major
  * ("KM": element (r,k) at ptr + k*ld + r).  Operands can be gathered on the fly from an NHWC
  * tensor (implicit-GEMM convolution) and transformed on load with relu(sc[c]*x+sh[c]) -- the
@@ -46,7 +45,7 @@ typedef struct KoafOperand {
     int64_t bs0, bs1; /* batch strides (elements) for batch index z = z0*nb1 + z1 */
     int64_t tap_stride;   /* gather 3 (K-major weights [C][taps][rows]): offset between taps in a tap row */
     int64_t tap_stride_h; /* gather 3: offset between tap rows; tap index = th*KW + tw */
-    int32_t kind;     /* 0 = KC, 1 = KM */
+    int32_t kind;     /* 0 = KC, 1 = KM, 2 = pre-split fp16 plane images (B operand only; see `planes`) */
     int32_t gather;   /* 0 none; 1 conv forward gather; 2 transposed-conv (dgrad) gather;
                          3 (KM only) tapped weights: k = (tap, c), element at c*ld + tap*tap_stride + r */
     int32_t H, W, C;  /* source NHWC tensor dims for a gathered operand (C = channels per tap) */
@@ -59,6 +58,21 @@ typedef struct KoafOperand {
     int32_t tf_bs;    /* channel offset of sc/sh per batch index z1 (grouped-conv slabs) */
     const float* sc;
     const float* sh;
+    /* kind 2 (B operand, KoafGemm.fmt 1): `planes` -> plane 0 of the two fp16 plane images (hi, lo) of a K-contiguous matrix
+       scaled by scale(*amax) (cut by koaf_wplanes_build): element (r, k) of plane q at planes + q*plane_stride + r*ld + k,
+       every row zero-filled up to a multiple of 32 k.  All strides (ld, plane_stride, bs0, bs1, tap_stride, tap_stride_h)
+       count 16-bit elements and are multiples of 8.  Tapped addressing as for conv weights: with C > 0 the GEMM's
+       k = (tap, c), tap = th*KW + tw, lives at th*tap_stride_h + tw*tap_stride + c of the row (C % 32 == 0); C == 0: k is
+       the row offset.  The kernel moves these planes global -> LDS directly (global_load_lds): no split arithmetic in
+       the k-loop. */
+    const uint16_t* planes;
+    int64_t plane_stride;
+    /* fp16 scheme (KoafGemm.fmt == 1): the operand is multiplied by a power of two before it is cut into fp16 pieces:
+       amax != NULL: scale(*amax) = 2^e with *amax * 2^e in [2^14, 2^15) (1 for *amax == 0) -- *amax = max |element| of the
+       tensor, written on the device by its producer; amax == NULL: fscale (0 = 1).  Scaled magnitudes are clamped to 65504. */
+    const float* amax;
+    float fscale;
+    int32_t _pad4;
 } KoafOperand;
 
 typedef struct KoafGemm {
@@ -70,11 +84,7 @@ typedef struct KoafGemm {
     float* C;
     int64_t ldc, cbs0, cbs1;
     float alpha;
-    int32_t prec;            /* 0: products carry every fp32 significand bit (3 bf16 planes per operand, forward);
-                              * 1: operands rounded to 16 significand bits (2 planes; products of those exact) --
-                              *    set by the library on data / weight GRADIENT contractions: relative error ~1e-5
-                              *    against the 1e-3 bar, 1.5x fewer matrix instructions.  KOAF_BWD_PRECISION=full
-                              *    in the environment forces 0 everywhere. */
+    int32_t prec;            /* 0: a forward contraction; 1: a data / weight gradient contraction (informational) */
     const float* bias;     /* [N] or NULL */
     const float* residual; /* [M][ldr] (+batch strides) or NULL */
     int64_t ldr, rbs0, rbs1;
@@ -89,7 +99,15 @@ typedef struct KoafGemm {
        dz instead of g, and emits per-M-tile column sums  bnb_part[tile][k][N]:  k=0: sum dz, k=1: sum dz*xhat with
        xhat = (c-mean)*invstd, k=2 (if bnb2_c): sum dz*xhat2 for a second BatchNorm fed by the same dz (the
        downsample branch).  c / y / c2 are laid out like C (same ldc, same row map).  bnb_mode 0 = off. */
-    int32_t bnb_mode, _pad3;
+    int32_t bnb_mode;
+    int32_t fmt;             /* how the fp32 x fp32 products are formed on the matrix pipe:
+                              * 0: three exact bf16 pieces per operand, the six piece products of weight >= 2^-16
+                              *    (v_mfma_f32_32x32x16_bf16): any fp32 operand, no scale information needed;
+                              * 1: two fp16 pieces of operand * 2^e (hi = fp16(x'), lo = fp16(x' - hi): x' = hi + lo to 2^-24
+                              *    relative down to |x'| = 2^-2, 2^-25 absolute below) and the three products hi*hi, hi*lo,
+                              *    lo*hi (v_mfma_f32_32x32x16_f16; each exact in fp32, the dropped lo*lo <= 2^-24 of the
+                              *    product): the same fp32-level accuracy from half the matrix instructions, for operands
+                              *    whose magnitude is known (KoafOperand.amax / fscale).  Needs the vector path. */
     const float* bnb_c;
     const float* bnb_y;
     const float* bnb_sc;
@@ -109,10 +127,6 @@ typedef struct KoafGemm {
     const float* stats_shift;
 } KoafGemm;
 
-/* Precision of the gradient contractions (KoafGemm.prec == 1) for this process: full != 0 -> every significand bit
- * like the forward; 0 -> 16-bit operands (default); negative -> back to the environment (KOAF_BWD_PRECISION=full).
- * Returns the previous setting (1 = full, 0 = 16-bit).  Not a per-stream state: set it between steps. */
-int koaf_set_backward_precision(int32_t full);
 int koaf_gemm(const KoafGemm* g, void* stream);
 /* block tile koaf_gemm picks for (M, N, batch) when bm = bn = 0 */
 int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn);
@@ -126,23 +140,50 @@ int koaf_slab_reduce(const float* slabs, int32_t nslab, int64_t n, float* out, v
 int koaf_slab_reduce_epilogue(const float* slabs, int32_t nslab, int32_t M, int32_t N, const float* bias,
                               const float* residual, int64_t ldr, float* out, int64_t ldo, void* stream);
 
+/* ---- Weight plane images ---------------------------------------------------------------------
+ * Every convolution weight of the model ([Cout][KH*KW][Cin] packed) is cut once per optimizer step into the two fp16
+ * piece planes of w * scale(amax(w)) that the MFMA kernel multiplies (KoafGemm.fmt 1), in two arrangements:
+ *   F image [2][R][Kp]          Kp = taps*C rounded up to 32: B operand of the forward GEMM (rows = output channels)
+ *   D image [2][C][taps*Rp]     Rp = R rounded up to 32: the transposed weight, B operand of the data-gradient GEMM
+ * Two launches handle a whole table of descriptors (device memory): max |w| per weight -> amax[i], then the images.
+ * tile0 = running sum of ceil(R/32) * taps * ceil(C/32) over the preceding entries, `ntiles` the total.  taps > 1 needs
+ * C % 32 == 0.  src_off counts floats from `base`, f_off / d_off 16-bit elements from `planes` (multiples of 8; -1 =
+ * image not wanted). */
+typedef struct KoafWPlane {
+    int64_t src_off, f_off, d_off, tile0;
+    int32_t R, taps, C, Kp, Rp, _pad;
+} KoafWPlane;
+int koaf_wplanes_build(const float* base, uint16_t* planes, float* amax, const KoafWPlane* table_dev, int32_t n,
+                       int64_t ntiles, void* stream);
+/* what the convolution entry points take for a weight whose images are current (all device pointers) */
+typedef struct KoafWImg {
+    const uint16_t* f;      /* F image or NULL */
+    const uint16_t* d;      /* D image or NULL */
+    const float* amax;      /* max |w| the images were scaled by */
+} KoafWImg;
+
 /* ---- Convolution (nn.Conv2d, bias-free; _torchvision.py:23-31) as implicit GEMM on NHWC -------
  * x [N,H,W,Cin], w packed [Cout,KH,KW,Cin] (the memory of a channels_last (Cout,Cin,KH,KW)
  * parameter), y [N,OH,OW,Cout].  in_sc/in_sh (nullable): fused BatchNorm+ReLU of the producer
  * applied to x on load.  stats (nullable): per-M-tile column sums / sums of squares of y for the
  * following BatchNorm (train mode), *stats_rows rows of [2][Cout], summed about stats_shift[Cout] (nullable = 0; pass
- * that BatchNorm's running_mean and hand the same pointer to koaf_bn_finalize).  */
+ * that BatchNorm's running_mean and hand the same pointer to koaf_bn_finalize).  wimg (nullable): plane images of w
+ * (koaf_wplanes_build; they must be current): the contraction then runs on the fp16 scheme (KoafGemm.fmt 1) with the
+ * activations at the fixed scale KOAF_ACT_SCALE and the weight tiles DMA'd from wimg->f (wimg->f NULL: weight split in
+ * the kernel with the same scale -- bit-identical, slower).  */
+#define KOAF_ACT_SCALE 16.0f   /* activations are O(1) behind BatchNorm: |x| * 16 clamps at 65504, 2^-29 absolute resolution */
 int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W,
                     int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                     const float* in_sc, const float* in_sh, float* stats, int32_t* stats_rows,
-                    const float* stats_shift, void* stream);
+                    const float* stats_shift, const KoafWImg* wimg, void* stream);
 /* rows of the stats buffer koaf_conv2d_fwd writes for M output pixels */
 int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout);
 /* dx [N,H,W,Cin] = conv_transpose(dy [N,OH,OW,Cout], w) (+residual: the other branch's gradient);
- * w is read K-major in place (no re-packed copy).  */
+ * w is read K-major in place (no re-packed copy).  With wimg AND dy_amax (device scalar: max |dy|, e.g. from
+ * koaf_bn_bwd_apply) the contraction runs on the fp16 scheme, the weight tiles DMA'd from wimg->d.  */
 int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
                       int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride,
-                      int32_t pad, const float* residual, void* stream);
+                      int32_t pad, const float* residual, const KoafWImg* wimg, const float* dy_amax, void* stream);
 /* Same, with the BatchNorm(+ReLU) backward reduction of the layer that PRODUCED x fused into the epilogue (see
  * KoafGemm.bnb_*): dx receives the masked gradient dz; part [*part_rows][nsum][Cin] (nsum = 2, or 3 with c2) feeds
  * koaf_bn_bwd_finalize.  koaf_conv2d_dgrad_bnb_rows() bounds *part_rows for sizing. */
@@ -162,15 +203,16 @@ int32_t koaf_conv2d_dgrad_bnb_rows(int32_t N, int32_t H, int32_t W, int32_t Cin,
 int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
                           int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                           const float* residual, const KoafBnb* bnb, float* part, int32_t* part_rows,
-                          void* stream);
+                          const KoafWImg* wimg, const float* dy_amax, void* stream);
 /* dw packed [Cout,KH,KW,Cin] = sum_pixels dy^T x, x optionally transformed on load.  Deterministic
- * split-K: slabs = workspace of koaf_conv2d_wgrad_ws() floats (0 = none needed).  */
+ * split-K: slabs = workspace of koaf_conv2d_wgrad_ws() floats (0 = none needed).  dy_amax (nullable): max |dy| on the
+ * device -> fp16 scheme.  */
 int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                              int32_t KH, int32_t KW, int32_t stride, int32_t pad);
 int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int32_t N, int32_t H, int32_t W,
                       int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride,
                       int32_t pad, const float* in_sc, const float* in_sh, float* slabs,
-                      void* stream);
+                      const float* dy_amax, void* stream);
 
 /* ---- Grouped 3x3 convolution (ResNeXt 32x4d; _torchvision.py:110,327-330) -------------------
  * Runs on the same MFMA GEMM as 64-channel block-diagonal slabs: packed weights [C][3][3][C/groups]
@@ -236,13 +278,15 @@ int koaf_bn_bwd_reduce(const float* g, const float* c, const float* ymask, const
                        float* dz_out, float* part, int32_t* part_rows, int64_t rows, int32_t C,
                        void* stream);
 /* part [rows][nsum][C] -> dgamma (= sum index i1), dbeta (= sum index 0), and apply coefficients
- * coef [3][C] = {sc, dbeta/M, sc*invstd*dgamma/M}.  (nsum, i1) = (2, 1) for the plain layout. */
+ * coef [3][C] = {sc, dbeta/M, sc*invstd*dgamma/M}.  (nsum, i1) = (2, 1) for the plain layout.  amax_reset (nullable): a
+ * device scalar set to 0 (the accumulator koaf_bn_bwd_apply raises). */
 int koaf_bn_bwd_finalize(const float* part, int32_t part_rows, int32_t C, int64_t count,
                          const float* sc, const float* invstd, float* dgamma, float* dbeta,
-                         float* coef, int32_t nsum, int32_t i1, double* ws, void* stream);
-/* dc = coef0*(dz - coef1) - coef2*(c - mean) */
+                         float* coef, int32_t nsum, int32_t i1, double* ws, float* amax_reset, void* stream);
+/* dc = coef0*(dz - coef1) - coef2*(c - mean).  amax (nullable): device scalar raised to max |dc| (atomic max; it must be
+ * zero beforehand: hand it to koaf_bn_bwd_finalize as amax_reset) -- the scale of dc as an operand of the fp16 scheme. */
 int koaf_bn_bwd_apply(const float* dz, const float* c, const float* mean, const float* coef,
-                      float* dc, int64_t rows, int32_t C, void* stream);
+                      float* dc, int64_t rows, int32_t C, float* amax, void* stream);
 
 /* ---- input pipeline on the device (koafusion/preproc/_pt.py; applied per sample by the reference's CPU loader
  * workers, koafusion/datasets/_data_provider.py:295-335) ------------------------------------------------------- */

@@ -40,6 +40,11 @@ class KoafOperand(ctypes.Structure):
         ("tf_bs", ctypes.c_int32),
         ("sc", ctypes.c_void_p),
         ("sh", ctypes.c_void_p),
+        ("planes", ctypes.c_void_p),
+        ("plane_stride", ctypes.c_int64),
+        ("amax", ctypes.c_void_p),
+        ("fscale", ctypes.c_float),
+        ("_pad4", ctypes.c_int32),
     ]
 
 
@@ -78,7 +83,7 @@ class KoafGemm(ctypes.Structure):
         ("cm_px", ctypes.c_int32),
         ("_pad2", ctypes.c_int32),
         ("bnb_mode", ctypes.c_int32),
-        ("_pad3", ctypes.c_int32),
+        ("fmt", ctypes.c_int32),
         ("bnb_c", ctypes.c_void_p),
         ("bnb_y", ctypes.c_void_p),
         ("bnb_sc", ctypes.c_void_p),
@@ -111,6 +116,25 @@ class KoafBnb(ctypes.Structure):
     ]
 
 
+class KoafWPlane(ctypes.Structure):
+    _fields_ = [
+        ("src_off", ctypes.c_int64),
+        ("f_off", ctypes.c_int64),
+        ("d_off", ctypes.c_int64),
+        ("tile0", ctypes.c_int64),
+        ("R", ctypes.c_int32),
+        ("taps", ctypes.c_int32),
+        ("C", ctypes.c_int32),
+        ("Kp", ctypes.c_int32),
+        ("Rp", ctypes.c_int32),
+        ("_pad", ctypes.c_int32),
+    ]
+
+
+class KoafWImg(ctypes.Structure):
+    _fields_ = [("f", ctypes.c_void_p), ("d", ctypes.c_void_p), ("amax", ctypes.c_void_p)]
+
+
 _SCALARS = {
     "int": ctypes.c_int,
     "int32_t": ctypes.c_int32,
@@ -128,6 +152,8 @@ def _ctype(decl: str):
             return ctypes.POINTER(KoafGemm)
         if base == "KoafBnb":
             return ctypes.POINTER(KoafBnb)
+        if base == "KoafWImg":
+            return ctypes.POINTER(KoafWImg)
         if base == "char":
             return ctypes.c_char_p
         return ctypes.c_void_p
@@ -140,6 +166,7 @@ def parse_header(path=HEADER):
     text = Path(path).read_text()
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     text = re.sub(r"typedef struct.*?\}\s*\w+;", " ", text, flags=re.S)
+    text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)          # preprocessor lines
     protos = {}
     for m in re.finditer(r"([\w\s\*]+?)\b(koaf_\w+)\s*\(([^)]*)\)\s*;", text):
         ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()

@@ -9,7 +9,15 @@ backward kernels straight into the twin buffer `G`; `p.grad` is a view of it.  O
   * the data-parallel gradient exchange is RCCL all-reduce over contiguous slices of `G` (buckets are
     just offsets; no flatten/unflatten copies),
   * BatchNorm running statistics sit in a third flat buffer so rank-0 broadcast is one collective.
+A fourth buffer `W` holds the fp16 PLANE IMAGES of every convolution weight: the two pieces hi + lo of w * 2^e that the
+MFMA kernel multiplies on its fp16 scheme (koaf.h: KoafGemm.fmt 1), cut once per optimizer step by one pair of launches
+over the whole arena (koaf_wplanes_build: max |w| per weight, then the images) instead of by every block of every GEMM
+for every k-tile; the kernels then move weight tiles global -> LDS directly.  Two arrangements per weight: F [2][Cout][K]
+(forward) and D [2][Cin][taps*Cout] (the transposed weight, data gradient).  `ensure_planes()` rebuilds them when the
+weights changed (own optimizer: epoch counter; anything else that writes parameters in place: tensor version counters).
 """
+import ctypes
+
 import torch
 from torch import nn
 
@@ -72,6 +80,64 @@ class ParamArena:
             b.data = view
         self.grad_dirty = False
         self.ready_hook = None  # set by the data-parallel wrapper: called with (offset, numel)
+        self.epoch = 0          # bumped by the fused optimizer (it writes P through raw pointers)
+        self._plane_stamp = None
+        self._build_plane_table(module)
+
+    # ---- weight plane images ------------------------------------------------------------------------------------
+    def _build_plane_table(self, module):
+        from ._lib import KoafWPlane
+        rup = lambda v, a: (v + a - 1) // a * a
+        ents, off, tile0, seen = [], 0, 0, set()
+        for m in module.modules():
+            if isinstance(m, nn.Conv2d):
+                if m.groups != 1 or m.in_channels % 32 or m.out_channels % 32 or m.weight.dim() != 4:
+                    continue            # (the 3-channel stem and the grouped 3x3 have their own kernels)
+                R, taps, C = m.out_channels, m.kernel_size[0] * m.kernel_size[1], m.in_channels
+            else:
+                continue                # (linear layers stay on the bf16 scheme: their gradient operands carry no scale)
+            w = m.weight
+            if id(w) in seen or id(w) not in self.slots:
+                continue
+            seen.add(id(w))
+            Kp, Rp = rup(taps * C, 32), rup(R, 32)
+            f_off = off
+            off += rup(2 * R * Kp, 64)
+            d_off = off
+            off += rup(2 * C * taps * Rp, 64)
+            ents.append((w, KoafWPlane(src_off=self.slots[id(w)][0], f_off=f_off, d_off=d_off, tile0=tile0, R=R, taps=taps,
+                                       C=C, Kp=Kp, Rp=Rp)))
+            tile0 += ((R + 31) // 32) * taps * ((C + 31) // 32)
+        self._plane_tiles = tile0
+        self._plane_n = len(ents)
+        if not ents:
+            self.W = self._plane_tab = None
+            return
+        self.W = torch.zeros(off, device=self.device, dtype=torch.int16)
+        self.Wamax = torch.zeros(len(ents), device=self.device, dtype=torch.float32)     # max |w| per weight
+        arr = (KoafWPlane * len(ents))(*[e for _, e in ents])
+        self._plane_tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        for i, (w, e) in enumerate(ents):
+            w._koaf_wimg = (self.W[e.f_off:e.f_off + 2 * e.R * e.Kp], self.W[e.d_off:e.d_off + 2 * e.C * e.taps * e.Rp],
+                            self.Wamax[i:i + 1])
+        self._plane_params = [w for w, _ in ents]
+
+    def _stamp(self):
+        return (self.epoch, self.P._version, sum(p._version for p in self._plane_params))
+
+    def ensure_planes(self):
+        """(re)build the weight plane images on the current stream if any weight changed since the last build"""
+        from . import ops
+        if self.W is None or not ops.CONV_F16:
+            return
+        st = self._stamp()
+        if st == self._plane_stamp:
+            return
+        from ._lib import check, lib
+        check(lib().koaf_wplanes_build(self.P.data_ptr(), self.W.data_ptr(), self.Wamax.data_ptr(), self._plane_tab.data_ptr(),
+                                       self._plane_n, self._plane_tiles, torch.cuda.current_stream().cuda_stream),
+              "wplanes_build")
+        self._plane_stamp = st
 
     @staticmethod
     def _view(flat, o, n, p):
@@ -102,13 +168,23 @@ class ParamArena:
 
 
 def get_arena(module: nn.Module) -> ParamArena:
-    """Adopt `module`'s parameters into an arena (once per device placement)."""
+    """Adopt `module`'s parameters into an arena (once per device placement); weight plane images current on return."""
     a = module.__dict__.get("_koaf_arena_obj")
-    if a is not None and a.valid():
-        return a
-    a = ParamArena(module)
-    module.__dict__["_koaf_arena_obj"] = a
+    if a is None or not a.valid():
+        a = ParamArena(module)
+        module.__dict__["_koaf_arena_obj"] = a
+    a.ensure_planes()
     return a
+
+
+def weight_planes(p):
+    """(F, D, amax) plane images of a convolution weight that lives in an arena (kept current by get_arena()), else None"""
+    a = getattr(p, "_koaf_arena", None)
+    from . import ops
+    if a is None or not ops.CONV_F16 or a._plane_stamp is None or a._plane_stamp[:2] != (a.epoch, a.P._version):
+        return None          # never built, or the weights moved on since (the caller falls back to the fp32 weight)
+    img = getattr(p, "_koaf_wimg", None)
+    return img if (img is not None and img[0].device == p.device) else None
 
 
 def is_packed(p):

@@ -10,6 +10,19 @@ inline void zero_gemm(KoafGemm* g) { *g = KoafGemm{}; g->alpha = 1.f; g->nb0 = g
 
 inline int conv_out(int H, int K, int s, int p) { return (H + 2 * p - K) / s + 1; }
 
+inline int64_t rup32(int64_t v) { return (v + 31) / 32 * 32; }
+
+// fp16 scheme with the activations at their fixed scale; B operand = the F plane image [2][R][Kp] of a weight [R][K]
+// (koaf_wplanes_build) when the image is there, else the fp32 weight split in the kernel at the same scale
+inline void set_fimg(KoafGemm* g, const KoafWImg* w, int R, int64_t K) {
+    g->fmt = 1;
+    g->A.fscale = KOAF_ACT_SCALE;
+    g->B.amax = w->amax;
+    if (!w->f) return;
+    g->B.kind = 2; g->B.gather = 0;
+    g->B.planes = w->f; g->B.ld = rup32(K); g->B.plane_stride = (int64_t)R * g->B.ld;
+}
+
 // split-K plan for weight gradients: M x N output, K = pixels.  ~1024 blocks, >= 512 k-rows per split.
 struct WgradPlan { int bm, bn, splitk; };
 inline WgradPlan wgrad_plan(int M, int N, int64_t K, int ctap, int batch) {
@@ -209,7 +222,7 @@ __global__ void __launch_bounds__(256) gconv_compress_kernel(const float* __rest
 extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W, int32_t Cin,
                                int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, const float* in_sc,
                                const float* in_sh, float* stats, int32_t* stats_rows, const float* stats_shift,
-                               void* stream) {
+                               const KoafWImg* wimg, void* stream) {
     KOAF_REQUIRE(x && w && y && N > 0 && Cin % 32 == 0 && Cout % 4 == 0, "koaf_conv2d_fwd: bad args (Cin=%d Cout=%d)",
                  Cin, Cout);
     KOAF_REQUIRE((in_sc == nullptr) == (in_sh == nullptr), "koaf_conv2d_fwd: in_sc/in_sh come together");
@@ -234,6 +247,7 @@ extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t
     g.B.kind = 0;
     g.B.ld = (int64_t)KH * KW * Cin;
     g.M = (int)M; g.N = Cout; g.K = KH * KW * Cin;
+    if (wimg && wimg->amax) set_fimg(&g, wimg, Cout, g.K);
     g.C = y; g.ldc = Cout;
     g.stats = stats;
     g.stats_shift = stats ? stats_shift : nullptr;
@@ -267,8 +281,14 @@ extern "C" int32_t koaf_conv2d_dgrad_bnb_rows(int32_t N, int32_t H, int32_t W, i
 extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
                                      int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                                      const float* residual, const KoafBnb* bnb, float* part, int32_t* part_rows,
-                                     void* stream) {
+                                     const KoafWImg* wimg, const float* dy_amax, void* stream) {
     KOAF_REQUIRE(dy && w && dx && N > 0 && Cout % 32 == 0 && Cin % 4 == 0, "koaf_conv2d_dgrad: bad args");
+    // fp16 scheme when both operands' magnitudes are known; the weight tiles then come from the D image [2][Cin][KH*KW*Cout]
+    // (rows = input channels, k = (tap, output channel): the k order of the gathered dy) if it is there
+    const bool f16 = wimg && wimg->amax && dy_amax;
+    const bool ps = f16 && wimg->d != nullptr;
+    const uint16_t* w_dimg = ps ? wimg->d : nullptr;
+    const int64_t dld = (int64_t)KH * KW * Cout, dps = (int64_t)Cin * dld;
     KOAF_REQUIRE(!bnb || (part && part_rows), "koaf_conv2d_dgrad_bnb: part / part_rows required");
     const int nsum = (bnb && bnb->c2) ? 3 : 2;
     int rows_done = 0;
@@ -289,7 +309,8 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
                 const int nkh = khs < KH ? (KH - khs + 1) / 2 : 0, nkw = kws < KW ? (KW - kws + 1) / 2 : 0;
                 const int offy = (py + pad - khs) / 2, offx = (px + pad - kws) / 2;
                 zero_gemm(&g);
-                g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
+                g.prec = 1;
+                if (f16) { g.fmt = 1; g.A.amax = dy_amax; g.B.amax = wimg->amax; }
                 g.A.ptr = dy; g.A.kind = 0; g.A.gather = 2;
                 g.A.H = OH; g.A.W = OW; g.A.C = Cout; g.A.CS = Cout;
                 g.A.PH = Hc; g.A.PW = Wc;
@@ -297,6 +318,11 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
                 g.B.ptr = w + ((int64_t)khs * KW + kws) * Cin; g.B.kind = 1; g.B.gather = 3;
                 g.B.C = Cout; g.B.ld = (int64_t)KH * KW * Cin;
                 g.B.KW = g.A.KW; g.B.tap_stride = 2ll * Cin; g.B.tap_stride_h = 2ll * KW * Cin;
+                if (ps) {   // the class's tap subset of the D image: taps (khs + 2i, kws + 2j)
+                    g.B.kind = 2; g.B.gather = 0;
+                    g.B.planes = w_dimg + ((int64_t)khs * KW + kws) * Cout; g.B.ld = dld; g.B.plane_stride = dps;
+                    g.B.tap_stride = 2ll * Cout; g.B.tap_stride_h = 2ll * KW * Cout;
+                }
                 g.M = N * Hc * Wc; g.N = Cin; g.K = nkh * nkw * Cout;
                 g.C = dx; g.ldc = Cin;
                 g.residual = residual; g.ldr = Cin;
@@ -312,7 +338,8 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
         return KOAF_OK;
     }
     zero_gemm(&g);
-    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
+    g.prec = 1;
+    if (f16) { g.fmt = 1; g.A.amax = dy_amax; g.B.amax = wimg->amax; }
     g.A.ptr = dy;
     g.A.kind = 0;
     g.B.ptr = w;
@@ -334,6 +361,10 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
         g.B.tap_stride = Cin;
         g.B.tap_stride_h = (int64_t)KW * Cin;
     }
+    if (ps) {   // all taps in order: k is simply the row offset of the D image
+        g.B.kind = 2; g.B.gather = 0; g.B.C = 0; g.B.tap_stride = g.B.tap_stride_h = 0;
+        g.B.planes = w_dimg; g.B.ld = dld; g.B.plane_stride = dps;
+    }
     g.M = (int)M; g.N = Cin; g.K = KH * KW * Cout;
     g.C = dx; g.ldc = Cin;
     g.residual = residual; g.ldr = Cin;
@@ -346,9 +377,9 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
 
 extern "C" int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
                                  int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
-                                 const float* residual, void* stream) {
+                                 const float* residual, const KoafWImg* wimg, const float* dy_amax, void* stream) {
     return koaf_conv2d_dgrad_bnb(dy, w, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, residual, nullptr, nullptr,
-                                 nullptr, stream);
+                                 nullptr, wimg, dy_amax, stream);
 }
 
 extern "C" int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH,
@@ -360,7 +391,8 @@ extern "C" int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t
 
 extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int32_t N, int32_t H, int32_t W,
                                  int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
-                                 const float* in_sc, const float* in_sh, float* slabs, void* stream) {
+                                 const float* in_sc, const float* in_sh, float* slabs, const float* dy_amax,
+                                 void* stream) {
     KOAF_REQUIRE(dy && x && dw && N > 0 && Cin % 64 == 0 && Cout % 4 == 0, "koaf_conv2d_wgrad: bad args");
     KOAF_REQUIRE((in_sc == nullptr) == (in_sh == nullptr), "koaf_conv2d_wgrad: in_sc/in_sh come together");
     const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
@@ -371,7 +403,8 @@ extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int
     KOAF_REQUIRE(p.splitk == 1 || slabs, "koaf_conv2d_wgrad: workspace required");
     KoafGemm g;
     zero_gemm(&g);
-    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
+    g.prec = 1;
+    if (dy_amax) { g.fmt = 1; g.A.amax = dy_amax; g.B.fscale = KOAF_ACT_SCALE; }   // fp16 scheme: dy at its own scale, x fixed
     g.A.ptr = dy; g.A.kind = 1; g.A.ld = Cout;
     g.B.ptr = x; g.B.kind = 1;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {
@@ -442,7 +475,7 @@ extern "C" int koaf_gconv3x3_dgrad(const float* dy, const float* wexp, float* dx
     KOAF_REQUIRE(M < (1ll << 31), "koaf_gconv3x3_dgrad: too many pixels");
     KoafGemm g;
     zero_gemm(&g);
-    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
+    g.prec = 1;
     g.nb1 = C / 64;
     g.A.ptr = dy; g.A.kind = 0; g.A.gather = 2; g.A.bs1 = 64;
     g.A.H = OH; g.A.W = OW; g.A.C = 64; g.A.CS = C; g.A.PH = H; g.A.PW = W;
@@ -476,7 +509,7 @@ extern "C" int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp
         // one launch: the C/64 slabs are the batch dimension (split-K slabs laid out [slab][split][64][576])
         KoafGemm g;
         zero_gemm(&g);
-        g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
+        g.prec = 1;
         g.A.ptr = dy; g.A.kind = 1; g.A.ld = C; g.A.bs1 = 64;
         g.B.ptr = x; g.B.kind = 1; g.B.gather = 1; g.B.bs1 = 64;
         g.B.H = H; g.B.W = W; g.B.C = 64; g.B.CS = C; g.B.PH = OH; g.B.PW = OW;
@@ -641,7 +674,7 @@ extern "C" int koaf_linear_dgrad(const float* dy, const float* w, const float* r
     }
     KoafGemm g;
     zero_gemm(&g);
-    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
+    g.prec = 1;
     g.A.ptr = dy; g.A.kind = 0; g.A.ld = N;
     g.B.ptr = w; g.B.kind = 1; g.B.ld = K;  // element (r = k_in, kk = n_out) at w + n_out*K + k_in
     g.M = M; g.N = K; g.K = N;
@@ -669,7 +702,7 @@ extern "C" int koaf_linear_wgrad(const float* dy, const float* x, float* dw, flo
     }
     KoafGemm g;
     zero_gemm(&g);
-    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
+    g.prec = 1;
     g.A.ptr = dy; g.A.kind = 1; g.A.ld = N;
     g.B.ptr = x; g.B.kind = 1; g.B.ld = K;
     g.M = N; g.N = K; g.K = M;
@@ -719,7 +752,7 @@ extern "C" int koaf_attention_bwd(const float* dout, const float* qkv, const flo
     int rc;
     // dV[j,dd] = sum_i P[i,j] dO[i,dd]
     zero_gemm(&g);
-    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
+    g.prec = 1;
     g.nb0 = B; g.nb1 = h; g.bm = 64; g.bn = 64;
     g.A.ptr = attn; g.A.kind = 1; g.A.ld = n; g.A.bs0 = pb0; g.A.bs1 = pb1;
     g.B.ptr = dout; g.B.kind = 1; g.B.ld = hd; g.B.bs0 = n * hd; g.B.bs1 = d;
@@ -728,7 +761,7 @@ extern "C" int koaf_attention_bwd(const float* dout, const float* qkv, const flo
     if ((rc = koaf_gemm(&g, stream)) != KOAF_OK) return rc;
     // dP[i,j] = sum_dd dO[i,dd] V[j,dd]
     zero_gemm(&g);
-    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
+    g.prec = 1;
     g.nb0 = B; g.nb1 = h; g.bm = 64; g.bn = 64;
     g.A.ptr = dout; g.A.kind = 0; g.A.ld = hd; g.A.bs0 = n * hd; g.A.bs1 = d;
     g.B.ptr = qkv + 2 * hd; g.B.kind = 0; g.B.ld = ld; g.B.bs0 = n * ld; g.B.bs1 = d;
@@ -739,7 +772,7 @@ extern "C" int koaf_attention_bwd(const float* dout, const float* qkv, const flo
     if ((rc = koaf_softmax_bwd_rows(ws, attn, (int64_t)B * h * n, n, scale, stream)) != KOAF_OK) return rc;
     // dQ[i,dd] = sum_j dS[i,j] K[j,dd]
     zero_gemm(&g);
-    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
+    g.prec = 1;
     g.nb0 = B; g.nb1 = h; g.bm = 64; g.bn = 64;
     g.A.ptr = ws; g.A.kind = 0; g.A.ld = n; g.A.bs0 = pb0; g.A.bs1 = pb1;
     g.B.ptr = qkv + hd; g.B.kind = 1; g.B.ld = ld; g.B.bs0 = n * ld; g.B.bs1 = d;
@@ -748,7 +781,7 @@ extern "C" int koaf_attention_bwd(const float* dout, const float* qkv, const flo
     if ((rc = koaf_gemm(&g, stream)) != KOAF_OK) return rc;
     // dK[j,dd] = sum_i dS[i,j] Q[i,dd]
     zero_gemm(&g);
-    g.prec = 1;   // gradient contraction: 16-bit-significand operands (KoafGemm.prec)
+    g.prec = 1;
     g.nb0 = B; g.nb1 = h; g.bm = 64; g.bn = 64;
     g.A.ptr = ws; g.A.kind = 1; g.A.ld = n; g.A.bs0 = pb0; g.A.bs1 = pb1;
     g.B.ptr = qkv; g.B.kind = 1; g.B.ld = ld; g.B.bs0 = n * ld; g.B.bs1 = d;

@@ -16,7 +16,7 @@ void koaf_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* koaf_last_error(void) { return g_err; }
-extern "C" int koaf_version(void) { return 110; }   // 1.1: KoafGemm.prec, bn *_ws arguments, input-pipeline entry points
+extern "C" int koaf_version(void) { return 130; }   // 1.3: fp16 contraction scheme (KoafGemm.fmt, KoafOperand.amax), weight plane images (KoafWImg)
 
 namespace {
 
@@ -281,8 +281,10 @@ template <typename T>
 __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const T* __restrict__ part, int rows, int C,
                                                                double inv_count, const float* __restrict__ sc,
                                                                const float* __restrict__ invstd, float* dgamma,
-                                                               float* dbeta, float* coef, int nsum, int i1) {
+                                                               float* dbeta, float* coef, int nsum, int i1,
+                                                               float* amax_reset) {
     __shared__ double red[2][16][64];
+    if (amax_reset && blockIdx.x == 0 && threadIdx.x == 0) *amax_reset = 0.f;   // the accumulator bn_bwd_apply raises
     const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     double a = 0.0, b = 0.0;
@@ -308,15 +310,24 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const T* __restri
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ c,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ coef, float* __restrict__ dc,
-                                                           int64_t nvec, int C) {
+                                                           int64_t nvec, int C, float* __restrict__ amax) {
     const int C4 = C / 4;
+    float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * EB) {
         const int cv = (int)(i % C4) * 4;
         v4f z = *(const v4f*)&dz[i * 4];
         v4f x = *(const v4f*)&c[i * 4];
         v4f k0 = *(const v4f*)&coef[cv], k1 = *(const v4f*)&coef[C + cv], k2 = *(const v4f*)&coef[2 * C + cv];
         v4f mu = *(const v4f*)&mean[cv];
-        *(v4f*)&dc[i * 4] = k0 * (z - k1) - k2 * (x - mu);
+        const v4f o = k0 * (z - k1) - k2 * (x - mu);
+        *(v4f*)&dc[i * 4] = o;
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    }
+    if (amax) {
+        // max |dc| of the tensor: the scale of dc as an operand of the fp16 contraction scheme (float bits of non-negative
+        // values order like unsigned integers; a NaN lands above every finite value and poisons the scale on purpose)
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(m));
     }
 }
 
@@ -921,23 +932,23 @@ extern "C" int koaf_bn_bwd_reduce(const float* g, const float* c, const float* y
 }
 extern "C" int koaf_bn_bwd_finalize(const float* part, int32_t part_rows, int32_t C, int64_t count, const float* sc,
                                     const float* invstd, float* dgamma, float* dbeta, float* coef, int32_t nsum,
-                                    int32_t i1, double* ws, void* stream) {
+                                    int32_t i1, double* ws, float* amax_reset, void* stream) {
     KOAF_REQUIRE(part && part_rows > 0 && C > 0 && count > 0 && sc && invstd && coef, "koaf_bn_bwd_finalize: bad args");
     KOAF_REQUIRE(nsum >= 2 && i1 >= 1 && i1 < nsum, "koaf_bn_bwd_finalize: bad (nsum, i1)");
     const int S = part_reduce(part, part_rows, C, nsum, i1, ws, STREAM);
     if (S)
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, ws, S, C,
-                           1.0 / (double)count, sc, invstd, dgamma, dbeta, coef, 2, 1);
+                           1.0 / (double)count, sc, invstd, dgamma, dbeta, coef, 2, 1, amax_reset);
     else
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, part, part_rows, C,
-                           1.0 / (double)count, sc, invstd, dgamma, dbeta, coef, nsum, i1);
+                           1.0 / (double)count, sc, invstd, dgamma, dbeta, coef, nsum, i1, amax_reset);
     return koaf_check_launch("koaf_bn_bwd_finalize");
 }
 extern "C" int koaf_bn_bwd_apply(const float* dz, const float* c, const float* mean, const float* coef, float* dc,
-                                 int64_t rows, int32_t C, void* stream) {
+                                 int64_t rows, int32_t C, float* amax, void* stream) {
     KOAF_REQUIRE(dz && c && mean && coef && dc && rows > 0 && C % 4 == 0, "koaf_bn_bwd_apply: bad args");
     const int64_t nvec = rows * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, dz, c, mean, coef, dc, nvec, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, dz, c, mean, coef, dc, nvec, C, amax);
     return koaf_check_launch("koaf_bn_bwd_apply");
 }
 

@@ -2,79 +2,50 @@
 // implicit-GEMM conv forward / dgrad / wgrad (NHWC), nn.Linear forward / dgrad / wgrad and the
 // attention contractions.  fp32 in, fp32 out, fp32 accumulate.
 //
-// Arithmetic ("split3", KOAF_SPLIT3 == 2, the shipped mode): gfx950 has no TF32-class matrix mode and its fp32
-// MFMA runs at 1/16 of the bf16 rate, so the fp32 x fp32 products go through the bf16 matrix pipe without losing
-// bits: every operand value is cut by truncation into three bf16 pieces hi + mid + lo that together hold all 24
-// significand bits (exact), and of the nine piece products the six of relative weight >= 2^-16
-// (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) are issued as v_mfma_f32_32x32x16_bf16 (each product exact,
-// fp32 accumulate); the three dropped ones are < 2^-21 of the product (2^-24 typically), i.e. at fp32 rounding level.  Measured
-// against float64 the result is as accurate as the fp32-MFMA path (KOAF_SPLIT3 == 0, kept for comparison) and
-// rocBLAS sgemm (scripts/gemm_accuracy.py).  Six 8-pass MFMAs replace eight 16-pass fp32 MFMAs per 16 k: the
-// matrix-pipe bound rises from 157 to 2500/6 = 417 TFLOP/s fp32-equivalent.  Inf operands become NaN (inf - inf
-// in the split); NaN stays NaN.  Gradient contractions (KoafGemm.prec == 1, template NPL = 2) keep two pieces -- hi by
-// truncation, mid = the remainder rounded to nearest, i.e. the operand rounded to 16 significand bits -- and issue all
-// four piece products: ~7e-6 relative error, four MFMAs instead of six, two LDS planes.
+// Arithmetic: gfx950 has no TF32-class matrix mode and its fp32 MFMA runs at 1/16 of the bf16 rate, so the fp32 x fp32
+// products are formed on the 16-bit matrix pipe from exact pieces of the operands, fp32 accumulate.  Two schemes
+// (KoafGemm.fmt), both at fp32 rounding level against float64 (scripts/gemm_accuracy.py, tests/test_kernels_gpu.py):
+//   fmt 0 "bf16 x 3": every operand value is cut by truncation into three bf16 pieces hi + mid + lo that together hold
+//       all 24 significand bits; of the nine piece products the six of relative weight >= 2^-16 are issued as
+//       v_mfma_f32_32x32x16_bf16 (each exact in fp32); the three dropped ones are < 2^-21 of the product.  Works for any
+//       fp32 operand (bf16 has fp32's exponent range): linear layers, attention, anything without scale information.
+//       Six 8-pass MFMAs replace eight 16-pass fp32 MFMAs per 16 k: matrix-pipe bound 2500 / 6 = 417 TFLOP/s.
+//   fmt 1 "fp16 x 2": the operand is multiplied by a power of two that puts its largest magnitude near 2^14 (the
+//       producer of the tensor leaves max |x| in device memory: KoafOperand.amax; activations behind BatchNorm use a
+//       fixed factor) and cut into hi = fp16(x'), lo = fp16(x' - hi), round-to-nearest: x' = hi + lo to 2^-24 relative
+//       (lo is signed: 22 explicit bits + sign) down to |x'| = 2^-2 and to 2^-25 ABSOLUTE below (fp16 subnormals, which
+//       the MFMA does not flush), i.e. <= 2^-40 of the tensor's largest magnitude.  Three products hi*hi, hi*lo, lo*hi on
+//       v_mfma_f32_32x32x16_f16 (11 x 11 bits: exact in fp32); the dropped lo*lo is <= 2^-24 of the product.  Half the
+//       matrix instructions of fmt 0 for the same accuracy -- this is what the convolutions (97 % of the FLOPs) run:
+//       the bf16 scheme sits at the chip's power limit (the clock falls under six MFMAs per product), so fewer matrix
+//       instructions per product is the lever.  Bound 2500 / 3 = 833 TFLOP/s.
+//   Inf operands become NaN (inf - inf in the split); NaN stays NaN.
 //
 // Block = 256 threads = 4 waves (2x2), block tile BM x BN x 32, wave tile (BM/2) x (BN/2) built from 32x32 MFMA
 // tiles; 2 blocks per CU.  Operand tiles are staged global -> registers (fused BN+ReLU prologue, zero fill) ->
 // split -> LDS; the next tile's global loads are in flight under the current tile's MFMAs.  LDS holds three
-// packed-bf16 plane images per operand (see plane_dwords()):
+// (fmt 1: two) packed 16-bit plane images per operand (see plane_dwords()):
 //   K-contiguous operand ("KC"): plane[row][32 k + 8 pad] -- ds_write_b64, fragments by ds_read_b128
 //       (80-B rows: the 16 lanes of a b128 group hit 16 distinct 4-bank slots).
 //   K-major operand ("KM"):      plane[k][ROWS + 32 pad]  -- ds_write_b64 of 4 rows, fragments by the transposing
 //       ds_read_b64_tr_b16 (k-row stride = 16 mod 64 dwords: conflict-free).
 // Both present the same k order to the MFMA (lane (r, h), element e: k = 16g + 8h + e), so any pairing of KC / KM
 // operands works.  Accumulators live in VGPRs (built with -mllvm -amdgpu-mfma-vgpr-form, see the Makefile).
+//   Pre-split operand ("PS", conv weights, fmt 1): the two planes are cut ONCE per optimizer step by koaf_wplanes_build into
+//       fp16 plane images [plane][row][K] in HBM; the kernel moves them global -> LDS with global_load_lds_dwordx4 (no
+//       VGPR staging, no split arithmetic in the k-loop) into a linear [row][32 k] image whose 16-B chunks are
+//       XOR-swizzled (chunk ^ (row / 4 % 4), applied to the per-lane SOURCE address and to the ds_read_b128 address):
+//       LDS-DMA writes are lane-linear, so rows cannot be padded, and the swizzle keeps the fragment reads conflict-free.
+//       Double-buffered: the DMA of k-tile t+1 lands while tile t is multiplied.
 #include "koaf_common.h"
 
 namespace {
 
 constexpr int BK = 32;
-[[maybe_unused]] constexpr int LDK = BK + 4;   // fp32 LDS row of the KOAF_SPLIT3 < 2 builds
-#ifndef KOAF_DB_ALL
-#define KOAF_DB_ALL 0
-#endif
-#ifndef KOAF_ISSUE_AT
-#define KOAF_ISSUE_AT 0   // 0: next tile's loads go out at the top of the k-step (longest flight time);
-#endif                    // 1: between the MFMA groups
-
-#ifndef KOAF_DB_BWD
-#define KOAF_DB_BWD 0     // 1: LDS double buffer for the two-plane (gradient) kernels (80 KB at 128x128): measured mixed (+8 % / -15 %), off
-#endif
-#ifndef KOAF_BWD_TERMS
-#define KOAF_BWD_TERMS 4
-#endif
-#ifndef KOAF_XCD_SWIZZLE
-#define KOAF_XCD_SWIZZLE 1
-#endif
-#ifndef KOAF_PIN_ACC
-#define KOAF_PIN_ACC 0
-#endif
-#ifndef KOAF_SPLIT3
-#define KOAF_SPLIT3 2
-#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 
-// eight fp32 values (x0 = k-slots 0..3, x1 = k-slots 4..7) -> three packed bf16x8 planes (hi, mid, lo) with
-// x = hi + mid + lo exactly: truncation keeps the top 8 significand bits of the running remainder each time
-__device__ __forceinline__ void split3(const v4f x0, const v4f x1, v4i out[3]) {
-    float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-    float r1[8], r2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        r1[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & 0xffff0000u);
-        r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & 0xffff0000u);
-    }
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        out[0][d] = (int)__builtin_amdgcn_perm(__float_as_uint(x[2 * d + 1]), __float_as_uint(x[2 * d]), 0x07060302u);
-        out[1][d] = (int)__builtin_amdgcn_perm(__float_as_uint(r1[2 * d + 1]), __float_as_uint(r1[2 * d]), 0x07060302u);
-        out[2][d] = (int)__builtin_amdgcn_perm(__float_as_uint(r2[2 * d + 1]), __float_as_uint(r2[2 * d]), 0x07060302u);
-    }
-}
-
-// KOAF_SPLIT3 == 2: the split runs once per element in the loader and LDS holds three packed-bf16 plane images
+// The split runs once per element in the loader and LDS holds three packed-bf16 plane images
 // per operand:  KC operand  plane[row][32 k + 8 pad]   (80-B rows: ds_read_b128 fragments, conflict-free)
 //               KM operand  plane[k][ROWS + 32 pad]    (ds_write_b64 of 4 rows, fragments by the transposing
 //                                                       ds_read_b64_tr_b16; k-row stride = 16 (mod 64) dwords)
@@ -82,20 +53,6 @@ __device__ __forceinline__ void split3(const v4f x0, const v4f x1, v4i out[3]) {
 __host__ __device__ constexpr int plane_dwords(int rows, bool kc) { return kc ? rows * 20 : 32 * (rows / 2 + 16); }
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-// four fp32 values -> two (hi, mid) pairs of dwords holding 4 packed bf16 each: hi by truncation (so x - hi is exact),
-// mid = the remainder rounded to nearest bf16.  hi + mid carries (at least) 16 significand bits of x: error <= 2^-16 |x|, zero mean.
-__device__ __forceinline__ void split2v(const v4f x, unsigned out[2][2]) {
-    float r1[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r1[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & 0xffff0000u);
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-        out[0][d] = __builtin_amdgcn_perm(__float_as_uint(x[2 * d + 1]), __float_as_uint(x[2 * d]), 0x07060302u);
-        const bf16x2 m = {(__bf16)r1[2 * d], (__bf16)r1[2 * d + 1]};
-        out[1][d] = __builtin_bit_cast(unsigned, m);
-    }
-}
 
 // four fp32 values -> three (hi, mid, lo) pairs of dwords holding 4 packed bf16 each
 __device__ __forceinline__ void split3v(const v4f x, unsigned out[3][2]) {
@@ -113,6 +70,37 @@ __device__ __forceinline__ void split3v(const v4f x, unsigned out[3][2]) {
     }
 }
 
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+// power of two that brings a tensor whose largest magnitude is amax to [2^14, 2^15) (1 for amax == 0); koaf_wplanes_build
+// and the GEMM kernel both derive an operand's scale from the same device scalar with this function
+__device__ __forceinline__ float scale_of_amax(float amax) {
+    if (!(amax > 0.f)) return 1.f;
+    const int e = min(max(__builtin_amdgcn_frexp_expf(amax), -100), 100);   // amax = m * 2^e, m in [0.5, 1)
+    return __builtin_ldexpf(1.f, 15 - e);
+}
+__device__ __forceinline__ float operand_scale(const KoafOperand& o) {
+    return o.amax ? scale_of_amax(*o.amax) : (o.fscale != 0.f ? o.fscale : 1.f);
+}
+
+// four fp32 values -> (hi, lo) pairs of dwords holding 4 packed fp16 each, of x * scale (scale = a power of two chosen so
+// that the operand's largest magnitude sits near 2^14; values are clamped to the fp16 range): hi = fp16(x'), lo =
+// fp16(x' - hi), both round-to-nearest, so x' = hi + lo to 2^-24 relative (lo carries a sign) down to |x'| = 2^-2 and to
+// 2^-25 absolute below that (fp16 subnormal spacing 2^-24).
+__device__ __forceinline__ void split2h(const v4f x, float scale, unsigned out[2][2]) {
+    float xs[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xs[e] = __builtin_amdgcn_fmed3f(x[e] * scale, -65504.f, 65504.f);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const h16x2 hv = {(_Float16)xs[2 * d], (_Float16)xs[2 * d + 1]};
+        const h16x2 lv = {(_Float16)(xs[2 * d] - (float)hv[0]), (_Float16)(xs[2 * d + 1] - (float)hv[1])};
+        out[0][d] = __builtin_bit_cast(unsigned, hv);
+        out[1][d] = __builtin_bit_cast(unsigned, lv);
+    }
+}
+
 // operand access modes (compile-time: the loaders are straight-line code, so hipcc can schedule their
 // address arithmetic into the shadows of the MFMAs)
 enum { M_KC = 0,     // K-contiguous rows, dense
@@ -120,7 +108,8 @@ enum { M_KC = 0,     // K-contiguous rows, dense
        M_KC_G2 = 2,  // K-contiguous, transposed-conv (dgrad) gather
        M_KM = 3,     // K-major, dense
        M_KM_G1 = 4,  // K-major, conv gather on the k index (wgrad activations)
-       M_KM_G3 = 5   // K-major, tapped weights (dgrad)
+       M_KM_G3 = 5,  // K-major, tapped weights (dgrad)
+       M_PS = 6      // pre-split bf16 plane images, K-contiguous rows, optionally tapped (weights: forward and dgrad)
 };
 __host__ __device__ constexpr bool mode_is_kc(int m) { return m < 3; }
 
@@ -129,7 +118,7 @@ struct TileLoader {
     static constexpr int NU = ROWS / 32;
     static constexpr bool KC = mode_is_kc(MODE);
     // registers of one k-tile in flight; two slots so that the tile after next can be on its way while the next one
-    // is transformed and split under the current tile's MFMAs (KOAF_SPLIT3 == 3)
+    // registers of one k-tile in flight
     struct Slot {
         v4f r[NU];
         unsigned vm;   // validity bits: VEC 1 bit / unit, else 4 bits / unit
@@ -433,36 +422,20 @@ struct TileLoader {
         }
     }
 
-#if KOAF_SPLIT3 >= 2
-    template <int NPL>
-    __device__ __forceinline__ void store(const Slot& s, float* Sf) const {
+    template <int NPL, bool F16>
+    __device__ __forceinline__ void store(const Slot& s, float* Sf, float scale) const {
         unsigned* S = (unsigned*)Sf;
         constexpr int P = plane_dwords(ROWS, KC);
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             unsigned pl[NPL][2];
-            if constexpr (NPL == 3) split3v(s.r[i], pl); else split2v(s.r[i], pl);
+            if constexpr (F16) split2h(s.r[i], scale, pl);
+            else split3v(s.r[i], pl);
             const int off = plane_off(i);
 #pragma unroll
             for (int q = 0; q < NPL; ++q) *(uint2*)&S[q * P + off] = make_uint2(pl[q][0], pl[q][1]);
         }
     }
-#else
-    template <int NPL>
-    __device__ __forceinline__ void store(const Slot& s, float* S) const {
-        const int t = threadIdx.x;
-        if constexpr (KC) {
-            const int kv = t & 7;
-#pragma unroll
-            for (int i = 0; i < NU; ++i) *(v4f*)&S[((t >> 3) + 32 * i) * LDK + 4 * kv] = s.r[i];
-        } else {
-            constexpr int CV = ROWS / 4;
-            constexpr int RP = 256 / CV;
-#pragma unroll
-            for (int i = 0; i < NU; ++i) *(v4f*)&S[(t / CV + RP * i) * ROWS + 4 * (t % CV)] = s.r[i];
-        }
-    }
-#endif
 };
 
 typedef short v4s __attribute__((ext_vector_type(4)));
@@ -484,6 +457,62 @@ __device__ __forceinline__ v4i frag_load(const unsigned* P, int row0, int g, int
         const v2i l2 = __builtin_bit_cast(v2i, lo), h2 = __builtin_bit_cast(v2i, hi);
         return (v4i){l2[0], l2[1], h2[0], h2[1]};
     }
+}
+
+// Pre-split operand (M_PS): bf16 plane images [plane][row][K] cut in HBM by koaf_wplanes_build, moved global -> LDS by
+// global_load_lds_dwordx4.  One wave instruction fills 1 KiB = 16 rows x 64 B of one plane; the LDS image is linear
+// (DMA writes land at wave base + 16 * lane), so its 16-B chunks are XOR-swizzled through the SOURCE address: lane l
+// fetches chunk (l & 3) ^ (row / 4 % 4) of row l / 4 of its piece, and frag_load_ps() applies the same XOR.
+template <int ROWS>
+struct PlaneLoader {
+    static constexpr int NPIECE = ROWS / 16;       // 1-KiB pieces per plane
+    static constexpr int PPW = NPIECE / 4;         // per wave
+    static constexpr int PLANE_BYTES = ROWS * 64;
+    int64_t src[PPW];      // element offset (bf16) of this lane's chunk at k = 0, plane 0
+    int u_coff, u_kh, u_kw;
+
+    __device__ __forceinline__ void init(const KoafOperand& op, int r0, int R) {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            // rows past R re-read the last row: finite values that only reach output columns >= N, which are never stored
+            const int row = min(r0 + 16 * (w + 4 * j) + (lane >> 2), R - 1);
+            src[j] = (int64_t)row * op.ld + 8 * ((lane & 3) ^ ((lane >> 4) & 3));
+        }
+        u_coff = u_kh = u_kw = 0;
+    }
+    __device__ __forceinline__ void seek(const KoafOperand& op, int k0) {
+        const int tap = k0 / op.C;
+        u_coff = k0 - tap * op.C;
+        u_kh = tap / op.KW;
+        u_kw = tap - u_kh * op.KW;
+    }
+    // DMA of the k-tile at the running position into the plane images at `lds` (one buffer = NPL * PLANE_BYTES)
+    template <int NPL>
+    __device__ __forceinline__ void issue(const KoafOperand& op, const unsigned short* planes, float* lds) {
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int w = threadIdx.x >> 6;
+        const int64_t koff = u_kh * op.tap_stride_h + u_kw * op.tap_stride + u_coff;
+        u_coff += BK;
+        if (u_coff >= op.C) {
+            u_coff -= op.C;
+            if (++u_kw == op.KW) { u_kw = 0; ++u_kh; }
+        }
+        char* base = reinterpret_cast<char*>(lds);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q)
+#pragma unroll
+            for (int j = 0; j < PPW; ++j)
+                __builtin_amdgcn_global_load_lds((gptr_t)(planes + q * op.plane_stride + src[j] + koff),
+                                                 (lptr_t)(base + q * PLANE_BYTES + (w + 4 * j) * 1024), 16, 0, 0);
+    }
+};
+
+// fragment of a swizzled linear plane image written by PlaneLoader: rows of 16 dwords (32 k)
+__device__ __forceinline__ v4i frag_load_ps(const unsigned* P, int row0, int g, int lane) {
+    const int row = row0 + (lane & 31);
+    return *(const v4i*)&P[row * 16 + 4 * ((2 * g + (lane >> 5)) ^ ((row >> 2) & 3))];
 }
 
 // Row loop of the vector epilogue for a FULL tile without row map, specialised on what is fused (residual, BatchNorm-
@@ -529,32 +558,24 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
     }
 }
 
-// NPL = bf16 planes per operand: 3 = every significand bit (forward), 2 = operands rounded to 16 significand bits
-// (backward contractions, KoafGemm.prec == 1)
-template <int BM, int BN, int AM, int BMD, bool TFA, bool TFB, bool VEC, int NPL>
+
+// F16 = KoafGemm.fmt == 1 (two fp16 planes per operand, three products); else three bf16 planes, six products
+template <int BM, int BN, int AM, int BMD, bool TFA, bool TFB, bool VEC, bool F16>
 __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
+    constexpr int NPL = F16 ? 2 : 3;
+    static_assert(BMD != M_PS || F16, "plane images are fp16");
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr bool AKC = mode_is_kc(AM), BKC = mode_is_kc(BMD);
-#if KOAF_SPLIT3 == 2
-    constexpr int A_PL = plane_dwords(BM, AKC), B_PL = plane_dwords(BN, BKC);
+    constexpr bool AKC = mode_is_kc(AM), BKC = mode_is_kc(BMD), BPS = (BMD == M_PS);
+    constexpr int A_PL = plane_dwords(BM, AKC), B_PL = BPS ? BN * 16 : plane_dwords(BN, BKC);
     constexpr int A_ELEMS = NPL * A_PL, B_ELEMS = NPL * B_PL;
-#else
-    constexpr int A_ELEMS = AKC ? BM * LDK : BK * BM;
-    constexpr int B_ELEMS = BKC ? BN * LDK : BK * BN;
-#endif
-    constexpr int STAGE = A_ELEMS + B_ELEMS;
-    // LDS double buffering (one barrier per k-step) only where it does not cost a resident block: the 128x128
-    // tile is register-limited to 2 blocks/CU either way; the rectangular tiles fit 3 blocks single-buffered
-    // (27 KB) but only 2 double-buffered (55 KB), and the third block hides more than the saved barrier.
-    constexpr bool DB = KOAF_SPLIT3 == 2 ? (KOAF_DB_BWD && NPL == 2) : (KOAF_DB_ALL ? true : (BM == BN));
-    constexpr int NSTAGE = DB ? 2 : 1;
+    constexpr int NBB = BPS ? 2 : 1;                                 // LDS buffers of the B operand (DMA target: two)
     constexpr int LDC_S = BN + 4;                                    // epilogue staging row (floats)
     constexpr int C_ELEMS = VEC ? BM * LDC_S : 0;
-    constexpr int SMEM = (NSTAGE * STAGE > C_ELEMS) ? NSTAGE * STAGE : C_ELEMS;
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];        // double-buffered operand tiles
+    constexpr int OPS = A_ELEMS + NBB * B_ELEMS;
+    constexpr int SMEM = (OPS > C_ELEMS) ? OPS : C_ELEMS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
     const int ntn = (p.N + BN - 1) / BN;
-#if KOAF_XCD_SWIZZLE
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MiB L2): without a remap the ntn blocks that
     // share an A row tile land on ntn different L2s and the tile is fetched from beyond L2 ntn times.  Bijective remap:
     // XCD x works through one contiguous chunk of the tile order, so a row tile's blocks follow each other on one L2.
@@ -563,9 +584,6 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         const unsigned nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, x = bid & 7, j = bid >> 3;
         bid = x * q + (x < rem ? x : rem) + j;
     }
-#else
-    const unsigned bid = blockIdx.x;
-#endif
     const int tn = bid % ntn;
     const int tm = bid / ntn;
     const int m0 = p.m_base + tm * BM, n0 = tn * BN;
@@ -575,15 +593,28 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     const int kbeg = split * kchunk;
     const int kend = min(p.K, kbeg + kchunk);
 
+    // operand scales of the fp16 scheme (powers of two; 1 otherwise): applied on load, divided out in the epilogue
+    const float sca = F16 ? operand_scale(p.A) : 1.f;
+    const float scb = F16 ? operand_scale(p.B) : 1.f;
+    const float alpha = F16 ? p.alpha / (sca * scb) : p.alpha;
+
     const float* Ap = p.A.ptr + z0 * p.A.bs0 + z1 * p.A.bs1;
-    const float* Bp = p.B.ptr + z0 * p.B.bs0 + z1 * p.B.bs1;
+    const float* Bp = BPS ? nullptr : p.B.ptr + z0 * p.B.bs0 + z1 * p.B.bs1;
+    const unsigned short* Bpl = BPS ? p.B.planes + z0 * p.B.bs0 + z1 * p.B.bs1 : nullptr;
 
     TileLoader<BM, AM, TFA, VEC> la;
-    TileLoader<BN, BMD, TFB, VEC> lb;
+    // (the unused one of the two B loaders is dead code to the compiler)
+    TileLoader<BN, BPS ? M_KC : BMD, TFB, VEC> lb;
+    PlaneLoader<BN> lp;
     la.init(p.A, m0, p.M, z1);
-    lb.init(p.B, n0, p.N, z1);
     la.seek(p.A, kbeg);
-    lb.seek(p.B, kbeg);
+    if constexpr (BPS) {
+        lp.init(p.B, n0, p.N);
+        lp.seek(p.B, kbeg);
+    } else {
+        lb.init(p.B, n0, p.N, z1);
+        lb.seek(p.B, kbeg);
+    }
 
     v16f acc[TM][TN];
 #pragma unroll
@@ -598,29 +629,35 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     const int wm = w >> 1, wn = w & 1;
     const int r = lane & 31, h = lane >> 5;
 
+    float* const Bs0 = smem + A_ELEMS;
     if (kbeg < kend) {
+        if constexpr (BPS) lp.template issue<NPL>(p.B, Bpl, Bs0);
         la.issue(la.sa, p.A, Ap, kbeg, kend, z1);
-        lb.issue(lb.sa, p.B, Bp, kbeg, kend, z1);
+        if constexpr (!BPS) lb.issue(lb.sa, p.B, Bp, kbeg, kend, z1);
         la.finish(la.sa);
-        lb.finish(lb.sa);
-        la.template store<NPL>(la.sa, smem);
-        lb.template store<NPL>(lb.sa, smem + A_ELEMS);
+        la.template store<NPL, F16>(la.sa, smem, sca);
+        if constexpr (!BPS) {
+            lb.finish(lb.sa);
+            lb.template store<NPL, F16>(lb.sa, Bs0, scb);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
+        }
     }
     __syncthreads();
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = (k0 + BK) < kend;
-        const float* As = smem + cur * STAGE;
-        const float* Bs = As + A_ELEMS;
-        if (KOAF_ISSUE_AT == 0 && more) {
+        const unsigned* Au = (const unsigned*)smem;
+        const unsigned* Bu = (const unsigned*)(Bs0 + cur * B_ELEMS);
+        // the next tile's global loads go out first: in flight under this tile's MFMAs (the DMA into the other B buffer,
+        // which every wave stopped reading at the last barrier)
+        if (more) {
+            if constexpr (BPS) lp.template issue<NPL>(p.B, Bpl, Bs0 + (cur ^ 1) * B_ELEMS);
             la.issue(la.sa, p.A, Ap, k0 + BK, kend, z1);
-            lb.issue(lb.sa, p.B, Bp, k0 + BK, kend, z1);
+            if constexpr (!BPS) lb.issue(lb.sa, p.B, Bp, k0 + BK, kend, z1);
         }
-#if KOAF_SPLIT3 == 2
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const unsigned* Au = (const unsigned*)As;
-            const unsigned* Bu = (const unsigned*)Bs;
             v4i ap[TM][NPL], bp[NPL];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -629,137 +666,48 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) {
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) bp[q] = frag_load<BN, BKC>(Bu + q * B_PL, wn * WN + 32 * jn, g, lane);
-                // piece products, smallest first.  3 planes: the six of weight >= 2^-16.  2 planes: all four (the exact
-                // product of the 16-bit operands), or without mid*mid when KOAF_BWD_TERMS == 3.
-                constexpr int NT = NPL == 3 ? 6 : KOAF_BWD_TERMS;
+                for (int q = 0; q < NPL; ++q) {
+                    if constexpr (BPS) bp[q] = frag_load_ps(Bu + q * B_PL, wn * WN + 32 * jn, g, lane);
+                    else bp[q] = frag_load<BN, BKC>(Bu + q * B_PL, wn * WN + 32 * jn, g, lane);
+                }
+                // piece products, smallest first.  bf16: the six of weight >= 2^-16.  fp16: lo*hi, hi*lo, hi*hi.
+                constexpr int NT = F16 ? 3 : 6;
                 constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
-                constexpr int PA2[4] = {1, 1, 0, 0}, PB2[4] = {1, 0, 1, 0};
+                constexpr int PAH[3] = {1, 0, 0}, PBH[3] = {0, 1, 0};
 #pragma unroll
                 for (int term = 0; term < NT; ++term) {
-                    const int pa = NPL == 3 ? PA3[term] : PA2[term + (4 - NT)];
-                    const int pb = NPL == 3 ? PB3[term] : PB2[term + (4 - NT)];
+                    const int pa = F16 ? PAH[term] : PA3[term];
+                    const int pb = F16 ? PBH[term] : PB3[term];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[i][pa]),
-                                                                             __builtin_bit_cast(bf16x8, bp[pb]),
-                                                                             acc[i][jn], 0, 0, 0);
-                }
-            }
-        }
-#elif KOAF_SPLIT3
-        // fp32 x fp32 on the bf16 matrix pipe: every operand value is cut (by truncation, exactly) into three bf16
-        // pieces hi + mid + lo = all 24 significand bits; of the nine piece products the six of relative weight
-        // >= 2^-16 go through v_mfma_f32_32x32x16_bf16 (each product exact, fp32 accumulate), the three dropped ones
-        // are < 2^-21 of the product.  Six 8-pass MFMAs replace eight 16-pass fp32 MFMAs per 16 k: 2.67x the rate.
-#pragma unroll
-        for (int kq = 0; kq < 2; ++kq) {
-            v4f a[TM][2], b[2];
-            v4i ap[TM][3], bp[3];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int kg = 2 * kq + u;
-                    if constexpr (AKC) {
-                        a[i][u] = *(const v4f*)&As[(wm * WM + 32 * i + r) * LDK + 8 * kg + 4 * h];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[i][u][j] = As[(8 * kg + 4 * h + j) * BM + wm * WM + 32 * i + r];
+                    for (int i = 0; i < TM; ++i) {
+                        if constexpr (F16)
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ap[i][pa]),
+                                                                                __builtin_bit_cast(h16x8, bp[pb]),
+                                                                                acc[i][jn], 0, 0, 0);
+                        else
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[i][pa]),
+                                                                                 __builtin_bit_cast(bf16x8, bp[pb]),
+                                                                                 acc[i][jn], 0, 0, 0);
                     }
                 }
-                split3(a[i][0], a[i][1], ap[i]);
-            }
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int kg = 2 * kq + u;
-                    if constexpr (BKC) {
-                        b[u] = *(const v4f*)&Bs[(wn * WN + 32 * jn + r) * LDK + 8 * kg + 4 * h];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) b[u][j] = Bs[(8 * kg + 4 * h + j) * BN + wn * WN + 32 * jn + r];
-                    }
-                }
-                split3(b[0], b[1], bp);
-                // smallest terms first; TM independent accumulators between two uses of the same one
-#pragma unroll
-                for (int term = 0; term < 6; ++term) {
-                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-                    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[i][PA[term]]),
-                                                                             __builtin_bit_cast(bf16x8, bp[PB[term]]),
-                                                                             acc[i][jn], 0, 0, 0);
-                }
             }
         }
-#else
-#pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-            v4f a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if constexpr (AKC) {
-                    a[i] = *(const v4f*)&As[(wm * WM + 32 * i + r) * LDK + 8 * kg + 4 * h];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) a[i][j] = As[(8 * kg + 4 * h + j) * BM + wm * WM + 32 * i + r];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                if constexpr (BKC) {
-                    b[i] = *(const v4f*)&Bs[(wn * WN + 32 * i + r) * LDK + 8 * kg + 4 * h];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) b[i][j] = Bs[(8 * kg + 4 * h + j) * BN + wn * WN + 32 * i + r];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int jn = 0; jn < TN; ++jn)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[jn][j], acc[i][jn], 0, 0, 0);
-            // the next tile's global loads go out between the MFMA groups (their address VALU work
-            // executes in the shadow of the MFMAs just issued)
-            if (KOAF_ISSUE_AT == 1) {
-                if (kg == 0 && more) la.issue(la.sa, p.A, Ap, k0 + BK, kend, z1);
-                if (kg == 1 && more) lb.issue(lb.sa, p.B, Bp, k0 + BK, kend, z1);
-            }
-        }
-#endif
-#if KOAF_PIN_ACC
-        // keep the loop-carried accumulators in AGPRs (hipcc otherwise carries them in VGPRs and copies all 64
-        // into AGPRs at the top of every k-step: 64 v_accvgpr_write per step)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn) asm volatile("" : "+a"(acc[i][jn]));
-#endif
-        if constexpr (DB) {
-            if (more) {
-                float* An = smem + (cur ^ 1) * STAGE;
-                la.finish(la.sa);
+        // every wave is done reading the A image (and this B buffer).  With LDS-DMA in flight __syncthreads() would
+        // drain vmcnt here, in the middle of the MFMA stream: a raw barrier behind the LDS-read wait keeps the next
+        // tile's loads in flight until finish() needs them.
+        if constexpr (BPS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
+        if (more) {
+            la.finish(la.sa);
+            la.template store<NPL, F16>(la.sa, smem, sca);
+            if constexpr (!BPS) {
                 lb.finish(lb.sa);
-                la.template store<NPL>(la.sa, An);
-                lb.template store<NPL>(lb.sa, An + A_ELEMS);
+                lb.template store<NPL, F16>(lb.sa, Bs0, scb);
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                cur ^= 1;
             }
             __syncthreads();
-            cur ^= 1;
-        } else {
-            __syncthreads();
-            if (more) {
-                la.finish(la.sa);
-                lb.finish(lb.sa);
-                la.template store<NPL>(la.sa, smem);
-                lb.template store<NPL>(lb.sa, smem + A_ELEMS);
-                __syncthreads();
-            }
         }
     }
 
@@ -797,7 +745,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
             for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float v = p.alpha * acc[i][jn][e];
+                    const float v = alpha * acc[i][jn][e];
                     s1[jn] += v - kshift[jn];
                     s2[jn] += (v - kshift[jn]) * (v - kshift[jn]);
                     Cs[(wm * WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC_S + wn * WN + 32 * jn + r] = v;
@@ -898,7 +846,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                float v = p.alpha * acc[i][jn][e];
+                float v = alpha * acc[i][jn][e];
                 s1[jn] += v - kshift[jn];
                 s2[jn] += (v - kshift[jn]) * (v - kshift[jn]);
                 if (cok && row < p.M) {
@@ -981,6 +929,12 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 bool operand_vec_ok(const KoafOperand& o, int R, int K) {
+    if (o.kind == 2) {
+        // pre-split plane images: rows and taps start on 16-B boundaries, k-tiles never straddle a tap
+        if (!aligned16(o.planes) || (o.ld & 7) || (o.plane_stride & 7) || (o.bs0 & 7) || (o.bs1 & 7)) return false;
+        if ((o.tap_stride & 7) || (o.tap_stride_h & 7) || o.C <= 0 || (o.C & 31) || o.KW <= 0) return false;
+        return true;
+    }
     if (!aligned16(o.ptr)) return false;
     if ((o.ld & 3) || (o.bs0 & 3) || (o.bs1 & 3)) return false;
     if (o.kind == 0) {
@@ -996,17 +950,18 @@ bool operand_vec_ok(const KoafOperand& o, int R, int K) {
 }
 
 int operand_mode(const KoafOperand& o) {
+    if (o.kind == 2) return M_PS;
     if (o.kind == 0) return o.gather == 0 ? M_KC : (o.gather == 1 ? M_KC_G1 : M_KC_G2);
     return o.gather == 0 ? M_KM : (o.gather == 1 ? M_KM_G1 : M_KM_G3);
 }
 
 #define KOAF_LAUNCH(AMODE, BMODE, TA, TB)                                                                        \
-    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, NPL>), grid, dim3(256), 0, s, g);    \
+    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16>), grid, dim3(256), 0, s, g);      \
     return koaf_check_launch("koaf_gemm")
 
-// the operand-mode pairs the library uses: conv fwd (KC|KC_G1 x KC), dgrad (KC x KM | KC_G2 x KM_G3),
-// wgrad (KM x KM|KM_G1), linear / attention (dense pairs).  tf only where a BatchNorm prologue exists.
-template <int BM, int BN, bool VEC, int NPL>
+// the operand-mode pairs the library uses: conv fwd (KC|KC_G1 x KC|PS), dgrad (KC|KC_G2 x PS, or KC x KM | KC_G2 x KM_G3
+// on fp32 weights), wgrad (KM x KM|KM_G1), linear / attention (dense pairs).  tf only where a BatchNorm prologue exists.
+template <int BM, int BN, bool VEC, bool F16>
 int launch_modes(const KoafGemm& g, dim3 grid, hipStream_t s) {
     const int am = operand_mode(g.A), bm = operand_mode(g.B);
     const bool ta = g.A.tf != 0, tb = g.B.tf != 0;
@@ -1017,8 +972,14 @@ int launch_modes(const KoafGemm& g, dim3 grid, hipStream_t s) {
         if (am == M_KC_G1 && bm == M_KC && !tb) { if (ta) { KOAF_LAUNCH(M_KC_G1, M_KC, true, false); } else { KOAF_LAUNCH(M_KC_G1, M_KC, false, false); } }
         if (am == M_KC_G2 && bm == M_KM_G3 && !ta && !tb) { KOAF_LAUNCH(M_KC_G2, M_KM_G3, false, false); }
         if (am == M_KM && bm == M_KM_G1 && !ta) { if (tb) { KOAF_LAUNCH(M_KM, M_KM_G1, false, true); } else { KOAF_LAUNCH(M_KM, M_KM_G1, false, false); } }
+        if constexpr (F16) {
+            if (am == M_KC && bm == M_PS) { if (ta) { KOAF_LAUNCH(M_KC, M_PS, true, false); } else { KOAF_LAUNCH(M_KC, M_PS, false, false); } }
+            if (am == M_KC_G1 && bm == M_PS) { if (ta) { KOAF_LAUNCH(M_KC_G1, M_PS, true, false); } else { KOAF_LAUNCH(M_KC_G1, M_PS, false, false); } }
+            if (am == M_KC_G2 && bm == M_PS && !ta) { KOAF_LAUNCH(M_KC_G2, M_PS, false, false); }
+        }
     }
-    koaf_set_error("koaf_gemm: operand mode pair (%d,%d) tf=(%d,%d) is not instantiated", am, bm, (int)ta, (int)tb);
+    koaf_set_error("koaf_gemm: operand mode pair (%d,%d) tf=(%d,%d) fmt=%d vec=%d is not instantiated", am, bm, (int)ta,
+                   (int)tb, (int)F16, (int)VEC);
     return KOAF_EINVAL;
 }
 
@@ -1035,9 +996,9 @@ extern "C" int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn) 
     if (b_m == 0) b_m = (g->M >= 128) ? 128 : 64;
     if (g->bm == 0 || g->bn == 0) {
         auto tiles = [&](int m, int n) { return cdiv64(g->M, m) * cdiv64(g->N, n) * batch; };
-        // fill the 256 CUs: shrink the tile while the grid is under `fill` blocks (KOAF_TILE_FILL, default 384 = 1.5 per CU:
-        // a single 78 %-full round of 128x128 tiles beats two rounds of the 1.25x costlier 64-row tiles; measured 512 / 384 / 256)
-        static const int64_t fill = [] { const char* e = getenv("KOAF_TILE_FILL"); return (int64_t)(e ? atoi(e) : 384); }();
+        // fill the 256 CUs: shrink the tile while the grid is under 384 blocks (1.5 per CU: a single 78 %-full round of
+        // 128x128 tiles beats two rounds of the 1.25x costlier 64-row tiles; measured 512 / 384 / 256)
+        constexpr int64_t fill = 384;
         if (g->bm == 0 && tiles(b_m, b_n) < fill && b_m == 128) b_m = 64;
         if (g->bn == 0 && tiles(b_m, b_n) < fill && b_n == 128) b_n = 64;
     }
@@ -1047,21 +1008,7 @@ extern "C" int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn) 
 }
 
 namespace {
-// KoafGemm.prec == 1 contractions (weight / data gradients) run on two bf16 planes per operand unless the environment
-// says KOAF_BWD_PRECISION=full (read once)
-// KOAF_FWD_PRECISION=16 (opt-in, not the shipped mode): forward contractions on two pieces as well
-bool reduced_forward() {
-    static const bool on = [] { const char* e = getenv("KOAF_FWD_PRECISION"); return e && e[0] == '1' && e[1] == '6'; }();
-    return on;
-}
-
-int g_bwd_full = -1;     // -1: not set by koaf_set_backward_precision -> environment decides
-bool reduced_backward() {
-    static const bool env_on = [] { const char* e = getenv("KOAF_BWD_PRECISION"); return !(e && e[0] == 'f'); }();
-    return g_bwd_full < 0 ? env_on : (g_bwd_full == 0);
-}
-
-struct TilePlan { int bm, bn; bool vec; int m_split; int part_rows; };   // m_split > 0: mixed-height tiling
+struct TilePlan { int bm, bn; bool vec; int part_rows; };
 
 bool gemm_vec_ok(const KoafGemm& g) {
     bool vec = operand_vec_ok(g.A, g.M, g.K) && operand_vec_ok(g.B, g.N, g.K);
@@ -1075,56 +1022,37 @@ bool gemm_vec_ok(const KoafGemm& g) {
 // g must already have its defaults filled (nb*, splitk, CS, stats_ld)
 TilePlan plan_tiles(const KoafGemm& g) {
     TilePlan t;
-    const bool autot = (g.bm == 0 && g.bn == 0);
     KoafGemm q = g;
     koaf_gemm_pick_tile(&q, &t.bm, &t.bn);
     t.vec = gemm_vec_ok(g);
     if (!t.vec) { t.bm = 64; t.bn = 64; }
-    t.m_split = -1;
     t.part_rows = (int)cdiv64(g.M - g.m_base, t.bm);
-    // Mixed-height tiling.  With 128x128 tiles a CU holds 2 blocks, so T tiles over 256 CUs leave some CUs with
-    // ceil(T/256) tiles while the average is T/256 (800 tiles: 4 vs 3.1 = 78 %).  Run the whole multiples of 512
-    // tiles as 128-row tiles and the remainder as 64-row tiles (half the grain, 3 blocks per CU) in a second
-    // launch over the same row space; epilogue semantics (statistics rows, residual, row map) are per tile and
-    // carry over unchanged.
-    if (autot && t.vec && t.bm == 128 && t.bn == 128 && g.splitk == 1 && g.nb0 * g.nb1 == 1 && g.m_base == 0 &&
-        getenv("KOAF_MIXED_TILES")) {   // opt-in: measured 146.5 ms vs 143.4 ms without on the native step (no gain)
-        const int64_t ntn = cdiv64(g.N, 128), ntm = cdiv64(g.M, 128);
-        const int64_t tm_full = (((ntm * ntn) / 512) * 512) / ntn;     // whole tile-rows inside the full rounds
-        const int64_t rem_tiles = (ntm - tm_full) * ntn;
-        if (rem_tiles > 0 && rem_tiles < 448) {
-            t.m_split = (int)(tm_full * 128);
-            t.part_rows = (int)(tm_full + cdiv64(g.M - t.m_split, 64));
-        }
-    }
     return t;
 }
 }  // namespace
 
-extern "C" int koaf_gemm_part_rows(const KoafGemm* gp) {
-    KoafGemm g = *gp;
-    if (g.nb0 < 1) g.nb0 = 1;
-    if (g.nb1 < 1) g.nb1 = 1;
-    if (g.splitk < 1) g.splitk = 1;
-    return plan_tiles(g).part_rows;
-}
-
-extern "C" int koaf_set_backward_precision(int32_t full) {
-    const int prev = reduced_backward() ? 0 : 1;
-    g_bwd_full = full < 0 ? -1 : (full ? 1 : 0);
-    return prev;
-}
-
-extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
-    KoafGemm g = *gp;
-    KOAF_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0, "koaf_gemm: bad dims M=%d N=%d K=%d", g.M, g.N, g.K);
-    KOAF_REQUIRE(g.A.ptr && g.B.ptr && g.C, "koaf_gemm: null operand");
+// defaults of the optional descriptor fields (shared by the launch and by the planning queries, which must agree)
+static void fill_defaults(KoafGemm& g) {
     if (g.nb0 < 1) g.nb0 = 1;
     if (g.nb1 < 1) g.nb1 = 1;
     if (g.splitk < 1) g.splitk = 1;
     if (g.A.CS == 0) g.A.CS = g.A.C;
     if (g.B.CS == 0) g.B.CS = g.B.C;
     if (g.stats_ld == 0) g.stats_ld = g.N;
+    if (g.B.kind == 2 && g.B.C == 0) { g.B.C = ((g.K + BK - 1) / BK) * BK; g.B.KW = 1; }   // dense: one "tap" spanning the padded K
+}
+
+extern "C" int koaf_gemm_part_rows(const KoafGemm* gp) {
+    KoafGemm g = *gp;
+    fill_defaults(g);
+    return plan_tiles(g).part_rows;
+}
+
+extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
+    KoafGemm g = *gp;
+    KOAF_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0, "koaf_gemm: bad dims M=%d N=%d K=%d", g.M, g.N, g.K);
+    KOAF_REQUIRE(g.A.ptr && (g.B.kind == 2 ? (const void*)g.B.planes : (const void*)g.B.ptr) && g.C, "koaf_gemm: null operand");
+    fill_defaults(g);
     KOAF_REQUIRE(!g.cmap || (g.splitk == 1 && !g.stats), "koaf_gemm: row map excludes split-K / stats");
     KOAF_REQUIRE(!g.bnb_mode || (g.splitk == 1 && !g.stats && g.nb0 * g.nb1 == 1 && g.bnb_c && g.bnb_mean &&
                                  g.bnb_invstd && g.bnb_part && (g.bnb_mode == 1 ? g.bnb_y != nullptr
@@ -1133,51 +1061,43 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     KOAF_REQUIRE(g.splitk == 1 || (!g.bias && !g.residual && !g.stats),
                  "koaf_gemm: split-K writes raw slabs (no epilogue)");
     KOAF_REQUIRE((int64_t)g.nb0 * g.nb1 <= 65535 && g.splitk <= 65535, "koaf_gemm: batch/splitk too large");
-    KOAF_REQUIRE(g.A.kind == 0 || g.A.gather == 0, "koaf_gemm: K-major A cannot be gathered");
+    KOAF_REQUIRE(g.A.kind == 0 || (g.A.kind == 1 && g.A.gather == 0), "koaf_gemm: A is K-contiguous fp32, or K-major without gather");
     KOAF_REQUIRE(!(g.A.kind == 0 && g.A.gather == 3) && !(g.B.kind == 0 && g.B.gather == 3),
                  "koaf_gemm: tapped gather needs a K-major operand");
     KOAF_REQUIRE(!(g.B.kind == 0 && g.B.gather), "koaf_gemm: K-contiguous B cannot be gathered");
+    KOAF_REQUIRE(g.fmt == 0 || g.fmt == 1, "koaf_gemm: fmt must be 0 (bf16 x 3) or 1 (fp16 x 2)");
+    if (g.B.kind == 2) {
+        KOAF_REQUIRE(g.fmt == 1 && g.B.amax, "koaf_gemm: plane images are fp16 pieces of B * scale(*B.amax): fmt 1, amax required");
+        KOAF_REQUIRE(g.A.kind == 0 && !g.B.tf, "koaf_gemm: a pre-split B pairs with a K-contiguous A and takes no transform");
+    }
     const TilePlan tp = plan_tiles(g);
     const bool vec = tp.vec;
     KOAF_REQUIRE((tp.bm == 64 || tp.bm == 128) && (tp.bn == 64 || tp.bn == 128), "koaf_gemm: tile must be 64|128");
     if (g.A.gather || g.B.gather) KOAF_REQUIRE(vec, "koaf_gemm: gathered operands need aligned, C%%32==0 tensors");
+    if (g.B.kind == 2) KOAF_REQUIRE(vec, "koaf_gemm: pre-split B needs 16-B aligned operands (and C %% 32 == 0 per tap)");
     if (g.B.kind == 1 && g.B.gather == 1)
         KOAF_REQUIRE(g.B.C % 4 == 0, "koaf_gemm: gathered K-major operand needs channels per tap (%d) %% 4 == 0", g.B.C);
     KOAF_REQUIRE(!g.cmap || vec, "koaf_gemm: row map needs the vector epilogue");
     KOAF_REQUIRE(!g.bnb_mode || vec, "koaf_gemm: fused BN-backward needs the vector epilogue");
     hipStream_t s = (hipStream_t)stream;
-    auto launch = [&](KoafGemm& q, int qbm, int qbn) -> int {
-        q.bm = qbm;
-        q.bn = qbn;
-        const int64_t tiles = cdiv64(q.M - q.m_base, qbm) * cdiv64(q.N, qbn);
-        if (tiles <= 0) return KOAF_OK;
-        if (tiles >= (1ll << 31)) { koaf_set_error("koaf_gemm: grid too large"); return KOAF_EINVAL; }
-        dim3 grid((unsigned)tiles, (unsigned)q.splitk, (unsigned)(q.nb0 * q.nb1));
-        if ((q.prec == 1 && reduced_backward()) || (q.prec == 0 && reduced_forward())) {
-            if (!vec) return launch_modes<64, 64, false, 2>(q, grid, s);
-            if (qbm == 128 && qbn == 128) return launch_modes<128, 128, true, 2>(q, grid, s);
-            if (qbm == 128 && qbn == 64) return launch_modes<128, 64, true, 2>(q, grid, s);
-            if (qbm == 64 && qbn == 128) return launch_modes<64, 128, true, 2>(q, grid, s);
-            return launch_modes<64, 64, true, 2>(q, grid, s);
-        }
-        if (!vec) return launch_modes<64, 64, false, 3>(q, grid, s);
-        if (qbm == 128 && qbn == 128) return launch_modes<128, 128, true, 3>(q, grid, s);
-        if (qbm == 128 && qbn == 64) return launch_modes<128, 64, true, 3>(q, grid, s);
-        if (qbm == 64 && qbn == 128) return launch_modes<64, 128, true, 3>(q, grid, s);
-        return launch_modes<64, 64, true, 3>(q, grid, s);
-    };
-    if (tp.m_split >= 0) {
-        KoafGemm a = g, b = g;
-        if (tp.m_split > 0) {
-            a.M = tp.m_split;
-            int rc = launch(a, 128, 128);
-            if (rc != KOAF_OK) return rc;
-        }
-        b.m_base = tp.m_split;
-        b.part_row0 = g.part_row0 + tp.m_split / 128;
-        return launch(b, 64, 128);
+    g.bm = tp.bm;
+    g.bn = tp.bn;
+    const int64_t tiles = cdiv64(g.M - g.m_base, tp.bm) * cdiv64(g.N, tp.bn);
+    if (tiles <= 0) return KOAF_OK;
+    if (tiles >= (1ll << 31)) { koaf_set_error("koaf_gemm: grid too large"); return KOAF_EINVAL; }
+    dim3 grid((unsigned)tiles, (unsigned)g.splitk, (unsigned)(g.nb0 * g.nb1));
+    if (g.fmt == 1) {
+        KOAF_REQUIRE(vec, "koaf_gemm: the fp16 scheme needs the vector path (16-B aligned operands, K %% 4 == 0, N %% 4 == 0)");
+        if (tp.bm == 128 && tp.bn == 128) return launch_modes<128, 128, true, true>(g, grid, s);
+        if (tp.bm == 128 && tp.bn == 64) return launch_modes<128, 64, true, true>(g, grid, s);
+        if (tp.bm == 64 && tp.bn == 128) return launch_modes<64, 128, true, true>(g, grid, s);
+        return launch_modes<64, 64, true, true>(g, grid, s);
     }
-    return launch(g, tp.bm, tp.bn);
+    if (!vec) return launch_modes<64, 64, false, false>(g, grid, s);
+    if (tp.bm == 128 && tp.bn == 128) return launch_modes<128, 128, true, false>(g, grid, s);
+    if (tp.bm == 128 && tp.bn == 64) return launch_modes<128, 64, true, false>(g, grid, s);
+    if (tp.bm == 64 && tp.bn == 128) return launch_modes<64, 128, true, false>(g, grid, s);
+    return launch_modes<64, 64, true, false>(g, grid, s);
 }
 
 extern "C" int koaf_slab_reduce(const float* slabs, int32_t nslab, int64_t n, float* out, void* stream) {
@@ -1209,4 +1129,112 @@ extern "C" int koaf_slab_reduce_epilogue(const float* slabs, int32_t nslab, int3
     hipLaunchKernelGGL(slab_reduce_epi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslab, M,
                        N, bias, residual, ldr, out, ldo);
     return koaf_check_launch("koaf_slab_reduce_epilogue");
+}
+
+
+// ================================================================================================
+// weight plane images (the M_PS operand): cut once per optimizer step for every convolution weight of the model
+// ================================================================================================
+namespace {
+// block -> (descriptor, tile): the last descriptor whose first tile is <= blockIdx.x; tile = 32 (rows) x 32 (k of one tap)
+struct WTile { KoafWPlane d; int idx, rt, tap, ct; };
+__device__ __forceinline__ WTile wtile_of_block(const KoafWPlane* __restrict__ tab, int ntab) {
+    int lo = 0, hi = ntab - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].tile0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    WTile w;
+    w.d = tab[lo];
+    w.idx = lo;
+    int tl = (int)((int64_t)blockIdx.x - w.d.tile0);
+    const int nct = (w.d.C + 31) / 32;
+    w.ct = tl % nct; tl /= nct;
+    w.tap = tl % w.d.taps;
+    w.rt = tl / w.d.taps;
+    return w;
+}
+__device__ __forceinline__ v4f wtile_load(const float* __restrict__ base, const WTile& w, int r, int c) {
+    const KoafWPlane& d = w.d;
+    const int64_t K = (int64_t)d.taps * d.C;
+    v4f x = {0.f, 0.f, 0.f, 0.f};
+    if (r < d.R) {
+        const float* s = base + d.src_off + (int64_t)r * K + (int64_t)w.tap * d.C + c;
+        if (c + 3 < d.C && ((K | d.C) & 3) == 0) x = *(const v4f*)s;
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (c + j < d.C) x[j] = s[j];
+        }
+    }
+    return x;
+}
+
+// pass 1: amax[i] = max |w| of weight i (amax zeroed beforehand; float bits of non-negative values order like integers)
+__global__ void __launch_bounds__(256) wplanes_amax_kernel(const float* __restrict__ base, const KoafWPlane* __restrict__ tab,
+                                                           int ntab, float* __restrict__ amax) {
+    const WTile w = wtile_of_block(tab, ntab);
+    const int t = threadIdx.x;
+    const v4f x = wtile_load(base, w, w.rt * 32 + (t >> 3), w.ct * 32 + 4 * (t & 7));
+    float m = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+    m = wave_max(m);
+    if ((t & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax + w.idx), __float_as_uint(m));
+}
+
+// pass 2: the images of w * scale_of_amax(amax[i]) (split2h: bit-identical to the in-kernel split of the same operand)
+//   F image [2][R][Kp]         (Kp = taps * C rounded up to 32; forward B operand: rows = output channels)
+//   D image [2][C][taps * Rp]  (Rp = R rounded up to 32; the transposed weight, dgrad B operand: rows = input channels,
+//                               k = (tap, output channel)); the tile is transposed through LDS.
+// Both are zero-filled up to their padded extents.
+__global__ void __launch_bounds__(256) wplanes_build_kernel(const float* __restrict__ base, unsigned short* __restrict__ planes,
+                                                            const KoafWPlane* __restrict__ tab, int ntab,
+                                                            const float* __restrict__ amax) {
+    __shared__ unsigned short tile[2][32][36];      // [plane][c][r] (+4 pad)
+    const WTile w = wtile_of_block(tab, ntab);
+    const KoafWPlane& d = w.d;
+    const int t = threadIdx.x, ty = t >> 3, tx = t & 7;
+    const int r = w.rt * 32 + ty, c = w.ct * 32 + 4 * tx;
+    unsigned pl[2][2];
+    split2h(wtile_load(base, w, r, c), scale_of_amax(amax[w.idx]), pl);
+    if (d.f_off >= 0 && r < d.R) {
+        // (c + 3 < Kp always: Kp and c are multiples of 4, the tile covers C rounded up to 32 only when taps == 1)
+        unsigned short* f = planes + d.f_off + (int64_t)r * d.Kp + (int64_t)w.tap * d.C + c;
+        const int64_t ps = (int64_t)d.R * d.Kp;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *(uint2*)(f + q * ps) = make_uint2(pl[q][0], pl[q][1]);
+    }
+    if (d.d_off < 0) return;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        tile[q][4 * tx + 0][ty] = (unsigned short)(pl[q][0] & 0xffffu);
+        tile[q][4 * tx + 1][ty] = (unsigned short)(pl[q][0] >> 16);
+        tile[q][4 * tx + 2][ty] = (unsigned short)(pl[q][1] & 0xffffu);
+        tile[q][4 * tx + 3][ty] = (unsigned short)(pl[q][1] >> 16);
+    }
+    __syncthreads();
+    const int cc = w.ct * 32 + ty;                   // this thread now owns input channel cc, rows rt*32 + 4tx .. +3
+    if (cc < d.C) {
+        const int64_t ldd = (int64_t)d.taps * d.Rp, ps = (int64_t)d.C * ldd;
+        unsigned short* o = planes + d.d_off + (int64_t)cc * ldd + (int64_t)w.tap * d.Rp + w.rt * 32 + 4 * tx;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned short* sr = &tile[q][ty][4 * tx];
+            *(uint2*)(o + q * ps) = make_uint2((unsigned)sr[0] | ((unsigned)sr[1] << 16), (unsigned)sr[2] | ((unsigned)sr[3] << 16));
+        }
+    }
+}
+}  // namespace
+
+extern "C" int koaf_wplanes_build(const float* base, uint16_t* planes, float* amax, const KoafWPlane* table_dev, int32_t n,
+                                  int64_t ntiles, void* stream) {
+    KOAF_REQUIRE(base && planes && amax && table_dev && n > 0 && ntiles > 0 && ntiles < (1ll << 31), "koaf_wplanes_build: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(amax, 0, sizeof(float) * (size_t)n, s) != hipSuccess) {
+        koaf_set_error("koaf_wplanes_build: memset failed");
+        return KOAF_ELAUNCH;
+    }
+    hipLaunchKernelGGL(wplanes_amax_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, base, table_dev, n, amax);
+    int rc = koaf_check_launch("koaf_wplanes_build/amax");
+    if (rc != KOAF_OK) return rc;
+    hipLaunchKernelGGL(wplanes_build_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, base, planes, table_dev, n, amax);
+    return koaf_check_launch("koaf_wplanes_build");
 }

@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..arena import deliver_grad, grad_target, packed_weight
+from ..arena import deliver_grad, grad_target, packed_weight, weight_planes
 from ._core_fes import BasicBlock, Bottleneck
 
 
@@ -52,7 +52,8 @@ def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None):
     wexp = None
     shift = _stat_shift(bn, train)
     if g == 1:
-        y, part = ops.conv2d_fwd(x, w, N, H, W, cin, cout, k, k, s, p, sc, sh, stats=train, shift=shift)
+        y, part = ops.conv2d_fwd(x, w, N, H, W, cin, cout, k, k, s, p, sc, sh, stats=train, shift=shift,
+                                 wimg=weight_planes(conv.weight))
     else:
         if k != 3 or p != 1 or cin != cout:
             raise NotImplementedError("grouped convolution other than the ResNeXt 3x3 is not built")
@@ -149,8 +150,11 @@ class _SideStream:
 
 
 def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True, side=None, bnb=None):
-    """weight gradient (x transformed on load by in_saved) and data gradient of one conv."""
+    """weight gradient (x transformed on load by in_saved) and data gradient of one conv.  dc comes out of a BatchNorm
+    backward (_bn_bwd*), which left max |dc| on the device (dc._koaf_amax): with it both contractions run on the fp16
+    scheme (koaf.h: KoafGemm.fmt 1)."""
     w = packed_weight(conv.weight)
+    amax = getattr(dc, "_koaf_amax", None)
     cin, cout = conv.in_channels, conv.out_channels
     k, s, p, g = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.groups
     sc, sh = (in_saved[2], in_saved[3]) if in_saved is not None else (None, None)
@@ -158,7 +162,7 @@ def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True,
 
     def wgrad():
         if g == 1:
-            ops.conv2d_wgrad(dc, x, gw, N, H, W, cin, cout, k, k, s, p, sc, sh)
+            ops.conv2d_wgrad(dc, x, gw, N, H, W, cin, cout, k, k, s, p, sc, sh, dy_amax=amax)
         else:
             dwexp = ops.gconv3x3_wgrad(dc, x, N, H, W, cin, s, sc, sh)
             ops.gconv_compress_dw(dwexp, gw, cin, g)
@@ -168,22 +172,28 @@ def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True,
     dx = None
     if need_dx:
         if g == 1:
-            dx = ops.conv2d_dgrad(dc, w, N, H, W, cin, cout, k, k, s, p, residual=residual, bnb=bnb)
+            dx = ops.conv2d_dgrad(dc, w, N, H, W, cin, cout, k, k, s, p, residual=residual, bnb=bnb,
+                                  wimg=weight_planes(conv.weight), dy_amax=amax)
         else:
             assert residual is None and bnb is None
             dx = ops.gconv3x3_dgrad(dc, wexp, N, H, W, cin, s)
     if side is not None:
         # enqueued BEHIND the sibling dgrad: the side stream starts this wgrad when the dgrad is done, so it
         # overlaps the HBM-bound BatchNorm backward of the next layer instead of fighting the dgrad for MFMAs
-        side.run((dc, x, in_saved), wgrad, conv.weight, gw, acc)
+        side.run((dc, x, in_saved, amax), wgrad, conv.weight, gw, acc)
     return dx
 
 
-def _bn_bwd(bn, g, c, saved, rows, mask_mode, ymask=None, dz_out=None, dc_out=None):
+def _bn_bwd(bn, g, c, saved, rows, mask_mode, ymask=None, dz_out=None, dc_out=None, amax=True):
+    """-> dc; with amax the device scalar max |dc| rides on the tensor object as dc._koaf_amax (see _conv_bwd)"""
     C = bn.num_features
     gg, ag = grad_target(bn.weight)
     gb, ab = grad_target(bn.bias)
-    dc = ops.bn_bwd(g, c, saved, rows, C, rows, gg, gb, mask_mode, ymask=ymask, dz_out=dz_out, dc_out=dc_out)
+    amax = amax and ops.CONV_F16
+    dc = ops.bn_bwd(g, c, saved, rows, C, rows, gg, gb, mask_mode, ymask=ymask, dz_out=dz_out, dc_out=dc_out, want_amax=amax)
+    if amax:
+        dc, a = dc
+        dc._koaf_amax = a
     deliver_grad(bn.weight, gg, ag)
     deliver_grad(bn.bias, gb, ab)
     return dc
@@ -194,7 +204,10 @@ def _bn_bwd_part(bn, part, nsum, i1, dz, c, saved, rows, dc_out=None):
     C = bn.num_features
     gg, ag = grad_target(bn.weight)
     gb, ab = grad_target(bn.bias)
-    dc = ops.bn_bwd_from_part(part, nsum, i1, dz, c, saved, rows, C, rows, gg, gb, dc_out=dc_out)
+    dc = ops.bn_bwd_from_part(part, nsum, i1, dz, c, saved, rows, C, rows, gg, gb, dc_out=dc_out, want_amax=ops.CONV_F16)
+    if ops.CONV_F16:
+        dc, a = dc
+        dc._koaf_amax = a
     deliver_grad(bn.weight, gg, ag)
     deliver_grad(bn.bias, gb, ab)
     return dc
@@ -443,7 +456,7 @@ class EncoderFn(torch.autograd.Function):
         c0 = S["c0"]
         if c0 is None:
             c0 = ops.stem_fwd(S["x"], ops.stem_fold_w(packed_weight(conv1.weight)), N, H, W)
-        dc0 = _bn_bwd(bn1, da0, c0, S["s0"], N * H1 * W1, 2, dc_out=da0)
+        dc0 = _bn_bwd(bn1, da0, c0, S["s0"], N * H1 * W1, 2, dc_out=da0, amax=False)    # (the stem is not a GEMM)
         gw, acc = grad_target(conv1.weight)
         ops.stem_wgrad(dc0, S["x"], gw, N, H, W)
         deliver_grad(conv1.weight, gw, acc)

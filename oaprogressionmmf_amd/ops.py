@@ -9,9 +9,15 @@ import ctypes
 
 import torch
 
-from ._lib import KoafBnb, KoafGemm, KoafError, check, lib
+from ._lib import KoafBnb, KoafGemm, KoafError, KoafWImg, check, lib
 
 _i32 = ctypes.c_int32
+
+# Convolutions run on the fp16 contraction scheme (koaf.h: KoafGemm.fmt 1) whenever their operands' scales are known
+# (weights: arena plane images; gradients: the amax the BatchNorm backward leaves behind).  KOAF_CONV_FMT=bf16 keeps them
+# on the bf16 x 3 scheme for A/B runs.
+import os
+CONV_F16 = os.environ.get("KOAF_CONV_FMT", "f16") != "bf16"
 
 # Optional live profiler (bench.py): when a list is installed here every MFMA-GEMM based call is bracketed
 # by two events recorded on the stream the kernel is launched on (torch's current stream) and logged as
@@ -50,6 +56,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _img(wimg):
+    """ctypes view of a weight's plane images: wimg = (F, D, amax) device tensors (F / D may be None) or None"""
+    if wimg is None:
+        return None
+    f, d, amax = wimg
+    for t in (f, d):
+        if t is not None and (not t.is_cuda or t.dtype != torch.int16):
+            raise KoafError("weight plane images are int16 (fp16 bit patterns) tensors on the HIP device")
+    return ctypes.byref(KoafWImg(f=f.data_ptr() if f is not None else None, d=d.data_ptr() if d is not None else None,
+                                 amax=_ptr(amax)))
+
+
 def _empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
 
@@ -61,9 +79,11 @@ def conv_out(h, k, s, p):
 # ------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------
-def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, stats=False, shift=None):
+def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, stats=False, shift=None, wimg=None):
     """x [N,H,W,Cin] (any view with that memory), w packed [Cout,KH,KW,Cin] -> y [N,OH,OW,Cout],
-    (part, rows) per-tile column statistics if stats, summed about `shift` [Cout] (hand the same tensor to bn_finalize)."""
+    (part, rows) per-tile column statistics if stats, summed about `shift` [Cout] (hand the same tensor to bn_finalize).
+    wimg = (F, D, amax) plane images of w (arena.weight_planes) or None: with them the contraction runs on the fp16
+    scheme (KoafGemm.fmt 1: half the matrix instructions, same accuracy), the weight tiles DMA'd from F."""
     L = lib()
     OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
     y = _empty((N, OH, OW, Cout), x)
@@ -73,8 +93,8 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
         part = _empty((nrows, 2, Cout), x)
     e0 = _prof_begin()
     check(L.koaf_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
-                            _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _ptr(shift) if stats else None, _stream()),
-          "conv2d_fwd")
+                            _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _ptr(shift) if stats else None,
+                            _img(wimg), _stream()), "conv2d_fwd")
     _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin, f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}",
               N * H * W * Cin + Cout * KH * KW * Cin + N * OH * OW * Cout)
     if stats:
@@ -82,10 +102,10 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     return y, part
 
 
-def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, bnb=None):
+def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, bnb=None, wimg=None, dy_amax=None):
     """dx = conv_transpose(dy, w) (+residual).  bnb = dict(mode, c, saved[, y][, c2, saved2]): fuse the
     BatchNorm(+ReLU)-backward reduction of the layer that produced x into the epilogue; then returns
-    (dz, part [rows][nsum][Cin]) instead of dx."""
+    (dz, part [rows][nsum][Cin]) instead of dx.  wimg + dy_amax (device scalar max |dy|, from bn_bwd*): fp16 scheme."""
     L = lib()
     dx = _empty((N, H, W, Cin), dy)
     fl = 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin
@@ -95,7 +115,7 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, 
     if bnb is None:
         e0 = _prof_begin()
         check(L.koaf_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
-                                  _ptr(residual), _stream()), "conv2d_dgrad")
+                                  _ptr(residual), _img(wimg), _ptr(dy_amax), _stream()), "conv2d_dgrad")
         _prof_end(e0, "gemm", fl, tag, el)
         return dx
     sv, sv2 = bnb["saved"], bnb.get("saved2")
@@ -107,21 +127,21 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, 
     rows = _i32(0)
     e0 = _prof_begin()
     check(L.koaf_conv2d_dgrad_bnb(_ptr(dy), _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
-                                  _ptr(residual), ctypes.byref(kb), _ptr(part), ctypes.addressof(rows), _stream()),
-          "conv2d_dgrad_bnb")
+                                  _ptr(residual), ctypes.byref(kb), _ptr(part), ctypes.addressof(rows), _img(wimg),
+                                  _ptr(dy_amax), _stream()), "conv2d_dgrad_bnb")
     el += N * H * W * Cin * (1 + (bnb.get("y") is not None) + (bnb.get("c2") is not None))
     _prof_end(e0, "gemm", fl, tag + " +bnb", el)
     return dx, part[:rows.value]
 
 
-def conv2d_wgrad(dy, x, dw, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None):
-    """writes dw (packed [Cout,KH,KW,Cin] memory)"""
+def conv2d_wgrad(dy, x, dw, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, dy_amax=None):
+    """writes dw (packed [Cout,KH,KW,Cin] memory); dy_amax (device scalar max |dy|): fp16 scheme"""
     L = lib()
     ws = L.koaf_conv2d_wgrad_ws(N, H, W, Cin, Cout, KH, KW, stride, pad)
     slabs = _empty((ws,), dy) if ws > 0 else None
     e0 = _prof_begin()
     check(L.koaf_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
-                              _ptr(in_sh), _ptr(slabs), _stream()), "conv2d_wgrad")
+                              _ptr(in_sh), _ptr(slabs), _ptr(dy_amax), _stream()), "conv2d_wgrad")
     _prof_end(e0, "gemm", 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin,
               f"conv_wgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}",
               N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout + N * H * W * Cin + Cout * KH * KW * Cin)
@@ -239,8 +259,9 @@ def bn_add_relu(c, saved, rows, C, idt=None, idsaved=None, out=None):
     return y
 
 
-def bn_bwd(g, c, saved, rows, C, count, dgamma, dbeta, mask_mode, ymask=None, dz_out=None, dc_out=None):
-    """Full BatchNorm(+ReLU mask) backward: returns dc.  g is the upstream gradient; with a mask the
+def bn_bwd(g, c, saved, rows, C, count, dgamma, dbeta, mask_mode, ymask=None, dz_out=None, dc_out=None, want_amax=False):
+    """Full BatchNorm(+ReLU mask) backward: returns dc -- or (dc, amax) with want_amax: amax = device scalar max |dc|, the
+    scale of dc as an operand of the fp16 contraction scheme.  g is the upstream gradient; with a mask the
     masked gradient dz is written to dz_out (default: in place over g)."""
     L = lib()
     if mask_mode != 0 and dz_out is None:
@@ -251,27 +272,29 @@ def bn_bwd(g, c, saved, rows, C, count, dgamma, dbeta, mask_mode, ymask=None, dz
                                _ptr(saved[1]), mask_mode, _ptr(dz_out), _ptr(part), ctypes.addressof(r), rows, C,
                                _stream()), "bn_bwd_reduce")
     coef = _empty((3, C), g)
+    amax = _empty((1,), g) if want_amax else None
     check(L.koaf_bn_bwd_finalize(_ptr(part), r.value, C, count, _ptr(saved[2]), _ptr(saved[1]), _ptr(dgamma),
-                                 _ptr(dbeta), _ptr(coef), 2, 1, _ptr(_reduce_ws(r.value, C, g)), _stream()),
+                                 _ptr(dbeta), _ptr(coef), 2, 1, _ptr(_reduce_ws(r.value, C, g)), _ptr(amax), _stream()),
           "bn_bwd_finalize")
     dz = dz_out if dz_out is not None else g
     dc = dc_out if dc_out is not None else torch.empty_like(c)
-    check(L.koaf_bn_bwd_apply(_ptr(dz), _ptr(c), _ptr(saved[0]), _ptr(coef), _ptr(dc), rows, C, _stream()),
+    check(L.koaf_bn_bwd_apply(_ptr(dz), _ptr(c), _ptr(saved[0]), _ptr(coef), _ptr(dc), rows, C, _ptr(amax), _stream()),
           "bn_bwd_apply")
-    return dc
+    return (dc, amax) if want_amax else dc
 
 
-def bn_bwd_from_part(part, nsum, i1, dz, c, saved, rows, C, count, dgamma, dbeta, dc_out=None):
+def bn_bwd_from_part(part, nsum, i1, dz, c, saved, rows, C, count, dgamma, dbeta, dc_out=None, want_amax=False):
     """BatchNorm backward when the reduction already happened in a dgrad epilogue: finalize + apply."""
     L = lib()
     coef = _empty((3, C), dz)
+    amax = _empty((1,), dz) if want_amax else None
     check(L.koaf_bn_bwd_finalize(_ptr(part), part.shape[0], C, count, _ptr(saved[2]), _ptr(saved[1]), _ptr(dgamma),
-                                 _ptr(dbeta), _ptr(coef), nsum, i1, _ptr(_reduce_ws(part.shape[0], C, dz)), _stream()),
-          "bn_bwd_finalize")
+                                 _ptr(dbeta), _ptr(coef), nsum, i1, _ptr(_reduce_ws(part.shape[0], C, dz)), _ptr(amax),
+                                 _stream()), "bn_bwd_finalize")
     dc = dc_out if dc_out is not None else torch.empty_like(c)
-    check(L.koaf_bn_bwd_apply(_ptr(dz), _ptr(c), _ptr(saved[0]), _ptr(coef), _ptr(dc), rows, C, _stream()),
+    check(L.koaf_bn_bwd_apply(_ptr(dz), _ptr(c), _ptr(saved[0]), _ptr(coef), _ptr(dc), rows, C, _ptr(amax), _stream()),
           "bn_bwd_apply")
-    return dc
+    return (dc, amax) if want_amax else dc
 
 
 def maxpool_fwd(c, saved, N, H, W, C):
@@ -319,12 +342,6 @@ def downscale2(x, B, R, Cc, S, fs):
 # ------------------------------------------------------------------------------------------------
 # transformer pieces
 # ------------------------------------------------------------------------------------------------
-def set_backward_precision(full):
-    """full=True: gradient contractions carry every significand bit; False: 16-bit operands (default); None: follow
-    KOAF_BWD_PRECISION.  Returns the previous setting (bool)."""
-    return bool(lib().koaf_set_backward_precision(-1 if full is None else int(bool(full))))
-
-
 def minmax(x, B):
     """per-sample (min, max) of a contiguous batch -> [B, 2]"""
     n = x.numel() // B
@@ -471,6 +488,24 @@ def focal_loss(logits, target, gamma, mean=True, focal=True):
 def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, adamw=False):
     check(lib().koaf_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, b1, b2, eps, wd, step, 1 if adamw else 0,
                                _stream()), "adam_step")
+
+
+def build_weight_planes(w, R, taps, C):
+    """(F, D, amax) fp16 plane images (int16 tensors) + device scalar max |w| of ONE weight w [R][taps][C] (packed conv
+    weight): what arena.ParamArena keeps for every convolution weight of a model, for callers without an arena (tests,
+    micro-benchmarks)."""
+    from ._lib import KoafWPlane
+    Kp, Rp = (taps * C + 31) // 32 * 32, (R + 31) // 32 * 32
+    nf, nd = 2 * R * Kp, 2 * C * taps * Rp
+    d_off = (nf + 63) // 64 * 64
+    planes = torch.zeros(d_off + nd, device=w.device, dtype=torch.int16)
+    amax = torch.zeros(1, device=w.device, dtype=torch.float32)
+    ent = KoafWPlane(src_off=0, f_off=0, d_off=d_off, tile0=0, R=R, taps=taps, C=C, Kp=Kp, Rp=Rp)
+    tab = torch.frombuffer(bytearray(bytes(ent)), dtype=torch.uint8).to(w.device)
+    ntiles = ((R + 31) // 32) * taps * ((C + 31) // 32)
+    check(lib().koaf_wplanes_build(_ptr(w), planes.data_ptr(), _ptr(amax), tab.data_ptr(), 1, ntiles, _stream()),
+          "wplanes_build")
+    return planes[:nf], planes[d_off:d_off + nd], amax
 
 
 def gemm(desc: KoafGemm):

@@ -62,6 +62,7 @@ class Adam(optim.Optimizer):
                     for lo, hi in a.active_ranges(ps):
                         ops.adam_step(a.P[lo:hi], a.G[lo:hi], stt["m"][lo:hi], stt["v"][lo:hi], hi - lo, lr, b1, b2,
                                       eps, wd, n, self._ADAMW)
+                a.epoch += 1             # the weights changed under the arena's plane images (arena.ensure_planes)
         return loss
 
     def _arena_state(self, a):
