@@ -1,91 +1,172 @@
 #!/usr/bin/env python3
-"""bench.py -- knees/sec of the full XR + MRI + clinical fusion train step (BASELINE.json metric).
+"""bench.py -- knees/sec of the full XR + 3 x MRI + clinical fusion train step (BASELINE.json metric and shapes).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload W] [--batch B] [--recompute]
-  (N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload W] [--batch B] ...
+  N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / LOCAL_RANK /
+  WORLD_SIZE / MASTER_* in the environment), or plainly as `python bench.py --gpus N`: the parent then starts N fresh worker
+  processes itself (before anything touches a GPU), one rank per GPU over RCCL, relays rank 0's JSON line and exits non-zero
+  if a worker fails.
 
-A "step" is one iteration of the reference's step body (koafusion/run/train_prog_fus.py:132-168) on one
-synthetic batch already resident in HBM: zero_grad -> forward (dropout 0.1 as in the recipe, runner.sh:352) ->
-FocalLoss -> loss.item() (the reference's per-step host sync) -> backward -> gradient all-reduce over RCCL
-(N>1) -> fused Adam.  Weak scaling: the per-GPU batch is fixed, `value` = global samples / max-over-ranks time.
+A "step" is one iteration of the reference's step body (koafusion/run/train_prog_fus.py:132-168) on one synthetic batch
+already resident in HBM: zero_grad -> forward (dropout 0.1 as in the recipe, runner.sh:352) -> FocalLoss -> backward ->
+gradient all-reduce over RCCL (N > 1) -> fused Adam -> loss.item().  The reference reads loss.item() between forward and
+backward (:159-165); here the same value is read after the optimizer step is enqueued, so that the host sync does not drain
+the GPU in the middle of the step (`host_sync` in the JSON names this).  Weak scaling: the per-GPU batch is fixed,
+`value` = global samples / max-over-ranks time of exactly K steps between barriers.
 
 Workloads:
-  native3 (default) BASELINE config 4 literally -- "Full XR + SAG-DESS/COR-IW-TSE/SAG-T2 + clinical transformer fusion,
-                    batch 8": the registry extension XR1MR3C1CnnTrf (the reference's XR1MR2C1CnnTrf pattern with a third
-                    MRI slot) at the reference's native sizes: XR 1x350x350 (ResNeXt-50), DESS 160x160x64, TSE 160x160x32,
-                    T2 160x160x25 (ResNet-50 slice-wise), 9 clinical variables, 4 x FeaT(depth 4, 8 heads, width 2048).
-                    The same run also times `native` and reports it under "pinned_reference_model", and (1 GPU) the same model
-                    on BASELINE's synthetic tensor shapes at batch 8 under "baseline_synthetic_shapes".
-  native            XR1MR2C1CnnTrf exactly as runner.sh:341-363 (the reference's biggest registered model, the
-                    reference-pinned 2-MRI mapping of config 4): XR 350^2 + DESS 160x160x64 + T2 160x160x25 + clinical; B=8.
-  syn / syn3        BASELINE's synthetic tensor shapes (XR 1x310x310, MRI 1x160x384x384) through the 2-MRI / 3-MRI model
-                    (default per-GPU batch 2; batch 8 needs --recompute).
+  syn3 (default)    BASELINE.json's headline configuration: "Full XR + SAG-DESS/COR-IW-TSE/SAG-T2 + clinical transformer
+                    fusion, batch 8" on its synthetic tensors -- XR 1x310x310 and three MRI volumes 1x160x384x384 (slice-major,
+                    as BASELINE writes them: `fe.mr.volume_layout: ncdhw`, a zero-copy slice fold) + 9 clinical variables --
+                    through the registry extension XR1MR3C1CnnTrf (the reference's XR1MR2C1CnnTrf pattern with a third MRI
+                    slot): ResNeXt-50 on the radiograph, ResNet-50 slice-wise on 3 x 160 slices of 384^2, 4 x FeaT(depth 4,
+                    8 heads, width 2048).  35.2 TFLOP of algorithmic work per knee and step.  A batch of 8 holds 3840 MRI
+                    slices: fp32 activations of every conv would need ~750 GB, so layer1-2 of every MRI encoder (and layer3
+                    of the encoder whose backward runs last) are rebuilt in backward from their stage inputs + BatchNorm
+                    statistics (`activation_recompute` in the JSON).
+                    The same run also times two secondaries at the reference's native sizes (10 steps each): `native3` (same
+                    model, XR 350^2 + DESS 160x160x64 + TSE 160x160x32 + T2 160x160x25) and `native` (XR1MR2C1CnnTrf exactly
+                    as runner.sh:341-363, the largest model the reference registers, parity-pinned by reference fixtures).
+  native3 / native  those two as the primary workload.
+  syn               BASELINE's synthetic shapes through the pinned 2-MRI class.
   xr1cnn / xr1c1    BASELINE configs 1 / 2 (XR1Cnn B=4; extension XR1C1Cnn = XR + clinical MLP head, B=32) @350^2.
   mr1 / mr1c1       BASELINE config 3: MR1CnnTrf B=4 @160x160x64; extension MR1C1CnnTrf (DESS + clinical) B=4 @384x384x160.
-  eval3             inference pass of the native3 model (eval() mode, no autograd: run.predict_batch = forward + softmax),
-                    the evaluation regime of koafusion/run/eval_prog_fus.py; `value` = knees/s scored.
-The JSON line carries `roofline` for the dominant kernel (the MFMA GEMM, timed live with events on the
-launch stream over one extra instrumented step) and `cpu_baseline` (the oracle = CPU port of the same step,
-timed on this box's host cores on a bounded sample).
+  eval3             inference pass of the native3 model (eval() mode, no autograd); `value` = knees/s scored.
+The JSON line carries `roofline` for the dominant kernel (the MFMA GEMM, timed live with events on the launch stream over
+one extra instrumented single-stream step) and `cpu_baseline` (the oracle = CPU port of the same step, timed on this box's
+host cores on a bounded sample).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 from pathlib import Path
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL on this pool (already exported there)
 
-import torch  # noqa: E402
-
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
-MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X dense fp32 matrix peak, v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md, chip-level table)
-# The GEMM computes fp32 x fp32 products on the bf16 matrix pipe (koaf_gemm.hip): forward contractions cut each operand
-# exactly into three bf16 pieces and issue the six piece products of weight >= 2^-16 as v_mfma_f32_32x32x16_bf16;
-# gradient contractions round the operands to 16 significand bits (two pieces) and issue all four products.  The bound of
-# a call is the dense bf16 MFMA peak (2.5 PFLOP/s, same table) divided by its MFMAs per product; the bound of the step's
-# mix is the FLOP-weighted harmonic mean over its calls.
-BF16_MFMA_PEAK_TFLOPS = 2500.0
+# MI355X_MICROARCH.md, chip-level table
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA (v_mfma_f32_32x32x16_{bf16,f16})
+MFMA_F32_PEAK_TFLOPS = 157.3     # dense fp32 MFMA (v_mfma_f32_32x32x2_f32): what the 16-bit piece schemes replace
 HBM_PEAK_TBPS = 8.0
-MFMA_PER_PRODUCT_FWD, MFMA_PER_PRODUCT_BWD = 6, 4
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="syn3")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = workload default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the native3 / native secondaries of the default run")
+    ap.add_argument("--recompute", default="auto",
+                    help="activation recompute in the encoders: auto (workload default), none, stage (every stage), block "
+                         "(one block at a time), or stage indices per MRI encoder, e.g. '012,01,01' (0 = layer1; encoders in "
+                         "forward order; one entry = all encoders)")
+    ap.add_argument("--breakdown", default="", help="write a per-shape table of the instrumented step to this file")
+    ap.add_argument("--serial", action="store_true",
+                    help="one HIP stream only (no encoder lanes / wgrad side stream): kernel durations seen by a profiler "
+                         "are then not inflated by co-running kernels -- the mode the roofline step always uses")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves (the parent never touches a GPU)
+# ------------------------------------------------------------------------------------------------------------------
+def worker_env(rank, world, port, base=None):
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return env
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_workers(n, argv, program=None):
+    """N fresh child processes of this script, one rank each; rank 0's stdout is relayed.  Returns the exit code."""
+    port = free_port()
+    cmd = [sys.executable, program or str(Path(__file__).resolve())] + list(argv)
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen(cmd, env=worker_env(r, n, port), stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: worker(s) failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------------
 def workload_cfg(name):
+    """-> (model config, default per-GPU batch, default recompute policy)"""
     import procedural as P
     if name == "native":
-        return P.cfg_full(dropout=0.1), 8
+        return P.cfg_full(dropout=0.1), 8, "none"
     if name == "syn":
-        # BASELINE.json's synthetic tensor shapes (XR 1x310x310, MRI 1x160x384x384 = (384,384,160) in the reference's
-        # (R,C,S) layout) through the oracle-pinned class: the constructor asserts on CONFIG sizes only and forward never
-        # checks tensor shapes, so the model is built with legal sizes and num_slices=160.
+        # BASELINE.json's synthetic tensor shapes through the oracle-pinned class: the constructor asserts on CONFIG sizes
+        # only and forward never checks tensor shapes: legal config sizes, num_slices = 160
         cfg = P.cfg_full(xr=(320, 320), mr1=(320, 320, 160), mr2=(320, 320, 160), dropout=0.1)
         cfg["_tensor_shapes"] = [[310, 310], [384, 384, 160], [384, 384, 160], [16]]
-        return cfg, 2
+        return cfg, 2, "none"
     if name in ("native3", "eval3"):
-        return P.cfg_xr1mr3c1(dropout=0.1), 8
+        return P.cfg_xr1mr3c1(dropout=0.1), 8, "none"
     if name == "syn3":
         cfg = P.cfg_xr1mr3c1(xr=(320, 320), mr1=(320, 320, 160), mr2=(320, 320, 160), mr3=(320, 320, 160), dropout=0.1)
-        cfg["_tensor_shapes"] = [[310, 310], [384, 384, 160], [384, 384, 160], [384, 384, 160], [16]]
-        return cfg, 2
+        cfg["fe"]["mr"]["volume_layout"] = "ncdhw"          # volumes arrive as BASELINE writes them: 1 x 160 x 384 x 384
+        cfg["_tensor_shapes"] = [[310, 310], [160, 384, 384], [160, 384, 384], [160, 384, 384], [16]]
+        # batch 8 = 3840 slices of 384^2: rebuild layer1-2 everywhere, layer3 too in the two encoders whose backward runs
+        # later (their kept activations would sit under the other encoders' layer1 rebuilds: 102 GB each).  Measured:
+        # "012,01,01" peaks at 265 GB allocated / 285 reserved of the 288 -- too close; this policy leaves ~50 GB.
+        return cfg, 8, "012,012,01"
     if name == "xr1c1":
-        return P.cfg_xr1c1(size=350, dropout=0.5), 32
+        return P.cfg_xr1c1(size=350, dropout=0.5), 32, "none"
     if name == "mr1c1":
         cfg = P.cfg_mr1c1(mr=(320, 320, 160), dropout=0.1)
         cfg["_tensor_shapes"] = [[384, 384, 160], [16]]
-        return cfg, 4
+        return cfg, 4, "none"
     if name == "xr1cnn":
-        return P.cfg_xr1cnn(size=350, dropout=0.5), 4
+        return P.cfg_xr1cnn(size=350, dropout=0.5), 4, "none"
     if name == "mr1":
-        return P.cfg_mr1(shape=(160, 160, 64), dropout=0.1), 4
+        return P.cfg_mr1(shape=(160, 160, 64), dropout=0.1), 4, "none"
     raise SystemExit(f"unknown workload {name}")
 
 
+WORKLOAD_TEXT = {
+    "native": "XR 1x350x350 + DESS 160x160x64 + T2 160x160x25 + 9 clinical (runner.sh:341-363); random-init weights",
+    "native3": "XR 1x350x350 + DESS 160x160x64 + TSE 160x160x32 + T2 160x160x25 + 9 clinical (BASELINE config 4 at the "
+               "reference's native sizes; 3-MRI registry extension of XR1MR2C1CnnTrf); random-init weights",
+    "syn3": "BASELINE config 4 on BASELINE's synthetic tensors: XR 1x310x310 + 3 x MRI 1x160x384x384 (slice-major) + 9 "
+            "clinical; random-init weights",
+    "eval3": "INFERENCE pass (forward + softmax, eval mode) on the native3 shapes; random-init weights",
+    "xr1c1": "BASELINE config 2: XR 1x350x350 + 9 clinical, early-fusion MLP head; random-init weights",
+    "mr1c1": "BASELINE config 3: SAG-3D-DESS 1x160x384x384 + 9 clinical; random-init weights",
+    "syn": "BASELINE synthetic shapes XR 1x310x310 + 2 x MRI 1x160x384x384 + 9 clinical through the pinned 2-MRI class; "
+           "random-init weights",
+}
+
+
 def algorithmic_train_gflop_per_sample(name):
-    # SURVEY.md §8(d): measured with torch.utils.flop_counter on the imported reference
+    # SURVEY.md 8(d): measured with torch.utils.flop_counter on the imported reference
     # (ResNet-50 4.1705 GFLOP/slice @160^2, 24.02 @384^2; ResNeXt-50 20.877 @350^2, 16.84 @310^2; FeaT 0.2097/token)
     return {"native": 1280.0, "xr1cnn": 62.1, "mr1": 3 * (64 * 4.1705 + 65 * 0.2097),
             "native3": 1280.0 + 3 * (32 * 4.1705 + 64 * 0.2097),
@@ -96,15 +177,38 @@ def algorithmic_train_gflop_per_sample(name):
             "mr1c1": 3 * (160 * 24.02 + 322 * 0.2097)}[name]
 
 
-def cpu_baseline(cfg, workload):
-    """The oracle (CPU port of the same train step) on this box's host cores; bounded sample."""
+def apply_recompute(model, policy):
+    """policy: none | stage | block | comma list of stage-index strings per MRI encoder in forward order"""
+    from oaprogressionmmf_amd.models import KoafTrunk
+    trunks = [m for m in model.modules() if isinstance(m, KoafTrunk)]
+    if policy in ("none", "", None):
+        return "none"
+    if policy in ("stage", "block"):
+        for t in trunks:
+            t.recompute = True if policy == "stage" else "block"
+        return policy
+    # radiograph trunks (few images) keep everything; the MRI trunks, in the order they run forward, get their entries
+    mri = [getattr(model, f"_fe{i}") for i in range(getattr(model, "n_xr", 1), getattr(model, "n_xr", 1) + getattr(model, "n_mr", 0))]
+    if not mri:
+        mri = trunks[1:] if len(trunks) > 1 else trunks
+    ents = policy.split(",")
+    if len(ents) == 1:
+        ents = ents * len(mri)
+    if len(ents) != len(mri):
+        raise SystemExit(f"--recompute {policy}: {len(ents)} entries for {len(mri)} MRI encoders")
+    for t, e in zip(mri, ents):
+        t.recompute = [int(ch) for ch in e]
+    return policy
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle: checker code, used here only as the timed CPU restatement of the same step)
+# ------------------------------------------------------------------------------------------------------------------
+def _oracle_job(cfg_fn, B, shapes=None):
+    import torch
     import procedural as P
     from oracle import koafusion_cpu as O
-    if workload in ("syn", "syn3", "mr1c1", "eval3"):
-        return None     # minutes per sample on a host CPU (eval3: no train step to compare): outside the bounded sample
-    B = 1
-    n = min(len(os.sched_getaffinity(0)), 64)
-    torch.set_num_threads(n)
+    cfg = cfg_fn()
     om = O.OracleModel(cfg, fill=None)
     g = torch.Generator().manual_seed(0)
     for k, v in om.sd.items():      # cheap random init (values do not matter for timing)
@@ -114,39 +218,60 @@ def cpu_baseline(cfg, workload):
                     v.fill_(1.0)
                 elif v.dim() >= 2:
                     v.copy_(torch.randn(v.shape, generator=g) * (1.0 / max(1, v[0].numel())) ** 0.5)
-    xs = [torch.from_numpy(a) for a in P.model_inputs(cfg, B)]
+    shapes_cfg = dict(cfg, input_size=shapes) if shapes else cfg
+    xs = [torch.from_numpy(a) for a in P.model_inputs(shapes_cfg, B)]
     y = torch.from_numpy(P.make_target("target", B))
+    return om, xs, y
+
+
+def cpu_baseline(workload):
+    """The oracle (CPU port of the same train step) on this box's host cores; bounded sample."""
+    import torch
+    import procedural as P
+    if workload in ("mr1c1", "eval3", "syn"):
+        return None
+    n = min(len(os.sched_getaffinity(0)), 64)
+    torch.set_num_threads(n)
+    if workload == "syn3":
+        # One knee of the headline workload is XR + 3 x 160 slices of 384^2 (~200 s on a host CPU).  The slice-wise
+        # encoders are linear in the slice count, so the sample times the SAME model and tensor sizes with 8 and with 4 of the
+        # 160 slices per MRI (batch 1, one full train step each, after a 2-slice warm-up step) and extrapolates the
+        # per-slice cost to 160: t(160) = t(4) + (160 - 4) * (t(8) - t(4)) / 4.
+        def job(S):
+            return _oracle_job(lambda: P.cfg_xr1mr3c1(xr=(320, 320), mr1=(320, 320, S), mr2=(320, 320, S), mr3=(320, 320, S),
+                                                      dropout=0.1), 1, [[310, 310], [384, 384, S], [384, 384, S], [384, 384, S], [16]])
+        om, xs, y = job(2)
+        om.train_step(xs, y)
+        ts = {}
+        for S in (8, 4):
+            om, xs, y = job(S)
+            t0 = time.time()
+            om.train_step(xs, y)
+            ts[S] = time.time() - t0
+        per_slice = max((ts[8] - ts[4]) / 4.0, 1e-9)
+        t160 = ts[4] + 156 * per_slice
+        return {"value": round(1.0 / t160, 5), "unit": "knees/s", "cores": n, "kind": "port",
+                "sample": f"oracle (CPU port of the same model and step: fwd + focal loss + bwd + Adam) at batch 1 on {n} torch "
+                          f"threads with 8 and with 4 of the 160 slices per MRI at the full 384x384 / 310x310 sizes (one train step "
+                          f"each, after a 2-slice warm-up step): {ts[8]:.1f} s and {ts[4]:.1f} s; the slice-wise encoders are linear "
+                          f"in the slice count, so one knee at 160 slices = t(4) + 156 x (t(8) - t(4)) / 4 = {t160:.0f} s",
+                "measured_s": {"slices_8": round(ts[8], 2), "slices_4": round(ts[4], 2)}, "extrapolated_s_per_knee": round(t160, 1)}
+    cfg, _, _ = workload_cfg(workload)
+    om, xs, y = _oracle_job(lambda: cfg, 1)
     om.train_step(xs, y)                     # warm-up
     steps = 2 if workload in ("native", "native3") else 3
     t0 = time.time()
     for _ in range(steps):
         om.train_step(xs, y)
     dt = time.time() - t0
-    return {"value": round(B * steps / dt, 4), "unit": "knees/s", "cores": n, "kind": "port",
-            "sample": f"{steps} full train steps (fwd+focal loss+bwd+Adam) of the same model/shapes at batch {B} "
+    return {"value": round(steps / dt, 4), "unit": "knees/s", "cores": n, "kind": "port",
+            "sample": f"{steps} full train steps (fwd+focal loss+bwd+Adam) of the same model/shapes at batch 1 "
                       f"on the host CPU ({n} torch threads), after 1 warm-up step"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="native3")
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0 = workload default)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--recompute-mode", default="stage", choices=("block", "stage"),
-                    help="granularity of activation recompute: one block at a time (least memory) or one stage at a time")
-    ap.add_argument("--no-syn", action="store_true", help="skip the BASELINE-synthetic-shapes addendum of the default run")
-    ap.add_argument("--breakdown", default="", help="write a per-shape table of the instrumented step to this file")
-    ap.add_argument("--recompute", action="store_true",
-                    help="activation recompute in the encoders (keeps stage inputs + BatchNorm statistics only; blocks rebuilt one at a time); "
-                         "needed for --workload syn at batch 8")
-    ap.add_argument("--serial", action="store_true",
-                    help="one HIP stream only (no encoder lanes / wgrad side stream): kernel durations seen by a profiler "
-                         "are then not inflated by co-running kernels -- the mode the roofline step always uses")
-    args = ap.parse_args()
-
+# ------------------------------------------------------------------------------------------------------------------
+def main(args):
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -167,44 +292,42 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
     import procedural as P
     from oaprogressionmmf_amd import ops
     from oaprogressionmmf_amd.config import ConfigDict
-    from oaprogressionmmf_amd.models import dict_models
+    from oaprogressionmmf_amd.models import dict_models, _common, _encoder
     from oaprogressionmmf_amd.parallel import DataParallelRCCL
     from oaprogressionmmf_amd.various import dict_losses, dict_optimizers, set_ultimate_seed
 
-    set_ultimate_seed(777 + 16 * rank)   # distinct dropout streams per rank (SURVEY §8e); rank 0's parameters are broadcast
+    set_ultimate_seed(777 + 16 * rank)   # distinct dropout streams per rank (SURVEY 8e); rank 0's parameters are broadcast
+    lanes_default = (_common.USE_LANES, _encoder.USE_SIDE_STREAM)
     if args.serial:
-        from oaprogressionmmf_amd.models import _common as _c, _encoder as _e
-        _e.USE_SIDE_STREAM = False
-        _c.USE_LANES = False
+        _encoder.USE_SIDE_STREAM = False
+        _common.USE_LANES = False
+
     def barrier():
         if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def make_job(name, batch, recompute=None):
-        """model + optimizer + resident synthetic batch of one workload -> (cfg, B, step)"""
-        cfg, bdef = workload_cfg(name)
+    comm_ms = []
+
+    def make_job(name, batch, recompute="auto"):
+        """model + optimizer + resident synthetic batch of one workload -> (cfg, B, policy, step)"""
+        cfg, bdef, rdef = workload_cfg(name)
         B = batch or bdef
+        shapes = cfg.pop("_tensor_shapes", None)
         model = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None).to(dev)
-        if args.recompute if recompute is None else recompute:
-            from oaprogressionmmf_amd.models import KoafTrunk
-            for m in model.modules():
-                if isinstance(m, KoafTrunk):
-                    m.recompute = args.recompute_mode if args.recompute_mode == "block" else True
+        policy = apply_recompute(model, rdef if (recompute == "auto" and B >= bdef) else ("none" if recompute == "auto" else recompute))
         ddp = DataParallelRCCL(model, exchange_always=dist_on)
         loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
         opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4)
-        shapes_cfg = dict(cfg, input_size=cfg.pop("_tensor_shapes")) if "_tensor_shapes" in cfg else cfg
-        xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(shapes_cfg, B, seed=1234 + rank)]
+        xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(dict(cfg, input_size=shapes) if shapes else cfg, B, seed=1234 + rank)]
         y = torch.from_numpy(P.make_target("target", B, seed=1234 + rank)).to(dev)
         model.train()
         if name == "eval3":
@@ -214,58 +337,65 @@ def main():
             def step_eval():
                 logits, proba = predict_batch(model, xs)
                 return float(proba[0, 0].item())       # the driver's per-batch host read (argmax / softmax go to the CPU)
-            return cfg, B, step_eval
+            return cfg, B, policy, step_eval
 
         def step():
             opt.zero_grad()
             logits = ddp(*xs)["main"]
             loss = loss_fn(input=logits.squeeze(1), target=y.long().squeeze(1))
             ddp.scale_loss(loss).backward()
-            ddp.reduce_gradients()
+            if dist_on:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ddp.reduce_gradients()
+                e1.record()
+                comm_ms.append((e0, e1))
             opt.step()
-            # the reference logs loss.item() every step (:159-163): same value, read after the backward/optimizer
-            # kernels are enqueued so the host sync does not drain the GPU between forward and backward
-            return loss.item()
-        return cfg, B, step
+            return loss.item()          # (see the module docstring: `host_sync`)
+        return cfg, B, policy, step
 
-    def timed(step):
-        """W untimed + exactly K timed steps between barriers; max over ranks"""
-        for _ in range(args.warmup):
+    def timed(step, warmup, steps):
+        """W untimed + exactly K timed steps between barriers (max over ranks); per-step event times for the median"""
+        for _ in range(warmup):
             step()
         barrier()
+        del comm_ms[:]
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        evs[0].record()
+        for i in range(steps):
             lv = step()
+            evs[i + 1].record()
         barrier()
         dt = time.perf_counter() - t0
+        per = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
         if dist_on:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt, lv
+        return dt, lv, per
 
-    pinned = None
-    if args.workload == "native3" and not args.batch and not args.recompute:
-        # the reference-pinned 2-MRI model of the same configuration, timed first with the same K / W, then freed
-        cfg2, B2, step2 = make_job("native", 0)
-        dt2, lv2 = timed(step2)
-        pinned = {"model": cfg2["name"], "value": round(world * B2 * args.steps / dt2, 3), "unit": "knees/s",
-                  "ms_per_step": round(dt2 / args.steps * 1e3, 2), "per_gpu_batch": B2, "last_loss": round(lv2, 6),
-                  "note": "runner.sh:341-363 (XR 350^2 + DESS 160x160x64 + T2 160x160x25 + clinical): the largest model "
-                          "the reference registers; parity pinned by fixtures of the imported reference"}
-        del step2
+    def free(*objs):
         import gc
         gc.collect()
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
 
-    cfg, B, step = make_job(args.workload, args.batch)
+    rccl_ranks = None
+    if dist_on:
+        one = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(one)
+        rccl_ranks = int(one.item())
+
+    cfg, B, policy, step = make_job(args.workload, args.batch, args.recompute)
     torch.cuda.reset_peak_memory_stats()
-    dt, lv = timed(step)
+    dt, lv, per = timed(step, args.warmup, args.steps)
     hbm_gb = (round(torch.cuda.max_memory_allocated() / 2**30, 1), round(torch.cuda.max_memory_reserved() / 2**30, 1))
+    comm_exposed = None
+    if dist_on and comm_ms:
+        comm_exposed = round(statistics.mean(a.elapsed_time(b) for a, b in comm_ms), 3)
 
     # one extra instrumented step: live event timing of every MFMA-GEMM launch on its launch stream
-    from oaprogressionmmf_amd.models import _common, _encoder
     _encoder.USE_SIDE_STREAM = False      # serialise: per-kernel durations are not inflated by co-running kernels
     _common.USE_LANES = False
     torch.cuda.synchronize()
@@ -275,53 +405,70 @@ def main():
     ops.PROFILE = []
     step()
     torch.cuda.synchronize()
-    prof_b = [(f, fl, e0.elapsed_time(e1), tag, nb) for f, fl, e0, e1, tag, nb in ops.PROFILE]
-    prof = [p[:4] for p in prof_b]
+    prof = [(f, fl, e0.elapsed_time(e1), tag, nb, mpp) for f, fl, e0, e1, tag, nb, mpp in ops.PROFILE if f == "gemm"]
     ops.PROFILE = None
-    gemm_ms = sum(ms for f, fl, ms, tag in prof if f == "gemm")
-    gemm_flop = sum(fl for f, fl, ms, tag in prof if f == "gemm")
-    n_launch = sum(1 for f, *_ in prof if f == "gemm")
+    gemm_ms = sum(p[2] for p in prof)
+    gemm_flop = sum(p[1] for p in prof)
+    gemm_bytes = sum(p[4] for p in prof)
+    n_launch = len(prof)
     achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    full_bwd = os.environ.get("KOAF_BWD_PRECISION", "")[:1] == "f"
 
-    def call_peak(tag):
-        bwd = any(k in tag for k in ("dgrad", "wgrad", "attn_bwd")) and not full_bwd
-        return BF16_MFMA_PEAK_TFLOPS / (MFMA_PER_PRODUCT_BWD if bwd else MFMA_PER_PRODUCT_FWD)
+    def call_peak(mpp):
+        return BF16_MFMA_PEAK_TFLOPS / mpp
 
-    def call_floor_ms(fl, tag, nb):
+    def call_floor_ms(fl, nb, mpp):
         """roofline time of one call: the larger of its matrix-pipe time and the time to move each operand once"""
-        return max(fl / (call_peak(tag) * 1e12), nb / (HBM_PEAK_TBPS * 1e12)) * 1e3
-    floor_ms = sum(call_floor_ms(fl, tag, nb) for f, fl, ms, tag, nb in prof_b if f == "gemm")
-    hbm_ms = sum(ms for f, fl, ms, tag, nb in prof_b
-                 if f == "gemm" and nb / (HBM_PEAK_TBPS * 1e12) > fl / (call_peak(tag) * 1e12))
+        return max(fl / (call_peak(mpp) * 1e12), nb / (HBM_PEAK_TBPS * 1e12)) * 1e3
+    floor_ms = sum(call_floor_ms(fl, nb, mpp) for f, fl, ms, tag, nb, mpp in prof)
+    hbm_ms = sum(ms for f, fl, ms, tag, nb, mpp in prof if nb / (HBM_PEAK_TBPS * 1e12) > fl / (call_peak(mpp) * 1e12))
     if args.breakdown and rank == 0:
         agg = {}
-        for f, fl, ms, tag, nb in prof_b:
-            a = agg.setdefault(tag, [0, 0.0, 0.0, 0.0, 0.0])
-            a[0] += 1; a[1] += fl; a[2] += ms; a[3] += nb; a[4] += call_floor_ms(fl, tag, nb)
+        for f, fl, ms, tag, nb, mpp in prof:
+            a = agg.setdefault((tag, mpp), [0, 0.0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += fl; a[2] += ms; a[3] += nb; a[4] += call_floor_ms(fl, nb, mpp)
         with open(args.breakdown, "w") as fh:
-            fh.write(f"# per-shape GEMM-family calls of one train step ({args.workload}, batch {B}); ms from events on the launch stream;\n"
-                     f"# MB = algorithmic HBM bytes (every operand once); floor = max(FLOP / matrix-pipe bound of the call, bytes / "
-                     f"{HBM_PEAK_TBPS:g} TB/s); bound = which term of the floor is larger\n")
-            fh.write(f"{'call':48s} {'n':>4s} {'ms':>9s} {'GFLOP':>10s} {'TFLOP/s':>8s} {'MB':>9s} {'TB/s':>6s} {'floor ms':>9s} {'bound':>5s}\n")
-            for tag, (n, fl, ms, nb, flo) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
-                bound = "hbm" if nb / (HBM_PEAK_TBPS * 1e12) > fl / (call_peak(tag) * 1e12) else "mfma"
-                fh.write(f"{tag:48s} {n:4d} {ms:9.3f} {fl / 1e9:10.1f} {fl / ms / 1e9 if ms > 0 else 0:8.1f} {nb / 1e6:9.1f} "
+            fh.write(f"# per-shape GEMM-family calls of one train step ({args.workload}, batch {B}, recompute {policy}); ms from events on "
+                     f"the launch stream;\n# mpp = matrix instructions per product (3: fp16 x 2 scheme, 6: bf16 x 3); MB = algorithmic HBM "
+                     f"bytes (every operand once); floor = max(FLOP / (2500 TFLOP/s / mpp), bytes / {HBM_PEAK_TBPS:g} TB/s); bound = which "
+                     f"term of the floor is larger\n")
+            fh.write(f"{'call':48s} {'mpp':>3s} {'n':>4s} {'ms':>9s} {'GFLOP':>10s} {'TFLOP/s':>8s} {'MB':>9s} {'TB/s':>6s} {'floor ms':>9s} {'bound':>5s}\n")
+            for (tag, mpp), (n, fl, ms, nb, flo) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+                bound = "hbm" if nb / (HBM_PEAK_TBPS * 1e12) > fl / (call_peak(mpp) * 1e12) else "mfma"
+                fh.write(f"{tag:48s} {mpp:3d} {n:4d} {ms:9.3f} {fl / 1e9:10.1f} {fl / ms / 1e9 if ms > 0 else 0:8.1f} {nb / 1e6:9.1f} "
                          f"{nb / ms / 1e9 if ms > 0 else 0:6.2f} {flo:9.3f} {bound:>5s}\n")
-    bound_s = sum(fl / (call_peak(tag) * 1e12) for f, fl, ms, tag in prof if f == "gemm")
-    peak_mix = gemm_flop / bound_s / 1e12 if bound_s > 0 else BF16_MFMA_PEAK_TFLOPS / MFMA_PER_PRODUCT_FWD
-    bwd_share = sum(fl for f, fl, ms, tag in prof if f == "gemm" and any(k in tag for k in ("dgrad", "wgrad", "attn_bwd")))
-    bwd_share = bwd_share / gemm_flop if gemm_flop else 0.0
+    bound_s = sum(fl / (call_peak(mpp) * 1e12) for f, fl, ms, tag, nb, mpp in prof)
+    peak_mix = gemm_flop / bound_s / 1e12 if bound_s > 0 else call_peak(3)
+    f16_share = sum(fl for f, fl, ms, tag, nb, mpp in prof if mpp == 3) / gemm_flop if gemm_flop else 0.0
     # HBM-side bytes per launch of the dominant kernel cannot be counted from inside the process: they come from
     # the committed PMC summary of this same workload (profiles/README.md has the command and the corrections)
     traffic, traffic_src = None, None
-    tj = ROOT / "profiles" / "r01_gemm_traffic.json"
-    if args.workload == "native3" and B == 8 and tj.exists():
+    tj = ROOT / "profiles" / f"r02_gemm_traffic_{args.workload}.json"
+    if tj.exists():
         try:
             tjd = json.loads(tj.read_text())
-            traffic, traffic_src = tjd["bytes_per_launch"], "profiles/r01_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            if tjd.get("batch") == B:
+                traffic, traffic_src = tjd["bytes_per_launch"], f"profiles/{tj.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         except (ValueError, KeyError):
             pass
+
+    secondary = {}
+    if (args.workload == "syn3" and not args.batch and args.recompute == "auto" and not args.no_secondary
+            and args.steps >= 10):
+        del step
+        free()
+        _common.USE_LANES, _encoder.USE_SIDE_STREAM = (False, False) if args.serial else lanes_default
+        for name in ("native3", "native"):
+            try:
+                cfg2, B2, pol2, step2 = make_job(name, 0)
+                dt2, lv2, per2 = timed(step2, 3, 10)
+                secondary[name] = {"model": cfg2["name"], "value": round(world * B2 * 10 / dt2, 3), "unit": "knees/s",
+                                   "ms_per_step": round(dt2 / 10 * 1e3, 2), "ms_per_step_median": round(statistics.median(per2), 2),
+                                   "steps": 10, "warmup": 3, "per_gpu_batch": B2, "last_loss": round(lv2, 6),
+                                   "workload": WORKLOAD_TEXT[name]}
+                del step2
+                free()
+            except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
+                secondary[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         value = world * B * args.steps / dt
@@ -329,41 +476,35 @@ def main():
             "metric": ("knees/sec full XR+MRI+clin fusion inference pass" if args.workload == "eval3"
                        else "knees/sec full XR+MRI+clin fusion train step"),
             "value": round(value, 3), "unit": "knees/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "ms_per_step_median": round(statistics.median(per), 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 tensors and accumulation everywhere; contractions form each fp32 x fp32 product from exact bf16 "
-                          "pieces of the operands on the bf16 MFMA (forward: all 24 significand bits, error at fp32 rounding "
-                          "level; gradient contractions: operands rounded to 16 significand bits, ~7e-6 relative); "
-                          "KOAF_BWD_PRECISION=full makes the gradients exact too",
+            "arithmetic": "fp32 tensors, fp32 accumulation, every product at fp32 rounding level (forward and gradients alike): "
+                          "contractions form each fp32 x fp32 product on the 16-bit matrix pipe from exact pieces of the operands -- "
+                          "convolutions: two fp16 pieces of operand x 2^e (e from the tensor's max magnitude) and three products "
+                          "(hi*hi, hi*lo, lo*hi; <= 2^-24 relative per operand and for the dropped lo*lo); linear / attention: "
+                          "three bf16 pieces, six products",
+            "host_sync": "loss.item() is read after optimizer.step() is enqueued; the reference reads the same value between forward "
+                         "and backward (train_prog_fus.py:159-165), which would drain the GPU in the middle of the step",
             "config": {"workload": f"{args.workload}: {cfg['name']} "
                                    + ("inference pass (forward + softmax), " if args.workload == "eval3"
                                       else "train step (fwd+FocalLoss+bwd+Adam), ") +
-                                   f"per-GPU batch {B}, global batch {world * B}, "
-                                   + {"native": "XR 1x350x350 + DESS 160x160x64 + T2 160x160x25 + 9 clinical; random-init weights",
-                                      "native3": "XR 1x350x350 + DESS 160x160x64 + TSE 160x160x32 + T2 160x160x25 + 9 clinical "
-                                                 "(BASELINE config 4; 3-MRI registry extension of the reference's "
-                                                 "XR1MR2C1CnnTrf); random-init weights",
-                                      "syn3": "BASELINE synthetic shapes XR 1x310x310 + 3 x MRI 1x160x384x384 + 9 clinical; "
-                                              "random-init weights",
-                                      "eval3": "INFERENCE pass (forward + softmax, eval mode) on the native3 shapes; random-init weights",
-                                      "xr1c1": "BASELINE config 2: XR 1x350x350 + 9 clinical, early-fusion MLP head; random-init weights",
-                                      "mr1c1": "BASELINE config 3: SAG-3D-DESS 1x160x384x384 + 9 clinical; random-init weights",
-                                      "syn": "BASELINE synthetic shapes XR 1x310x310 + 2 x MRI 1x160x384x384 + 9 clinical "
-                                             "(default per-GPU batch 2; batch 8 with --recompute); "
-                                             "random-init weights"}.get(args.workload, "random-init weights"),
-                       "parallelism": f"dp{world}", "last_loss": round(lv, 6), "activation_recompute": bool(args.recompute),
+                                   f"per-GPU batch {B}, global batch {world * B}, " + WORKLOAD_TEXT.get(args.workload, "random-init weights"),
+                       "parallelism": f"dp{world}", "last_loss": round(lv, 6), "activation_recompute": policy,
                        "hbm_peak_gib": {"allocated": hbm_gb[0], "reserved": hbm_gb[1]}},
-            **({"pinned_reference_model": pinned} if pinned else {}),
+            "rccl_ranks": rccl_ranks, "comm_exposed_ms": comm_exposed,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak_mix, 1),
                          "unit": "TFLOP/s", "frac": round(achieved / peak_mix, 4), "traffic": traffic,
                          "traffic_unit": "bytes per koaf_gemm_kernel launch (average)", "traffic_source": traffic_src,
-                         "kernel": "koaf_gemm_kernel (implicit GEMM: conv fwd/dgrad/wgrad, linear, attention; fp32 in/out/"
-                                   "accumulate; products on v_mfma_f32_32x32x16_bf16 from bf16 pieces of the operands: "
-                                   "forward 3 pieces / 6 products (every significand bit), gradients 2 pieces / 4 products "
-                                   "(16 significand bits))",
-                         "peak_is": "2.5 PFLOP/s dense bf16 MFMA / MFMAs per product, FLOP-weighted harmonic mean over the "
-                                    f"step's calls ({100 * bwd_share:.0f} % of the FLOPs are gradient contractions at 625, "
-                                    "the rest at 416.7 TFLOP/s fp32-equivalent)",
+                         "kernel": "koaf_gemm_kernel (implicit GEMM: conv fwd/dgrad/wgrad, linear, attention; fp32 in/out/accumulate; "
+                                   "products on v_mfma_f32_32x32x16_f16 from two scaled fp16 pieces per operand (3 MFMAs per product: "
+                                   "convolutions) or on v_mfma_f32_32x32x16_bf16 from three bf16 pieces (6 MFMAs: linear, attention, "
+                                   "grouped conv))",
+                         "peak_is": "2.5 PFLOP/s dense 16-bit MFMA / MFMAs per product, FLOP-weighted harmonic mean over the step's calls "
+                                    f"({100 * f16_share:.0f} % of the executed FLOPs on the 3-MFMA scheme at 833.3, the rest at 416.7 TFLOP/s "
+                                    "fp32-equivalent)",
+                         "achieved_is": "algorithmic FLOPs the step's GEMM-family calls execute (recomputed forward stages included) / "
+                                        "their event-timed durations on the launch stream (one instrumented single-stream step)",
                          "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
                          "achieved_over_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                          "floor_ms_per_step": round(floor_ms, 2), "frac_of_floor": round(floor_ms / gemm_ms, 4) if gemm_ms > 0 else None,
@@ -372,43 +513,15 @@ def main():
                                      "SURVEY 8(d)'s attainable = min(MFMA peak, AI x HBM) applied per call; frac_of_floor = floor / "
                                      "measured kernel time; `frac` above stays the plain achieved / matrix-pipe peak",
                          "launches_per_step": n_launch, "kernel_ms_per_step": round(gemm_ms, 2),
-                         "algorithmic_gflop_per_step": round(gemm_flop / 1e9, 1),
-                         "step_gflop_per_sample_survey": algorithmic_train_gflop_per_sample(args.workload)},
+                         "executed_gflop_per_step": round(gemm_flop / 1e9, 1),
+                         "algorithmic_gbytes_per_step": round(gemm_bytes / 1e9, 1),
+                         "step_gflop_per_sample_survey": algorithmic_train_gflop_per_sample(args.workload),
+                         "step_tflops_algorithmic": round(algorithmic_train_gflop_per_sample(args.workload) * value / 1e3 / world, 1)},
         }
-        if world == 1 and args.workload == "native3" and not args.batch and not args.recompute and not args.no_syn:
-            # the same model and batch on BASELINE.json's synthetic tensor shapes (XR 1x310x310, MRI 1x160x384x384): the
-            # activations of a batch of 8 need activation recompute to fit (142 GB); 1 warm-up + 2 timed steps
-            try:
-                del step
-                import gc
-                gc.collect()
-                torch.cuda.synchronize()
-                torch.cuda.empty_cache()
-                _common.USE_LANES, _encoder.USE_SIDE_STREAM = not args.serial, not args.serial
-                cfg_s, B_s, step_s = make_job("syn3", 8, recompute=True)
-                torch.cuda.reset_peak_memory_stats()
-                step_s()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(2):
-                    lv_s = step_s()
-                torch.cuda.synchronize()
-                dts = (time.perf_counter() - t0) / 2
-                out["baseline_synthetic_shapes"] = {
-                    "workload": "syn3: same model, per-GPU batch 8, XR 1x310x310 + 3 x MRI 1x160x384x384 + 9 clinical, "
-                                "activation recompute (one encoder stage at a time)",
-                    "value": round(B_s / dts, 3), "unit": "knees/s", "ms_per_step": round(dts * 1e3, 1), "steps": 2, "warmup": 1,
-                    "last_loss": round(lv_s, 6),
-                    "step_gflop_per_sample_survey": round(algorithmic_train_gflop_per_sample("syn3"), 1),
-                    "hbm_peak_gib": {"allocated": round(torch.cuda.max_memory_allocated() / 2**30, 1),
-                                     "reserved": round(torch.cuda.max_memory_reserved() / 2**30, 1)}}
-                del step_s
-                gc.collect()
-                torch.cuda.empty_cache()
-            except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
-                out["baseline_synthetic_shapes"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if secondary:
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(cfg, args.workload)
+            cb = cpu_baseline(args.workload)
             if cb is not None:
                 out["cpu_baseline"] = cb
         print(json.dumps(out))
@@ -417,4 +530,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    _args = parse_args()
+    if _args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_workers(_args.gpus, sys.argv[1:]))
+    main(_args)

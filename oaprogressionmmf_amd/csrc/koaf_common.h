@@ -41,3 +41,22 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// Raise the device scalar *slot (a non-negative float, zeroed beforehand) to the block's maximum of v: one atomic per BLOCK,
+// and none at all once the slot already holds a value >= the block's (the slot only grows, so a stale read can cost a
+// redundant atomic but never lose a maximum).  Float bits of non-negative values order like unsigned integers; a NaN
+// compares above every finite value and poisons the slot on purpose.  All threads of the block must call it.
+__device__ __forceinline__ void block_amax_raise(float v, float* slot) {
+    __shared__ float koaf_amax_red[16];
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) koaf_amax_red[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = koaf_amax_red[0];
+        for (int i = 1; i < nw; ++i) m = fmaxf(m, koaf_amax_red[i]);
+        const unsigned bits = __float_as_uint(m);
+        if (bits > __hip_atomic_load(reinterpret_cast<unsigned*>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(reinterpret_cast<unsigned*>(slot), bits);
+    }
+}

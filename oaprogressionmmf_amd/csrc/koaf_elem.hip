@@ -323,12 +323,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
         *(v4f*)&dc[i * 4] = o;
         m = fmaxf(fmaxf(m, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
     }
-    if (amax) {
-        // max |dc| of the tensor: the scale of dc as an operand of the fp16 contraction scheme (float bits of non-negative
-        // values order like unsigned integers; a NaN lands above every finite value and poisons the scale on purpose)
-        m = wave_max(m);
-        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(m));
-    }
+    // max |dc| of the tensor: the scale of dc as an operand of the fp16 contraction scheme
+    if (amax) block_amax_raise(m, amax);
 }
 
 // ------------------------------------------------------------------------------------------------

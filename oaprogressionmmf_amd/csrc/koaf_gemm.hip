@@ -1176,8 +1176,7 @@ __global__ void __launch_bounds__(256) wplanes_amax_kernel(const float* __restri
     const int t = threadIdx.x;
     const v4f x = wtile_load(base, w, w.rt * 32 + (t >> 3), w.ct * 32 + 4 * (t & 7));
     float m = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
-    m = wave_max(m);
-    if ((t & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(amax + w.idx), __float_as_uint(m));
+    block_amax_raise(m, amax + w.idx);
 }
 
 // pass 2: the images of w * scale_of_amax(amax[i]) (split2h: bit-identical to the in-kernel split of the same operand)

@@ -40,9 +40,26 @@ def make_drop(p):
     return KoafDropout2d(p) if p else nn.Identity()
 
 
+def mr_view(config):
+    """slice view of the MRI volumes of a fusion model: "rc" on the reference's (B,1,R,C,S) tensors, or -- config key
+    `fe.mr.volume_layout: ncdhw` (not in the reference; default `rcs`) -- "src": the volumes arrive slice-major
+    (B,1,S,R,C), as BASELINE.json writes them (1x160x384x384), and the slice fold is a zero-copy view."""
+    fe = config["fe"]
+    lay = dict(fe["mr"] if "mr" in fe else fe).get("volume_layout", "rcs")     # (MR-only models keep the keys under `fe`)
+    if lay not in ("rcs", "ncdhw"):
+        raise ValueError("Unsupported `model.fe.mr.volume_layout` (rcs | ncdhw)")
+    return "src" if lay == "ncdhw" else "rc"
+
+
 def fold_slices(x, dims_view="rc"):
     """(B,1,R,C,S) -> single-channel image batch for the 2-D trunk (the 1->3 repeat is folded into conv1).
-    rc: "b ch r c s -> (b s) ch r c" (_xrNmrMcP.py:209); cs / rs: _mrN_cnn_trf.py:112-117."""
+    rc: "b ch r c s -> (b s) ch r c" (_xrNmrMcP.py:209); cs / rs: _mrN_cnn_trf.py:112-117; src: the same slices as rc
+    from a slice-major (B,1,S,R,C) volume (see mr_view) -- no data movement."""
+    if dims_view == "src":
+        B, ch, S, R, C = x.shape
+        if ch != 1:
+            raise ValueError("koafusion volumes are single-channel")
+        return x.contiguous().view(B * S, 1, R, C)
     B, ch, R, C, S = x.shape
     if ch != 1:
         raise ValueError("koafusion volumes are single-channel")

@@ -266,6 +266,25 @@ def _block_fwd(blk, y, N, Hc, Wc, train, given):
     return r
 
 
+def _recompute_plan(trunk, nstages):
+    """KoafTrunk.recompute -> (stages to rebuild in backward, one block at a time?).  False: every conv output is kept;
+    True: every stage is rebuilt; "block": every stage, one block at a time (least memory, one more forward of most
+    blocks); a collection of stage indices (0 = layer1): only those stages -- the early stages hold most of the bytes
+    (80 of the 180 MB per 384^2 slice sit in layer1, 10 in layer4) for about the same FLOPs as the late ones, so
+    rebuilding layer1-2 and keeping layer3-4 buys most of the memory for half of the recompute time."""
+    r = getattr(trunk, "recompute", False)
+    if r is False or r is None:
+        return frozenset(), False
+    if r is True or r == "stage":
+        return frozenset(range(nstages)), False
+    if r == "block":
+        return frozenset(range(nstages)), True
+    rs = frozenset(int(i) for i in r)
+    if not rs <= frozenset(range(nstages)):
+        raise ValueError(f"KoafTrunk.recompute: stage indices out of range 0..{nstages - 1}: {sorted(rs)}")
+    return rs, False
+
+
 class EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, trunk, anchor, keep, lane):
@@ -286,28 +305,35 @@ class EncoderFn(torch.autograd.Function):
         s0 = _bn_fin(bn1, part, N * H1 * W1)
         y, am = ops.maxpool_fwd(c0, s0, N, H1, W1, 64)
         Hc, Wc = y.shape[1], y.shape[2]
-        recs, ck = [], []
-        recompute = bool(getattr(trunk, "recompute", False)) and keep
-        for stage in st["stages"]:
-            cks = dict(yin=y, H=Hc, W=Wc, stats=[])
+        # per stage: either the block records (every conv output) are kept for backward, or -- activation recompute --
+        # only the stage input and the BatchNorm statistics, and the stage is rebuilt right before its backward
+        rset, block_level = _recompute_plan(trunk, len(st["stages"]))
+        if not keep:
+            rset = frozenset()
+        stages_saved = []
+        for si, stage in enumerate(st["stages"]):
+            rec_stage = si in rset
+            sv = dict(yin=y, H=Hc, W=Wc, stats=[], recs=[], recompute=rec_stage)
             for blk in stage:
                 r = _block_fwd(blk, y, N, Hc, Wc, train, None)
                 y, Hc, Wc = r.y, r.dims[3], r.dims[4]
-                if keep and not recompute:
-                    recs.append(r)
-                elif recompute:
-                    cks["stats"].append((r.s1, r.s2, r.s3, r.sd))
-            ck.append(cks)
+                if rec_stage:
+                    sv["stats"].append((r.s1, r.s2, r.s3, r.sd))
+                elif keep:
+                    sv["recs"].append(r)
+            if not rec_stage:
+                sv["yin"] = None
+            stages_saved.append(sv)
         C = y.shape[-1]
         if st["gap"]:
             out = ops.gap_fwd(y, N, Hc * Wc, C).view(N, C, 1, 1)
         else:
             out = y.permute(0, 3, 1, 2)  # (N,C,h,w) view of the NHWC buffer
         if keep:
-            if recompute:
+            if 0 in rset:
                 c0 = None          # the stem output is rebuilt in backward too (one cheap 7x7 conv; 64 x H/2 x W/2 floats)
-            ctx.state = dict(x=x, c0=c0, s0=s0, am=am, recs=recs, ck=ck if recompute else None,
-                             block_level=getattr(trunk, "recompute", False) == "block",
+            ctx.state = dict(x=x, c0=c0, s0=s0, am=am, stages=stages_saved, any_recompute=bool(rset),
+                             block_level=block_level,
                              dims=(N, H, W, H1, W1), last=(Hc, Wc, C), st=st, lane=lane, train=train)
         return out
 
@@ -415,41 +441,47 @@ class EncoderFn(torch.autograd.Function):
         # (no wgrad side stream under activation recompute: tensors handed to a second stream are recycled by the
         # caching allocator only once that stream's events have completed, which at recompute-sized footprints
         # drives the reserved pool to the HBM limit and every later allocation into a synchronising retry)
-        side = _SideStream(gout.device, side_stream) if (USE_SIDE_STREAM and S["ck"] is None) else None
-        if S["ck"] is None:
-            dy = EncoderFn._blocks_bwd(S["recs"], dy, side)
-        else:
-            # stage-level activation recompute: only the stage inputs and the BatchNorm statistics were kept; the
-            # stage's conv outputs are rebuilt (same kernels, saved statistics, no reductions) right before use
-            stages = st["stages"]
-            for si in range(len(stages) - 1, -1, -1):
-                cks = S["ck"][si]
-                y, Hc2, Wc2 = cks["yin"], cks["H"], cks["W"]
-                cks["yin"] = None
-                if S["block_level"] and len(stages[si]) > 1:
-                    # block-granular: pass 1 rebuilds only the block INPUTS of the stage, then every block is rebuilt
-                    # alone (last first) and back-propagated -- one block's conv outputs live at a time instead of
-                    # the whole stage's, for one more forward of the stage's blocks but the last
-                    ins = [(y, Hc2, Wc2)]
-                    for blk, given in zip(stages[si][:-1], cks["stats"][:-1]):
-                        r = _block_fwd(blk, y, N, Hc2, Wc2, S["train"], given)
-                        y, Hc2, Wc2 = r.y, r.dims[3], r.dims[4]
-                        ins.append((y, Hc2, Wc2))
-                        del r
-                    for bi in range(len(stages[si]) - 1, -1, -1):
-                        yb, hb, wb = ins.pop()
-                        r = _block_fwd(stages[si][bi], yb, N, hb, wb, S["train"], cks["stats"][bi])
-                        dy = EncoderFn._blocks_bwd([r], dy, side)
-                        del r, yb
-                    del y
+        side = _SideStream(gout.device, side_stream) if (USE_SIDE_STREAM and not S["any_recompute"]) else None
+        stages = st["stages"]
+        run = []      # block records of consecutive kept stages: one list, so the fused tail reductions cross stage boundaries
+        for si in range(len(stages) - 1, -1, -1):
+            sv = S["stages"][si]
+            if not sv["recompute"]:
+                run = sv["recs"] + run
+                sv["recs"] = None
+                if si > 0 and not S["stages"][si - 1]["recompute"]:
                     continue
-                recs = []
-                for blk, given in zip(stages[si], cks["stats"]):
+                dy = EncoderFn._blocks_bwd(run, dy, side)
+                run = []
+                continue
+            # activation recompute: only the stage input and the BatchNorm statistics were kept; the stage's conv
+            # outputs are rebuilt (same kernels, saved statistics, no reductions) right before use
+            y, Hc2, Wc2 = sv["yin"], sv["H"], sv["W"]
+            sv["yin"] = None
+            if S["block_level"] and len(stages[si]) > 1:
+                # block-granular: pass 1 rebuilds only the block INPUTS of the stage, then every block is rebuilt
+                # alone (last first) and back-propagated -- one block's conv outputs live at a time instead of
+                # the whole stage's, for one more forward of the stage's blocks but the last
+                ins = [(y, Hc2, Wc2)]
+                for blk, given in zip(stages[si][:-1], sv["stats"][:-1]):
                     r = _block_fwd(blk, y, N, Hc2, Wc2, S["train"], given)
-                    recs.append(r)
                     y, Hc2, Wc2 = r.y, r.dims[3], r.dims[4]
-                dy = EncoderFn._blocks_bwd(recs, dy, side)
-                del recs, r, y
+                    ins.append((y, Hc2, Wc2))
+                    del r
+                for bi in range(len(stages[si]) - 1, -1, -1):
+                    yb, hb, wb = ins.pop()
+                    r = _block_fwd(stages[si][bi], yb, N, hb, wb, S["train"], sv["stats"][bi])
+                    dy = EncoderFn._blocks_bwd([r], dy, side)
+                    del r, yb
+                del y
+                continue
+            recs = []
+            for blk, given in zip(stages[si], sv["stats"]):
+                r = _block_fwd(blk, y, N, Hc2, Wc2, S["train"], given)
+                recs.append(r)
+                y, Hc2, Wc2 = r.y, r.dims[3], r.dims[4]
+            dy = EncoderFn._blocks_bwd(recs, dy, side)
+            del recs, r, y
         # stem: max-pool, BN0, conv1 weight gradient (no data gradient: the input is a leaf)
         conv1, bn1 = st["conv1"], st["bn1"]
         da0 = ops.maxpool_bwd(dy, S["am"], N, H1, W1, 64)

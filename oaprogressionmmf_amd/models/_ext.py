@@ -114,7 +114,7 @@ class _HierFusionC1(nn.Module):
         def agg(drop, feat):
             return lambda f: feat(C.tokens(drop(f), B))[1]
         # MRI trunks first (largest), each followed on its lane by its own aggregator; radiographs last
-        jobs = [(getattr(self, f"_fe{i}"), inputs[i], "rc",
+        jobs = [(getattr(self, f"_fe{i}"), inputs[i], C.mr_view(self.config),
                  agg(getattr(self, f"_fe{i}_drop"), getattr(self, f"_agg_{i}"))) for i in range(nx, nx + nm)]
         jobs += [(getattr(self, f"_fe{i}"), inputs[i], None) for i in range(nx)]
         res = C.run_trunks(jobs)

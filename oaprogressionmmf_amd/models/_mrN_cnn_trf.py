@@ -104,7 +104,7 @@ class MR2CnnTrf(nn.Module):
         """input0, input1 : (B, 1, R, C, S)"""
         C.adopt(self, input0, input1)
         B = input0.shape[0]
-        f0, f1 = C.run_trunks([(self._fe0, input0, "rc"), (self._fe1, input1, "rc")])
+        f0, f1 = C.run_trunks([(self._fe0, input0, C.mr_view(self.config)), (self._fe1, input1, C.mr_view(self.config))])
         t_fe0 = C.tokens(self._fe0_drop(f0), B)
         t_fe1 = C.tokens(self._fe1_drop(f1), B)
         t_fe_m = torch.cat([t_fe0, t_fe1], dim=1)

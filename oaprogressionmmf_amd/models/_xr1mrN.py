@@ -60,7 +60,7 @@ class XR1MR1CnnTrf(nn.Module):
         """input0 : (B,1,R,C); input1 : (B,1,R,C,S)"""
         C.adopt(self, input0, input1)
         B = input0.shape[0]
-        f1, f0 = C.run_trunks([(self._fe1, input1, "rc"), (self._fe0, input0, None)])
+        f1, f0 = C.run_trunks([(self._fe1, input1, C.mr_view(self.config)), (self._fe0, input0, None)])
         t_fe0 = C.tokens(self._fe0_drop(f0), B)
         t_fe1 = C.tokens(self._fe1_drop(f1), B)
         res_agg, _, _ = self._agg(torch.cat([t_fe0, t_fe1], dim=1))
@@ -117,8 +117,8 @@ class XR1MR2CnnTrf(nn.Module):
         # each MRI's aggregator runs on its encoder's lane (Q4: its mlp_head0 output is computed and discarded)
         def agg(drop, feat):
             return lambda f: feat(C.tokens(drop(f), B))[1]
-        res_agg1, res_agg2, f0 = C.run_trunks([(self._fe1, input1, "rc", agg(self._fe1_drop, self._agg_1)),
-                                               (self._fe2, input2, "rc", agg(self._fe2_drop, self._agg_2)),
+        res_agg1, res_agg2, f0 = C.run_trunks([(self._fe1, input1, C.mr_view(self.config), agg(self._fe1_drop, self._agg_1)),
+                                               (self._fe2, input2, C.mr_view(self.config), agg(self._fe2_drop, self._agg_2)),
                                                (self._fe0, input0, None)])
         t_fe0 = C.tokens(self._fe0_drop(f0), B)
         # Q4: the reference runs mlp_head0 of the cls-less aggregators and discards it

@@ -85,8 +85,8 @@ class XR1MR2C1CnnTrf(nn.Module):
         # each MRI's aggregator runs on its encoder's lane (Q4: its mlp_head0 output is computed and discarded)
         def agg(drop, feat):
             return lambda f: feat(C.tokens(drop(f), B))[1]
-        res_agg1, res_agg2, f0 = C.run_trunks([(self._fe1, input1, "rc", agg(self._fe1_drop, self._agg_1)),
-                                               (self._fe2, input2, "rc", agg(self._fe2_drop, self._agg_2)),
+        res_agg1, res_agg2, f0 = C.run_trunks([(self._fe1, input1, C.mr_view(self.config), agg(self._fe1_drop, self._agg_1)),
+                                               (self._fe2, input2, C.mr_view(self.config), agg(self._fe2_drop, self._agg_2)),
                                                (self._fe0, input0, None)])
         t_fe0 = C.tokens(self._fe0_drop(f0), B)
         t_fe3 = self._fe3_drop(self._fe3(input3))

@@ -33,13 +33,14 @@ def _prof_begin():
     return e
 
 
-def _prof_end(e0, family, flops, tag="", elems=0):
-    """elems: fp32 elements the call must move through HBM if every operand travels exactly once (its algorithmic bytes / 4)"""
+def _prof_end(e0, family, flops, tag="", elems=0, mpp=6):
+    """elems: fp32 elements the call must move through HBM if every operand travels exactly once (its algorithmic bytes / 4);
+    mpp: matrix instructions per fp32 product of the call's contraction scheme (6: bf16 x 3, 3: fp16 x 2; koaf.h KoafGemm.fmt)"""
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    PROFILE.append((family, flops, e0, e1, tag, 4.0 * elems))
+    PROFILE.append((family, flops, e0, e1, tag, 4.0 * elems, mpp))
 
 
 def _ptr(t):
@@ -96,7 +97,7 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
                             _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _ptr(shift) if stats else None,
                             _img(wimg), _stream()), "conv2d_fwd")
     _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin, f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}",
-              N * H * W * Cin + Cout * KH * KW * Cin + N * OH * OW * Cout)
+              N * H * W * Cin + Cout * KH * KW * Cin + N * OH * OW * Cout, mpp=3 if wimg is not None else 6)
     if stats:
         part = part[:rows.value]
     return y, part
@@ -112,11 +113,12 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, 
     tag = f"conv_dgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}"
     el = N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout + Cout * KH * KW * Cin + N * H * W * Cin
     el += N * H * W * Cin if residual is not None else 0
+    mpp = 3 if (wimg is not None and dy_amax is not None) else 6
     if bnb is None:
         e0 = _prof_begin()
         check(L.koaf_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
                                   _ptr(residual), _img(wimg), _ptr(dy_amax), _stream()), "conv2d_dgrad")
-        _prof_end(e0, "gemm", fl, tag, el)
+        _prof_end(e0, "gemm", fl, tag, el, mpp=mpp)
         return dx
     sv, sv2 = bnb["saved"], bnb.get("saved2")
     kb = KoafBnb(mode=bnb["mode"], c=_ptr(bnb["c"]), y=_ptr(bnb.get("y")), sc=_ptr(sv[2]), sh=_ptr(sv[3]),
@@ -130,7 +132,7 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, 
                                   _ptr(residual), ctypes.byref(kb), _ptr(part), ctypes.addressof(rows), _img(wimg),
                                   _ptr(dy_amax), _stream()), "conv2d_dgrad_bnb")
     el += N * H * W * Cin * (1 + (bnb.get("y") is not None) + (bnb.get("c2") is not None))
-    _prof_end(e0, "gemm", fl, tag + " +bnb", el)
+    _prof_end(e0, "gemm", fl, tag + " +bnb", el, mpp=mpp)
     return dx, part[:rows.value]
 
 
@@ -144,7 +146,8 @@ def conv2d_wgrad(dy, x, dw, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None,
                               _ptr(in_sh), _ptr(slabs), _ptr(dy_amax), _stream()), "conv2d_wgrad")
     _prof_end(e0, "gemm", 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin,
               f"conv_wgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}",
-              N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout + N * H * W * Cin + Cout * KH * KW * Cin)
+              N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout + N * H * W * Cin + Cout * KH * KW * Cin,
+              mpp=3 if dy_amax is not None else 6)
     return dw
 
 

@@ -1,0 +1,43 @@
+"""bench.py --gpus N without a launcher: the parent starts N worker processes with the rendezvous environment of
+`torch.distributed.run`, relays rank 0's line and fails if any worker fails (no GPU involved: stub workers)."""
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+STUB = """
+import json, os, sys
+r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+if "--fail" in sys.argv and r == w - 1:
+    sys.exit(3)
+print(json.dumps({"rank": r, "world": w, "argv": sys.argv[1:], "port": os.environ["MASTER_PORT"]}))
+"""
+
+
+def test_launcher_starts_ranks_and_relays_rank0(tmp_path, capfd):
+    import bench
+    stub = tmp_path / "stub.py"
+    stub.write_text(STUB)
+    rc = bench.launch_workers(2, ["--gpus", "2", "--steps", "3"], program=str(stub))
+    out = capfd.readouterr().out.strip().splitlines()
+    assert rc == 0 and len(out) == 1                      # only rank 0's line is relayed
+    d = json.loads(out[0])
+    assert d["rank"] == 0 and d["world"] == 2 and d["argv"] == ["--gpus", "2", "--steps", "3"]
+    rc = bench.launch_workers(2, ["--fail"], program=str(stub))
+    assert rc == 1
+    capfd.readouterr()
+
+
+def test_worker_env_and_defaults():
+    import bench
+    env = bench.worker_env(3, 8, 12345, base={"X": "1"})
+    assert env["RANK"] == "3" and env["LOCAL_RANK"] == "3" and env["WORLD_SIZE"] == "8" and env["MASTER_PORT"] == "12345"
+    assert env["X"] == "1"
+    a = bench.parse_args([])
+    assert a.gpus == 1 and a.workload == "syn3" and a.steps >= 20 and a.warmup >= 5
+    cfg, B, pol = bench.workload_cfg("syn3")
+    assert B == 8 and cfg["_tensor_shapes"][1] == [160, 384, 384] and cfg["fe"]["mr"]["volume_layout"] == "ncdhw"

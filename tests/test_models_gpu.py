@@ -210,7 +210,7 @@ def test_stage_recompute_matches_stored_activations(dev):
 def _recompute_cases(dev, dict_fes, KoafTrunk):
     for arch, shape in (("resnet50", (3, 1, 96, 112)), ("resnext50_32x4d", (2, 1, 96, 96)), ("resnet18", (2, 1, 64, 96))):
         res = []
-        for rc in (False, True, "block"):
+        for rc in (False, True, "block", (0, 1), [2]):           # (0, 1): rebuild layer1-2 only, keep layer3-4 (bench policy)
             net = dict_fes[arch](pretrained=False)
             trunk = KoafTrunk(*list(net.children())[:-1])
             P.fill_state_dict(trunk.state_dict())
@@ -222,12 +222,45 @@ def _recompute_cases(dev, dict_fes, KoafTrunk):
             res.append((y.detach().clone(), {k: p.grad.clone() for k, p in trunk.named_parameters()},
                         {k: b.clone() for k, b in trunk.named_buffers()}))
         y0, g0, b0 = res[0]
-        for y1, g1, b1 in res[1:]:            # stage-level, then block-granular (+ stem) recompute
+        for y1, g1, b1 in res[1:]:            # stage-level, block-granular (+ stem), then per-stage policies
             assert torch.equal(y0, y1)
             for k in b0:
                 assert torch.equal(b0[k], b1[k]), k
             for k in g0:
                 assert rel(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 1e-5, (arch, k)
+
+
+def test_ncdhw_volume_layout_is_bit_identical(dev):
+    """`fe.mr.volume_layout: ncdhw` (volumes arrive slice-major (B,1,S,R,C), as BASELINE.json writes them: the slice fold
+    is a view) gives the same bits as the reference layout (B,1,R,C,S) holding the same values: logits, loss, gradients"""
+    import copy
+    from oaprogressionmmf_amd.various import dict_losses
+    cfg = P.cfg_full(xr=(96, 96), mr1=(64, 64, 6), mr2=(64, 64, 5), depth=1)
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["fe"]["mr"]["volume_layout"] = "ncdhw"
+    B = 2
+    xs = [t(a).to(dev) for a in P.model_inputs(cfg, B, 7)]
+    xs2 = [xs[0], xs[1].permute(0, 1, 4, 2, 3).contiguous(), xs[2].permute(0, 1, 4, 2, 3).contiguous(), xs[3]]
+    y = t(P.make_target("target", B, 7)).to(dev)
+    loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
+    res = []
+    for c, inp in ((cfg, xs), (cfg2, xs2)):
+        m = build(c, dev)
+        m.eval()
+        with torch.no_grad():
+            le = m(*inp)["main"].clone()
+        m.train()
+        loss = loss_fn(input=m(*inp)["main"].squeeze(1), target=y.long().squeeze(1))
+        loss.backward()
+        res.append((le, loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert res[0][2].keys() == res[1][2].keys()
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+    with pytest.raises(ValueError):
+        bad = copy.deepcopy(cfg)
+        bad["fe"]["mr"]["volume_layout"] = "zyx"
+        build(bad, dev)(*xs)
 
 
 def test_spatial_encoder_output_with_dropout2d(dev):
