@@ -359,11 +359,14 @@ int koaf_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* s
 /* inverted dropout with a counter-based generator: y = x * keep(seed, i) / (1-p).  The same call
  * with x := dy is the backward.  (nn.Dropout / nn.Dropout2d on (N,C,1,1); streams differ from
  * torch's by construction -- SURVEY a10.)  */
-int koaf_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* epoch (nullable, both dropouts): device-resident step counter folded into the seed -- a captured (HIP-graph) step replays with
+ * frozen arguments, the counter (koaf_counter_add) is what changes from step to step */
+int koaf_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, const int64_t* epoch, void* stream);
+int koaf_counter_add(int64_t* counter, int64_t delta, void* stream);   /* *counter += delta on the device */
 /* nn.Dropout2d on an NHWC map x [N][HW][C] (_xrNmrMcP.py:62-72 with with_gap false): one draw per (image, channel),
  * generator index n*C + c -- identical to koaf_dropout on the pooled [N][C] output.  Backward = same call on dy. */
 int koaf_dropout2d(const float* x, float* y, int32_t N, int32_t HW, int32_t C, float p, uint64_t seed,
-                   void* stream);
+                   const int64_t* epoch, void* stream);
 /* out = a + b */
 int koaf_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* column sums of x [rows][C] -> out [C] (bias gradients); part: koaf_colsum_ws floats or NULL */
@@ -381,7 +384,10 @@ int koaf_ce_loss(const float* logits, const int64_t* target, float* loss, float*
 /* ---- torch.optim.Adam (coupled L2) over a flat arena (_optimizers.py:47-52) ------------------ */
 int koaf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int32_t step, int32_t adamw,
-                   void* stream);
+                   const float* hyper, void* stream);
+/* Device-resident optimizer step state for captured (HIP-graph) train steps: ++*step; hyper[3] = {lr, lr / (1 - beta1^step),
+ * sqrt(1 - beta2^step)} from the device scalars; hand `hyper` to koaf_adam_step (its host lr / step are then ignored). */
+int koaf_adam_hyper(int32_t* step, const float* lr, float beta1, float beta2, float* hyper, void* stream);
 int koaf_fill(float* p, float value, int64_t n, void* stream);
 
 #ifdef __cplusplus

@@ -131,7 +131,9 @@ class ParamArena:
         if self.W is None or not ops.CONV_F16:
             return
         st = self._stamp()
-        if st == self._plane_stamp:
+        # (inside a HIP-graph capture the build is always recorded: a replayed step must rebuild from the weights the
+        # previous replay's optimizer step left, whatever the host-side stamp of the capturing call says)
+        if st == self._plane_stamp and not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
             return
         from ._lib import check, lib
         check(lib().koaf_wplanes_build(self.P.data_ptr(), self.W.data_ptr(), self.Wamax.data_ptr(), self._plane_tab.data_ptr(),

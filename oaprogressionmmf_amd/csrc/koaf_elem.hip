@@ -729,8 +729,15 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
+// `epoch` (nullable): a device-resident step counter folded into the seed, so that a HIP-graph replay of a captured step
+// (whose `seed` argument is frozen) still draws fresh masks every step; forward and backward of one step read the same value
+__device__ __forceinline__ uint64_t step_seed(uint64_t seed, const int64_t* epoch) {
+    return epoch ? seed ^ mix64(0x9E3779B97F4A7C15ull * (uint64_t)(*epoch + 1)) : seed;
+}
+
 __global__ void __launch_bounds__(256) dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
-                                                      float p, float inv_keep, uint64_t seed) {
+                                                      float p, float inv_keep, uint64_t seed0, const int64_t* epoch) {
+    const uint64_t seed = step_seed(seed0, epoch);
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) {
         const uint64_t h = mix64(seed ^ mix64((uint64_t)i));
         const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
@@ -741,7 +748,9 @@ __global__ void __launch_bounds__(256) dropout_kernel(const float* __restrict__ 
 // nn.Dropout2d on an NHWC feature map: one Bernoulli draw per (image, channel), index n*C + c -- the same draw the
 // element-wise kernel makes on the (N, C) pooled output, so pooled and spatial encoders share their masks
 __global__ void __launch_bounds__(256) dropout2d_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
-                                                        int64_t hwc, int C, float p, float inv_keep, uint64_t seed) {
+                                                        int64_t hwc, int C, float p, float inv_keep, uint64_t seed0,
+                                                        const int64_t* epoch) {
+    const uint64_t seed = step_seed(seed0, epoch);
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) {
         const int64_t idx = (i / hwc) * C + (i % C);
         const uint64_t h = mix64(seed ^ mix64((uint64_t)idx));
@@ -749,6 +758,8 @@ __global__ void __launch_bounds__(256) dropout2d_kernel(const float* __restrict_
         y[i] = (u >= p) ? x[i] * inv_keep : 0.f;
     }
 }
+
+__global__ void counter_add_kernel(int64_t* ctr, int64_t delta) { *ctr += delta; }
 
 __global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ p, float v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) p[i] = v;
@@ -803,10 +814,22 @@ __global__ void __launch_bounds__(256) focal_loss_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam single-tensor update rule, coupled L2; adamw: decoupled)
 // ------------------------------------------------------------------------------------------------
+// ++step; hyper = {lr, lr / (1 - b1^step), sqrt(1 - b2^step)}: what koaf_adam_step derives on the host from (lr, step), derived
+// on the device so that a captured (HIP-graph) optimizer step advances from replay to replay
+__global__ void adam_hyper_kernel(int32_t* step, const float* lr, float b1, float b2, float* hyper) {
+    const int st = *step + 1;
+    *step = st;
+    const double bc1 = 1.0 - pow((double)b1, (double)st), bc2 = 1.0 - pow((double)b2, (double)st);
+    hyper[0] = *lr;
+    hyper[1] = (float)((double)*lr / bc1);
+    hyper[2] = (float)sqrt(bc2);
+}
+
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                    float b1, float b2, float eps, float wd, float step_size,
-                                                   float bc2_sqrt, int adamw) {
+                                                   float bc2_sqrt, int adamw, const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; step_size = hyper[1]; bc2_sqrt = hyper[2]; }   // device-resident step state (koaf_adam_hyper)
     const int64_t nvec = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * EB) {
         v4f pv = *(const v4f*)&p[i * 4], gv = *(const v4f*)&g[i * 4];
@@ -1081,17 +1104,22 @@ extern "C" int koaf_add(const float* a, const float* b, float* out, int64_t n, v
     KOAF_REQUIRE(b, "koaf_add: bad args");
     PW_LAUNCH(PW_ADD, a, b, out, n, "koaf_add");
 }
-extern "C" int koaf_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+extern "C" int koaf_counter_add(int64_t* counter, int64_t delta, void* stream) {
+    KOAF_REQUIRE(counter, "koaf_counter_add: null counter");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, STREAM, counter, delta);
+    return koaf_check_launch("koaf_counter_add");
+}
+extern "C" int koaf_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, const int64_t* epoch, void* stream) {
     KOAF_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "koaf_dropout: bad args");
-    hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(EB), 0, STREAM, x, y, n, p, 1.f / (1.f - p), seed);
+    hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(EB), 0, STREAM, x, y, n, p, 1.f / (1.f - p), seed, epoch);
     return koaf_check_launch("koaf_dropout");
 }
 extern "C" int koaf_dropout2d(const float* x, float* y, int32_t N, int32_t HW, int32_t C, float p, uint64_t seed,
-                              void* stream) {
+                              const int64_t* epoch, void* stream) {
     KOAF_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && p >= 0.f && p < 1.f, "koaf_dropout2d: bad args");
     const int64_t n = (int64_t)N * HW * C;
     hipLaunchKernelGGL(dropout2d_kernel, dim3(ew_grid(n)), dim3(EB), 0, STREAM, x, y, n, (int64_t)HW * C, C, p,
-                       1.f / (1.f - p), seed);
+                       1.f / (1.f - p), seed, epoch);
     return koaf_check_launch("koaf_dropout2d");
 }
 extern "C" int koaf_fill(float* p, float value, int64_t n, void* stream) {
@@ -1134,8 +1162,15 @@ extern "C" int koaf_ce_loss(const float* logits, const int64_t* target, float* l
     return koaf_check_launch("koaf_ce_loss");
 }
 
+extern "C" int koaf_adam_hyper(int32_t* step, const float* lr, float beta1, float beta2, float* hyper, void* stream) {
+    KOAF_REQUIRE(step && lr && hyper, "koaf_adam_hyper: bad args");
+    hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(1), 0, STREAM, step, lr, beta1, beta2, hyper);
+    return koaf_check_launch("koaf_adam_hyper");
+}
 extern "C" int koaf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int32_t step, int32_t adamw, void* stream) {
+                              float beta2, float eps, float weight_decay, int32_t step, int32_t adamw,
+                              const float* hyper, void* stream) {
+    if (hyper) step = 1;      // (lr / step come from the device; the host values are ignored)
     KOAF_REQUIRE(p && g && m && v && n > 0 && step >= 1, "koaf_adam_step: bad args");
     KOAF_REQUIRE(al16(p) && al16(g) && al16(m) && al16(v), "koaf_adam_step: unaligned");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -1143,6 +1178,6 @@ extern "C" int koaf_adam_step(float* p, const float* g, float* m, float* v, int6
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EB), 0, STREAM, p, g, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, step_size, bc2_sqrt, adamw);
+                       weight_decay, step_size, bc2_sqrt, adamw, hyper);
     return koaf_check_launch("koaf_adam_step");
 }

@@ -10,9 +10,42 @@ from . import ops
 from .arena import deliver_grad, grad_target
 
 
+class DeviceStepState(object):
+    """Step-to-step randomness without host involvement, for train steps captured into a HIP graph (run.GraphedTrainStep).
+
+    Eager steps draw one dropout seed per call site from torch's CPU generator; a captured step replays with frozen kernel
+    arguments, so instead every call site gets a fixed salt (site index within the step, mixed with `base_seed`) and the
+    kernels fold a device-resident step counter (`epoch`, bumped by one kernel at the start of every step) into it.
+    While an instance is installed as `functional.STEP_STATE` eager steps use the same scheme, so eager and replayed
+    steps draw identical masks."""
+
+    def __init__(self, device, base_seed):
+        self.epoch = torch.zeros(1, dtype=torch.int64, device=device)
+        self.base = int(base_seed) & (2 ** 62 - 1)
+        self.site = 0
+
+    def begin_step(self):
+        from . import ops as _ops
+        self.site = 0
+        _ops.counter_add(self.epoch, 1)
+
+    def salt(self):
+        z = (self.base + 0x9E3779B97F4A7C15 * (self.site + 1)) & (2 ** 64 - 1)
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+        self.site += 1
+        return (z ^ (z >> 31)) & (2 ** 62 - 1)
+
+
+STEP_STATE = None      # a DeviceStepState while a graph-capturable train step runs (run.GraphedTrainStep installs it)
+
+
 def _seed():
+    """-> (seed, epoch tensor or None)"""
+    if STEP_STATE is not None:
+        return STEP_STATE.salt(), STEP_STATE.epoch
     # drawn from torch's CPU generator so `set_ultimate_seed` (various/_seed.py) makes runs repeatable
-    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()), None
 
 
 class LinearFn(torch.autograd.Function):
@@ -158,12 +191,12 @@ class DropoutFn(torch.autograd.Function):
     def forward(ctx, x, p, seed):
         xc = x if x.is_contiguous() else x.contiguous()
         ctx.p, ctx.seed = p, seed
-        return ops.dropout(xc, p, seed)
+        return ops.dropout(xc, p, seed[0], seed[1])
 
     @staticmethod
     def backward(ctx, dy):
         d = dy if dy.is_contiguous() else dy.contiguous()
-        return ops.dropout(d, ctx.p, ctx.seed), None, None
+        return ops.dropout(d, ctx.p, ctx.seed[0], ctx.seed[1]), None, None
 
 
 class Dropout2dFn(torch.autograd.Function):
@@ -175,14 +208,14 @@ class Dropout2dFn(torch.autograd.Function):
         xc = x.permute(0, 2, 3, 1)
         xc = xc if xc.is_contiguous() else xc.contiguous()
         ctx.meta = (N, h * w, C, p, seed)
-        return ops.dropout2d(xc, N, h * w, C, p, seed).permute(0, 3, 1, 2)
+        return ops.dropout2d(xc, N, h * w, C, p, seed[0], seed[1]).permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, dy):
         N, HW, C, p, seed = ctx.meta
         d = dy.permute(0, 2, 3, 1)
         d = d if d.is_contiguous() else d.contiguous()
-        return ops.dropout2d(d, N, HW, C, p, seed).permute(0, 3, 1, 2), None, None
+        return ops.dropout2d(d, N, HW, C, p, seed[0], seed[1]).permute(0, 3, 1, 2), None, None
 
 
 class AddFn(torch.autograd.Function):

@@ -130,18 +130,23 @@ def run_trunks(jobs):
     # activations at once and defeat it, so recomputing trunks run one after the other
     if not USE_LANES or len(jobs) < 2 or any(getattr(j[0], "recompute", False) for j in jobs):
         return [one(j, None) for j in jobs]
+    from . import _encoder
     main = torch.cuda.current_stream()
     ev = main.record_event()
     outs = []
     dev = jobs[0][1].device
-    for lane, job in enumerate(jobs):
-        s, _ = lane_streams(dev, lane)
-        s.wait_event(ev)
-        with torch.cuda.stream(s):
-            out = one(job, lane)
-        job[1].record_stream(s)
-        out.record_stream(main)
-        outs.append(out)
+    _encoder.CALLER_STREAM = main          # (the lanes' backward joins this stream at the end of backward())
+    try:
+        for lane, job in enumerate(jobs):
+            s, _ = lane_streams(dev, lane)
+            s.wait_event(ev)
+            with torch.cuda.stream(s):
+                out = one(job, lane)
+            job[1].record_stream(s)
+            out.record_stream(main)
+            outs.append(out)
+    finally:
+        _encoder.CALLER_STREAM = None
     for lane in range(len(jobs)):
         main.wait_stream(lane_streams(dev, lane)[0])
     return outs

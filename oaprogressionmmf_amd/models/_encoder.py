@@ -97,19 +97,21 @@ def _priorities():
 
 
 _JOIN = {"queued": False, "streams": []}
+CALLER_STREAM = None     # set by run_trunks around the lane launches: the stream the model's forward was called on
 
 
 def _final_join():
-    """End of the backward pass: the caller's stream waits for every encoder lane that ran."""
-    cur = torch.cuda.current_stream()
-    for st in _JOIN["streams"]:
-        cur.wait_stream(st)
+    """End of the backward pass: the stream the step runs on waits for every encoder lane that ran.  That stream is the
+    one the forward was called on (recorded then): this callback may run on autograd's worker thread, whose own current
+    stream is not the caller's -- under HIP-graph capture it is not even part of the capture."""
+    for st, caller in _JOIN["streams"]:
+        (caller if caller is not None else torch.cuda.current_stream()).wait_stream(st)
     _JOIN["streams"] = []
     _JOIN["queued"] = False
 
 
-def _register_join(stream):
-    _JOIN["streams"].append(stream)
+def _register_join(stream, caller=None):
+    _JOIN["streams"].append((stream, caller))
     if not _JOIN["queued"]:
         _JOIN["queued"] = True
         from torch.autograd import Variable
@@ -332,7 +334,7 @@ class EncoderFn(torch.autograd.Function):
         if keep:
             if 0 in rset:
                 c0 = None          # the stem output is rebuilt in backward too (one cheap 7x7 conv; 64 x H/2 x W/2 floats)
-            ctx.state = dict(x=x, c0=c0, s0=s0, am=am, stages=stages_saved, any_recompute=bool(rset),
+            ctx.state = dict(x=x, c0=c0, s0=s0, am=am, stages=stages_saved, any_recompute=bool(rset), caller=CALLER_STREAM,
                              block_level=block_level,
                              dims=(N, H, W, H1, W1), last=(Hc, Wc, C), st=st, lane=lane, train=train)
         return out
@@ -353,7 +355,7 @@ class EncoderFn(torch.autograd.Function):
             gout.record_stream(main_s)
         with torch.cuda.stream(main_s):
             out = EncoderFn._backward_body(S, gout, side_s)
-        _register_join(main_s)
+        _register_join(main_s, S.get("caller"))
         return out
 
     @staticmethod

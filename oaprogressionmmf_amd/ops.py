@@ -458,16 +458,22 @@ def relu_bwd(dy, y):
     return dx
 
 
-def dropout(x, p, seed):
+def dropout(x, p, seed, epoch=None):
+    """epoch: optional int64 device scalar folded into the seed (functional.DeviceStepState)"""
     y = torch.empty_like(x)
-    check(lib().koaf_dropout(_ptr(x), _ptr(y), x.numel(), p, seed, _stream()), "dropout")
+    check(lib().koaf_dropout(_ptr(x), _ptr(y), x.numel(), p, seed, _ptr(epoch), _stream()), "dropout")
     return y
 
 
-def dropout2d(x, N, HW, C, p, seed):
+def dropout2d(x, N, HW, C, p, seed, epoch=None):
     y = torch.empty_like(x)
-    check(lib().koaf_dropout2d(_ptr(x), _ptr(y), N, HW, C, p, seed, _stream()), "dropout2d")
+    check(lib().koaf_dropout2d(_ptr(x), _ptr(y), N, HW, C, p, seed, _ptr(epoch), _stream()), "dropout2d")
     return y
+
+
+def counter_add(counter, delta=1):
+    """counter (int64 device scalar) += delta, on the stream (a graph node when the step is captured)"""
+    check(lib().koaf_counter_add(_ptr(counter), delta, _stream()), "counter_add")
 
 
 def add(a, b):
@@ -488,9 +494,17 @@ def focal_loss(logits, target, gamma, mean=True, focal=True):
     return loss, dl
 
 
-def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, adamw=False):
+def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, adamw=False, hyper=None):
+    """hyper: optional device float[3] from adam_hyper() -- lr and step then come from the device (captured steps)"""
     check(lib().koaf_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, b1, b2, eps, wd, step, 1 if adamw else 0,
-                               _stream()), "adam_step")
+                               _ptr(hyper), _stream()), "adam_step")
+
+
+def adam_hyper(step, lr, b1, b2, hyper):
+    """++step (int32 device scalar); hyper[3] = {lr, lr / (1 - b1^step), sqrt(1 - b2^step)} from the device scalars"""
+    if step.dtype != torch.int32 or not step.is_cuda:
+        raise KoafError("adam_hyper: step is an int32 device scalar")
+    check(lib().koaf_adam_hyper(step.data_ptr(), _ptr(lr), b1, b2, _ptr(hyper), _stream()), "adam_hyper")
 
 
 def build_weight_planes(w, R, taps, C):

@@ -2,9 +2,9 @@
 path.  The drivers themselves (hydra, data loaders, tensorboard, metrics) stay the reference's."""
 from ._steps import downscale_inputs, train_step, predict_batch
 from ._eval import eval_epoch, ensemble_eval_foldw, InferenceTimer
-from ._graph import GraphedPredictor
+from ._graph import GraphedPredictor, GraphedTrainStep
 from ._explain import explain_epoch, ensemble_explain_foldw, modal_ablation, ablation_percent
 
 __all__ = ["downscale_inputs", "train_step", "predict_batch", "eval_epoch", "ensemble_eval_foldw",
-           "InferenceTimer", "GraphedPredictor", "explain_epoch", "ensemble_explain_foldw", "modal_ablation",
+           "InferenceTimer", "GraphedPredictor", "GraphedTrainStep", "explain_epoch", "ensemble_explain_foldw", "modal_ablation",
            "ablation_percent"]

@@ -1,15 +1,19 @@
-"""HIP-graph replay of the inference pass.
+"""HIP-graph replay of the inference pass and of the train step.
 
 One patient at a time the forward of the fusion model is launch-bound (about 1 700 kernel launches for four encoders and
 four transformers against a few milliseconds of GPU work): capturing `predict_batch` once into a HIP graph and replaying it
 removes the per-launch host cost (batch 1, native sizes: 13.2 -> 7.9 ms).  The encoder lanes (one HIP stream each) fork
 from and join the capturing stream inside the capture, so the graph keeps their concurrency.
 
-Only the evaluation regime is captured: training draws dropout seeds on the host every step and updates BatchNorm
-running statistics through host-visible counters, which a static graph would freeze."""
+The TRAIN step (train_prog_fus.py:132-168) is captured too (GraphedTrainStep): everything that changes from step to step
+lives in device memory -- the dropout step counter folded into every mask seed (functional.DeviceStepState), Adam's update
+count and learning rate (Adam(capturable=True), koaf_adam_hyper), BatchNorm's num_batches_tracked (bumped by the finalize
+kernel), the weight plane images (rebuilt by a node of the graph) -- and the lane joins at the end of backward() are
+recorded inside the capture."""
 import torch
 
-from ._steps import predict_batch
+from .. import functional as KF
+from ._steps import predict_batch, train_step
 
 
 class GraphedPredictor(object):
@@ -46,3 +50,63 @@ class GraphedPredictor(object):
             dst.copy_(src, non_blocking=True)
         self.graph.replay()
         return self.static_out
+
+
+class GraphedTrainStep(object):
+    """step = GraphedTrainStep(model, loss_fn, optimizer, example_xs, example_ys[, downscale]);  logits, loss = step(xs, ys)
+
+    The first `warmup` calls run the step eagerly (arena adoption, optimizer state, allocator warm-up: real training steps),
+    the next call captures it into a HIP graph and replays it, later calls only copy the batch into the captured input
+    buffers and replay.  Eager and replayed steps are the same kernels on the same device-resident step state, so a run
+    is bit-identical whether or not (and when) it switches to replay.  `optimizer` must be Adam/AdamW(capturable=True);
+    `model` a registry model on one GPU (the RCCL exchange of DataParallelRCCL is not captured).  The returned tensors are
+    owned by the graph and overwritten by the next call.  Learning-rate changes (schedulers) are picked up at every call."""
+
+    def __init__(self, model, loss_fn, optimizer, example_xs, example_ys, downscale=None, warmup=2, seed=None):
+        if not getattr(optimizer, "capturable", False):
+            raise RuntimeError("GraphedTrainStep needs Adam/AdamW(capturable=True): step count and learning rate on the device")
+        if hasattr(model, "reduce_gradients"):
+            raise RuntimeError("GraphedTrainStep captures single-GPU steps (the RCCL gradient exchange is not captured)")
+        self.model, self.loss_fn, self.opt, self.downscale = model, loss_fn, optimizer, downscale
+        self.xs = [x.detach().clone().contiguous() for x in example_xs]
+        self.ys = example_ys.detach().clone().contiguous()
+        if not all(x.is_cuda for x in self.xs):
+            raise RuntimeError("GraphedTrainStep needs inputs on the HIP device (there is no CPU path)")
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())    # (set_ultimate_seed makes it repeatable)
+        self.state = KF.DeviceStepState(self.xs[0].device, seed)
+        self.warmup, self.calls, self.graph, self.out = int(warmup), 0, None, None
+
+    def _body(self):
+        # (the per-lane weight-gradient side streams stay off in these steps: with encoder lanes AND side streams forked
+        # inside one capture, ROCm 7.2's hipStreamEndCapture crashes; each alone captures fine.  Same kernels, same bits --
+        # only the wgrad / BatchNorm-backward overlap inside a lane is given up, which launch-bound steps do not miss.)
+        from ..models import _encoder
+        prev, KF.STEP_STATE = KF.STEP_STATE, self.state
+        side, _encoder.USE_SIDE_STREAM = _encoder.USE_SIDE_STREAM, False
+        try:
+            self.state.begin_step()
+            return train_step(self.model, self.loss_fn, self.opt, self.xs, self.ys, self.downscale)
+        finally:
+            KF.STEP_STATE = prev
+            _encoder.USE_SIDE_STREAM = side
+
+    def __call__(self, xs, ys):
+        if len(xs) != len(self.xs):
+            raise TypeError(f"expected {len(self.xs)} inputs, got {len(xs)}")
+        for dst, src in zip(self.xs + [self.ys], list(xs) + [ys]):
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"input shape {tuple(src.shape)} differs from the captured {tuple(dst.shape)}")
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self.calls += 1
+        if self.graph is None and self.calls <= self.warmup:
+            return self._body()
+        self.opt.sync_hyper()
+        if self.graph is None:
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._body()
+        self.graph.replay()
+        return self.out

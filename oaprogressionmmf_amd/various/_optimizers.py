@@ -15,12 +15,17 @@ from ..arena import _round_up
 class Adam(optim.Optimizer):
     _ADAMW = False
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, capturable=False):
+        """capturable (as in torch.optim.Adam): learning rate and step count live in device memory (koaf_adam_hyper), so that
+        step() can be captured into a HIP graph and still advance on every replay (run.GraphedTrainStep); arena parameters
+        only, one shared update count (every trained parameter receives a gradient every step)."""
         if amsgrad:
             raise NotImplementedError("amsgrad is not built")
         if lr < 0 or eps < 0 or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.capturable = bool(capturable)
+        self._dev = {}       # capturable: (id(arena), group index) -> dict(step int32[1], lr float[1], hyper float[3], lr_host)
         self._flat = {}      # id(arena) -> dict(m, v) flat moment buffers
         self._loose = {}     # id(param) -> dict(m, v) for parameters outside any arena
         self._steps = {}     # id(param) -> number of updates it has received (torch keeps `step` per parameter)
@@ -51,6 +56,9 @@ class Adam(optim.Optimizer):
                     self._step_loose(p, lr, b1, b2, eps, wd)
             for a, plist in by_arena.values():
                 stt = self._arena_state(a)
+                if self.capturable:
+                    self._step_capturable(a, plist, stt, group, lr, b1, b2, eps, wd)
+                    continue
                 # the bias correction depends on the parameter's own update count: one fused launch per contiguous run
                 # of parameters with the same count (for the reference models: every trained parameter, one count)
                 by_step = {}
@@ -64,6 +72,42 @@ class Adam(optim.Optimizer):
                                       eps, wd, n, self._ADAMW)
                 a.epoch += 1             # the weights changed under the arena's plane images (arena.ensure_planes)
         return loss
+
+    def _dev_state(self, a, group):
+        key = (id(a), id(group))
+        d = self._dev.get(key)
+        if d is None:
+            d = dict(step=torch.full((1,), int(getattr(self, "_resume_step", 0)), dtype=torch.int32, device=a.device),
+                     lr=torch.full((1,), float(group["lr"]), device=a.device), hyper=torch.zeros(3, device=a.device),
+                     lr_host=float(group["lr"]), params=set())
+            self._dev[key] = d
+        return d
+
+    def sync_hyper(self):
+        """copy the (scheduler-driven) learning rates to their device scalars; call outside a graph capture / before a replay"""
+        for group in self.param_groups:
+            for (aid, gid), d in self._dev.items():
+                if gid == id(group) and d["lr_host"] != float(group["lr"]):
+                    d["lr"].fill_(float(group["lr"]))
+                    d["lr_host"] = float(group["lr"])
+
+    def _step_capturable(self, a, plist, stt, group, lr, b1, b2, eps, wd):
+        d = self._dev_state(a, group)
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()
+        d["params"].update(id(p) for p in plist)
+        ops.adam_hyper(d["step"], d["lr"], b1, b2, d["hyper"])
+        for lo, hi in a.active_ranges(plist):
+            ops.adam_step(a.P[lo:hi], a.G[lo:hi], stt["m"][lo:hi], stt["v"][lo:hi], hi - lo, lr, b1, b2, eps, wd, 1,
+                          self._ADAMW, hyper=d["hyper"])
+        a.epoch += 1
+
+    def _sync_steps(self):
+        """capturable: the per-parameter update counts torch's state_dict layout wants, from the device counters"""
+        for d in self._dev.values():
+            n = int(d["step"].item())
+            for pid in d["params"]:
+                self._steps[pid] = n
 
     def _arena_state(self, a):
         stt = self._flat.get(id(a))
@@ -110,6 +154,8 @@ class Adam(optim.Optimizer):
         self._pending = {}
 
     def state_dict(self):
+        if self.capturable:
+            self._sync_steps()
         sd = super().state_dict()            # param_groups with index lists; `state` is kept outside self.state
         params = [p for g in self.param_groups for p in g["params"]]
         state = {}
@@ -132,6 +178,13 @@ class Adam(optim.Optimizer):
         if len(ids) != len(params):
             raise ValueError("loaded state dict has a different number of parameters")
         self._steps, self._pending = {}, {}
+        if self.capturable and state_dict["state"]:
+            counts = {int(round(float(st["step"]))) for st in state_dict["state"].values()}
+            if len(counts) != 1:
+                raise ValueError("capturable Adam keeps one update count for all parameters; the loaded state has several")
+            self._resume_step = counts.pop()         # (device counters created later start here)
+            for d in self._dev.values():
+                d["step"].fill_(self._resume_step)
         for stt in list(self._flat.values()) + list(self._loose.values()):
             stt["m"].zero_()
             stt["v"].zero_()

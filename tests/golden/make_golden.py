@@ -123,7 +123,11 @@ def fp64_twin(build, run, grads32, logits32):
     return out
 
 
-def run_model_case(km, losses, cfg, B, fname, eval_fwd=True, train_step=True, adam_steps=0, seed=1234):
+def run_model_case(km, losses, cfg, B, fname, eval_fwd=True, train_step=True, adam_steps=0, seed=1234, tensor_shapes=None,
+                   twin=True):
+    """tensor_shapes: sizes of the input TENSORS when they differ from the config's `input_size` (the reference's
+    constructors assert on config sizes only; forward never checks tensor shapes); twin=False skips the float64 run
+    (full-size cases whose saved activations would not fit the build container in float64)."""
     t0 = time.time()
 
     def build():
@@ -133,11 +137,13 @@ def run_model_case(km, losses, cfg, B, fname, eval_fwd=True, train_step=True, ad
         return m
 
     model = build()
-    xs = [t(a) for a in P.model_inputs(cfg, B, seed)]
+    xs = [t(a) for a in P.model_inputs(dict(cfg, input_size=tensor_shapes) if tensor_shapes else cfg, B, seed)]
     y = t(P.make_target("target", B, seed))
     loss_fn = losses.FocalLoss(reduction="mean", gamma=2.0, num_classes=2)
     out = {"B": np.int64(B), "cfg_json": np.array(json.dumps(cfg)), "seed": np.int64(seed),
            "torch_version": np.array(torch.__version__)}
+    if tensor_shapes:
+        out["tensor_shapes_json"] = np.array(json.dumps(tensor_shapes))
     if eval_fwd:
         model.eval()
         with torch.no_grad():
@@ -160,8 +166,9 @@ def run_model_case(km, losses, cfg, B, fname, eval_fwd=True, train_step=True, ad
             ls = loss_fn(input=lg.squeeze(1), target=y.long().squeeze(1))
             ls.backward()
             return lg.detach(), {k: p.grad.detach() for k, p in m64.named_parameters() if p.grad is not None}
-        g32 = {k: p.grad.detach() for k, p in model.named_parameters() if p.grad is not None}
-        out.update(fp64_twin(build, run64, g32, logits.detach()))
+        if twin:
+            g32 = {k: p.grad.detach() for k, p in model.named_parameters() if p.grad is not None}
+            out.update(fp64_twin(build, run64, g32, logits.detach()))
     if adam_steps:
         # continue from the state after the train step above: 3 Adam steps on the same batch
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
@@ -434,10 +441,61 @@ def case_f11_bookkeeping(km, losses, **_):
     print("  wrote f11_bookkeeping.json")
 
 
+def case_f14_fullsize(km, tv, losses, **_):
+    """BASELINE.json's full sizes (384^2 slices, 160 slices per volume, 483 fusion tokens): values, not only properties"""
+    t0 = time.time()
+    out = {}
+    arch, shape = "resnet50", (2, 1, 384, 384)
+
+    def build():
+        torch.manual_seed(0)
+        net = getattr(tv, arch)(pretrained=False)
+        tr = torch.nn.Sequential(*list(net.children())[:-1])
+        P.fill_state_dict(tr.state_dict())
+        return tr
+    trunk = build()
+    x = t(P.make_input("trunk", shape)).repeat(1, 3, 1, 1)
+    tag = f"{arch}_{shape[0]}x{shape[2]}x{shape[3]}"
+    trunk.eval()
+    with torch.no_grad():
+        out[tag + ":eval"] = trunk(x).numpy()
+
+    def run(m, dt):
+        m.train()
+        yy = m(x.to(dt))
+        (yy * t(P.make_input("trunkg", tuple(yy.shape))).to(dt)).sum().backward()
+        return yy.detach(), {k: p.grad.detach() for k, p in m.named_parameters()}
+    y, g32 = run(trunk, torch.float32)
+    out[tag + ":train"] = y.numpy()
+    out.update({tag + ":" + k: v for k, v in P.summarize_tensors({"grad:" + k: v.numpy() for k, v in g32.items()}).items()})
+    out.update({tag + ":" + k: v for k, v in P.summarize_tensors({"buf:" + k: b.numpy() for k, b in trunk.named_buffers()}).items()})
+    out.update({tag + ":" + k: v for k, v in fp64_twin(build, run, g32, y).items()})
+    np.savez_compressed(HERE / "f14_trunk384.npz", **out)
+    print(f"  wrote f14_trunk384.npz in {time.time() - t0:.1f}s")
+    # the fusion transformer at the synthetic-shape token count: 482 tokens + cls
+    t0 = time.time()
+    torch.manual_seed(0)
+    f = km.FeaT(num_patches=482, patch_dim=2048, emb_dim=2048, depth=4, heads=8, mlp_dim=2048, num_classes=2, with_cls=True)
+    P.fill_state_dict(f.state_dict())
+    f.train()                                       # (all dropout probabilities are 0)
+    xf = t(P.make_input("feat483", (2, 482, 2048))).requires_grad_(True)
+    o, st, att = f(xf)
+    ((o * t(P.make_input("feat483go", tuple(o.shape)))).sum() + (st * t(P.make_input("feat483gs", tuple(st.shape)))).sum() * 1e-2).backward()
+    fo = {"outputs": o.detach().numpy()}
+    fo.update(P.summarize_tensors({"states": st.detach().numpy(), "attn0": att[0].detach().numpy(),
+                                   "attn3": att[3].detach().numpy(), "dx": xf.grad.numpy()}, k=64))
+    fo.update(P.summarize_tensors({"grad:" + k: p.grad.numpy() for k, p in f.named_parameters() if p.grad is not None}))
+    np.savez_compressed(HERE / "f14_feat483.npz", **fo)
+    print(f"  wrote f14_feat483.npz in {time.time() - t0:.1f}s")
+    del f, trunk
+    # BASELINE config 3's pinned class on its full tensor: one DESS volume of 160 slices x 384 x 384
+    run_model_case(km, losses, P.cfg_mr1(shape=(320, 320, 160)), 1, "f14_mr1_s160_384.npz", tensor_shapes=[[384, 384, 160]], twin=False)
+
+
 CASES = {
     "f1": case_f1_attention_feat, "f2": case_f2_bottleneck, "f3": case_f3_trunk, "f4": case_f4_xr1cnn,
     "f5": case_f5_mr, "f5g": case_f5_nogap, "f6": case_f6_full, "f7": case_f7_focal, "f8": case_f8_interp, "f9": case_f9_sched,
-    "f11": case_f11_bookkeeping, "f12": case_f12_augment, "f13": case_f13_modal_abl,
+    "f11": case_f11_bookkeeping, "f12": case_f12_augment, "f13": case_f13_modal_abl, "f14": case_f14_fullsize,
 }
 
 

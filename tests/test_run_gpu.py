@@ -215,3 +215,66 @@ def test_explain_epoch_modal_ablation(dev):
     np.testing.assert_allclose(np.asarray(ens["modal_abl_percent"]) * 100.0, acc["modal_abl_percent"], atol=2e-3)
     with pytest.raises(ValueError):
         explain_epoch(m, loader, MODALS, explain_fn="grad_cam")
+
+
+def test_graphed_train_step_replay_is_bit_identical_to_eager(dev):
+    """run.GraphedTrainStep: one eager step, then the captured step replayed three times == four eager steps of the same
+    kernels on the same device-resident step state: losses, logits and every parameter bit-identical.  Dropout is ON (0.1):
+    the masks change from replay to replay (device step counter), BatchNorm's num_batches_tracked and Adam's update count
+    advance inside the graph, and the optimizer state exported afterwards carries the right count."""
+    from oaprogressionmmf_amd.run import GraphedTrainStep
+    from oaprogressionmmf_amd.various import dict_losses, dict_optimizers
+    cfg = P.cfg_full(xr=(96, 96), mr1=(64, 64, 6), mr2=(64, 64, 5), depth=1, dropout=0.1)
+    B = 2
+    xs = [t(a).to(dev) for a in P.model_inputs(cfg, B, 11)]
+    ys = t(P.make_target("target", B, 11)).to(dev)
+    loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
+    runs = []
+    for warmup in (100, 1):                              # never captures / captures at the second call
+        m = build(cfg, dev).train()
+        opt = dict_optimizers["Adam"](m.parameters(), lr=2e-5, weight_decay=1e-4, capturable=True)
+        step = GraphedTrainStep(m, loss_fn, opt, xs, ys, warmup=warmup, seed=4242)
+        losses, logits = [], []
+        for it in range(4):
+            if it == 2:
+                opt.param_groups[0]["lr"] = 1e-5         # a scheduler step between two replays
+            lg, ls = step(xs, ys)
+            losses.append(float(ls))
+            logits.append(lg.clone())
+        assert (step.graph is not None) == (warmup == 1)
+        sd = opt.state_dict()
+        assert {float(v["step"]) for v in sd["state"].values()} == {4.0}
+        nbt = {int(b) for k, b in m.named_buffers() if k.endswith("num_batches_tracked")}
+        assert nbt == {4}
+        runs.append((losses, logits, {k: p.detach().clone() for k, p in m.named_parameters()}))
+    (l0, g0, p0), (l1, g1, p1) = runs
+    assert l0 == l1, (l0, l1)
+    assert len(set(l0)) == 4                             # the steps differ (training moves, fresh dropout masks)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+
+
+def test_graphed_train_step_dropout_masks_follow_the_device_counter(dev):
+    """the same call site draws a different mask after every begin_step() and the same mask within a step (forward and
+    backward regenerate it from (salt, epoch)); without a step state the host-drawn seed path is unchanged"""
+    from oaprogressionmmf_amd import functional as KF
+    st = KF.DeviceStepState(dev, 99)
+    x = torch.ones(4096, device=dev, requires_grad=True)
+    masks = []
+    KF.STEP_STATE = st
+    try:
+        for _ in range(3):
+            st.begin_step()
+            y = KF.dropout(x, 0.5, True)
+            y.sum().backward()
+            assert torch.equal((x.grad > 0), (y > 0))     # backward regenerated the forward's mask
+            x.grad = None
+            masks.append((y > 0).clone())
+        st.site = 0                                       # same site, same epoch -> same mask
+        assert torch.equal((KF.dropout(x, 0.5, True) > 0), masks[-1])
+    finally:
+        KF.STEP_STATE = None
+    assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
+    assert abs(float(masks[0].float().mean()) - 0.5) < 0.05
