@@ -70,6 +70,9 @@ def parse_args(argv=None):
                     help="activation recompute in the encoders: auto (workload default), none, stage (every stage), block "
                          "(one block at a time), or stage indices per MRI encoder, e.g. '012,01,01' (0 = layer1; encoders in "
                          "forward order; one entry = all encoders)")
+    ap.add_argument("--graph", action="store_true",
+                    help="1 GPU: capture the train step into a HIP graph after 2 eager steps and replay it (run.GraphedTrainStep): "
+                         "for the launch-bound small configurations (xr1cnn, xr1c1)")
     ap.add_argument("--breakdown", default="", help="write a per-shape table of the instrumented step to this file")
     ap.add_argument("--serial", action="store_true",
                     help="one HIP stream only (no encoder lanes / wgrad side stream): kernel durations seen by a profiler "
@@ -326,7 +329,7 @@ def main(args):
         policy = apply_recompute(model, rdef if (recompute == "auto" and B >= bdef) else ("none" if recompute == "auto" else recompute))
         ddp = DataParallelRCCL(model, exchange_always=dist_on)
         loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
-        opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4)
+        opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=bool(args.graph))
         xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(dict(cfg, input_size=shapes) if shapes else cfg, B, seed=1234 + rank)]
         y = torch.from_numpy(P.make_target("target", B, seed=1234 + rank)).to(dev)
         model.train()
@@ -338,6 +341,16 @@ def main(args):
                 logits, proba = predict_batch(model, xs)
                 return float(proba[0, 0].item())       # the driver's per-batch host read (argmax / softmax go to the CPU)
             return cfg, B, policy, step_eval
+
+        if args.graph:
+            if dist_on:
+                raise SystemExit("--graph captures single-GPU steps")
+            from oaprogressionmmf_amd.run import GraphedTrainStep
+            gstep = GraphedTrainStep(model, lambda lg, tg: loss_fn(input=lg, target=tg), opt, xs, y, warmup=2)
+
+            def step_graph():
+                return gstep(xs, y)[1].item()
+            return cfg, B, policy, step_graph
 
         def step():
             opt.zero_grad()
@@ -395,6 +408,15 @@ def main(args):
     if dist_on and comm_ms:
         comm_exposed = round(statistics.mean(a.elapsed_time(b) for a, b in comm_ms), 3)
 
+    if args.graph:
+        if rank == 0:
+            print(json.dumps({"metric": "knees/sec full XR+MRI+clin fusion train step", "value": round(world * B * args.steps / dt, 3),
+                              "unit": "knees/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_step_median": round(statistics.median(per), 3),
+                              "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": f"{args.workload}: {cfg['name']} train step replayed from a HIP graph "
+                                                     f"(run.GraphedTrainStep), per-GPU batch {B}", "last_loss": round(lv, 6)}}))
+        return
     # one extra instrumented step: live event timing of every MFMA-GEMM launch on its launch stream
     _encoder.USE_SIDE_STREAM = False      # serialise: per-kernel durations are not inflated by co-running kernels
     _common.USE_LANES = False

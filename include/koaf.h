@@ -290,6 +290,10 @@ int koaf_bn_bwd_apply(const float* dz, const float* c, const float* mean, const 
 
 /* ---- input pipeline on the device (koafusion/preproc/_pt.py; applied per sample by the reference's CPU loader
  * workers, koafusion/datasets/_data_provider.py:295-335) ------------------------------------------------------- */
+/* Integer volumes as stored on disk (dtype 1 = uint8: radiograph PNGs, 2 = uint16, 3 = int16: MRI NIfTI) -> fp32.  The loader
+ * ships the raw integers over PCIe (4x / 2x fewer bytes than the fp32 tensors the reference's workers produce,
+ * _data_provider.py:460-498) and the device widens them ahead of koaf_minmax / koaf_augment. */
+int koaf_widen(const void* x, int32_t dtype, float* y, int64_t n, void* stream);
 /* per-sample minimum and maximum of x [B][n] -> mm [B][2]; ws: B * koaf_minmax_ws(n) floats.  PTToUnitRange :75-99 */
 int64_t koaf_minmax_ws(int64_t n);
 int koaf_minmax(const float* x, int32_t B, int64_t n, float* mm, float* ws, void* stream);

@@ -761,6 +761,18 @@ __global__ void __launch_bounds__(256) dropout2d_kernel(const float* __restrict_
 
 __global__ void counter_add_kernel(int64_t* ctr, int64_t delta) { *ctr += delta; }
 
+// integer volumes as they come off the disk (uint8 radiographs, uint16 / int16 MRI) -> fp32, 16 elements per thread step
+template <typename T>
+__global__ void __launch_bounds__(256) widen_kernel(const T* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t nv = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * EB) {
+        T v[4];
+        __builtin_memcpy(v, x + i * 4, sizeof(v));        // one 4- or 8-byte load (4-element alignment checked by the caller)
+        *(v4f*)&y[i * 4] = (v4f){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[nv * 4 + threadIdx.x] = (float)x[nv * 4 + threadIdx.x];
+}
+
 __global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ p, float v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n; i += (int64_t)gridDim.x * EB) p[i] = v;
 }
@@ -1103,6 +1115,15 @@ extern "C" int koaf_relu_bwd(const float* dy, const float* y, float* dx, int64_t
 extern "C" int koaf_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
     KOAF_REQUIRE(b, "koaf_add: bad args");
     PW_LAUNCH(PW_ADD, a, b, out, n, "koaf_add");
+}
+extern "C" int koaf_widen(const void* x, int32_t dtype, float* y, int64_t n, void* stream) {
+    KOAF_REQUIRE(x && y && n > 0 && dtype >= 1 && dtype <= 3, "koaf_widen: bad args (dtype 1 = uint8, 2 = uint16, 3 = int16)");
+    KOAF_REQUIRE(al16(y) && (((uintptr_t)x) & 7) == 0, "koaf_widen: unaligned");
+    const unsigned grid = ew_grid(n / 4 + 1);
+    if (dtype == 1) hipLaunchKernelGGL(widen_kernel<uint8_t>, dim3(grid), dim3(EB), 0, STREAM, (const uint8_t*)x, y, n);
+    else if (dtype == 2) hipLaunchKernelGGL(widen_kernel<uint16_t>, dim3(grid), dim3(EB), 0, STREAM, (const uint16_t*)x, y, n);
+    else hipLaunchKernelGGL(widen_kernel<int16_t>, dim3(grid), dim3(EB), 0, STREAM, (const int16_t*)x, y, n);
+    return koaf_check_launch("koaf_widen");
 }
 extern "C" int koaf_counter_add(int64_t* counter, int64_t delta, void* stream) {
     KOAF_REQUIRE(counter, "koaf_counter_add: null counter");

@@ -122,10 +122,17 @@ class _SideStream:
     """Second HIP stream for the weight gradients.  In backward every wgrad GEMM is off the critical path
     (dgrad -> BatchNorm backward -> next dgrad), so they run here: MFMA-bound wgrad blocks fill the CUs while the
     main stream runs HBM-bound BatchNorm kernels or the tail of a dgrad.  Gradients are delivered (p.grad /
-    data-parallel hook) only after the main stream has joined this one."""
+    data-parallel hook) only after the main stream has joined this one.
+
+    Two ways to keep the tensors a weight gradient reads alive under the lagging stream: record_stream() (free running:
+    one join at the end of the encoder's backward), or -- `hold`, for activation recompute -- this object keeps the
+    references and the main stream joins after every block: tensors handed over with record_stream() are recycled by the
+    caching allocator only once the side stream's events have completed, which at recompute-sized footprints (a 102 GB stage
+    rebuilt at a time) drove the reserved pool to the HBM limit and every allocation into a synchronising retry; with a join
+    per block the main stream is ordered behind the reads before the tensors die, so plain stream-ordered reuse is safe."""
     _streams = {}
 
-    def __init__(self, device, stream=None):
+    def __init__(self, device, stream=None, hold=False):
         if stream is None:
             key = (device.type, device.index)
             if key not in _SideStream._streams:
@@ -133,15 +140,20 @@ class _SideStream:
             stream = _SideStream._streams[key]
         self.stream = stream
         self.pending = []
+        self.hold = hold
+        self.held = []
 
     def run(self, inputs, fn, param, buf, acc):
         main = torch.cuda.current_stream()
         self.stream.wait_stream(main)
         with torch.cuda.stream(self.stream):
             fn()
-        for t in inputs:
-            if t is not None:
-                t.record_stream(self.stream)     # the caching allocator must not recycle them under the side stream
+        if self.hold:
+            self.held.append(inputs)
+        else:
+            for t in inputs:
+                if t is not None:
+                    t.record_stream(self.stream)     # the caching allocator must not recycle them under the side stream
         self.pending.append((param, buf, acc))
 
     def join(self):
@@ -149,6 +161,7 @@ class _SideStream:
         for param, buf, acc in self.pending:
             deliver_grad(param, buf, acc)
         self.pending = []
+        self.held = []
 
 
 def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True, side=None, bnb=None):
@@ -427,6 +440,8 @@ class EncoderFn(torch.autograd.Function):
             else:
                 dy, pend = res, None
             del dc1, da1, dz, resid, r
+            if side is not None and side.hold:
+                side.join()        # (recompute: the block's tensors may die now, see _SideStream)
         return dy
 
     @staticmethod
@@ -440,10 +455,7 @@ class EncoderFn(torch.autograd.Function):
             dy = gout.permute(0, 2, 3, 1).contiguous()
             if dy.data_ptr() == gout.data_ptr():
                 dy = dy.clone()  # masked in place below
-        # (no wgrad side stream under activation recompute: tensors handed to a second stream are recycled by the
-        # caching allocator only once that stream's events have completed, which at recompute-sized footprints
-        # drives the reserved pool to the HBM limit and every later allocation into a synchronising retry)
-        side = _SideStream(gout.device, side_stream) if (USE_SIDE_STREAM and not S["any_recompute"]) else None
+        side = _SideStream(gout.device, side_stream, hold=S["any_recompute"]) if USE_SIDE_STREAM else None
         stages = st["stages"]
         run = []      # block records of consecutive kept stages: one list, so the fused tail reductions cross stage boundaries
         for si in range(len(stages) - 1, -1, -1):

@@ -345,6 +345,21 @@ def downscale2(x, B, R, Cc, S, fs):
 # ------------------------------------------------------------------------------------------------
 # transformer pieces
 # ------------------------------------------------------------------------------------------------
+_WIDEN = {torch.uint8: 1, torch.uint16: 2, torch.int16: 3}
+
+
+def widen(x):
+    """uint8 / uint16 / int16 device tensor -> fp32 (koaf_widen); fp32 passes through"""
+    if x.dtype == torch.float32:
+        return x
+    if x.dtype not in _WIDEN or not x.is_cuda:
+        raise KoafError(f"widen: uint8 / uint16 / int16 tensors on the HIP device, got {x.dtype} on {x.device}")
+    x = x.contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(lib().koaf_widen(x.data_ptr(), _WIDEN[x.dtype], _ptr(y), x.numel(), _stream()), "widen")
+    return y
+
+
 def minmax(x, B):
     """per-sample (min, max) of a contiguous batch -> [B, 2]"""
     n = x.numel() // B

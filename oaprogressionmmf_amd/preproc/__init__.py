@@ -1,1 +1,1 @@
-from ._pt import PTBatchAugment, PTInterpolate
+from ._pt import PTBatchAugment, PTInterpolate, PinnedPrefetcher

@@ -45,37 +45,46 @@ def load_train_state(path, model, optimizer=None, scheduler=None):
 
 
 class CheckpointHandler(object):
-    def __init__(self, path_root, fname_pattern=("{model_name}__fold_{fold_idx}__epoch_{epoch_idx:>03d}.pth"),
-                 num_saved=1):
-        self.path_root = Path(path_root)
-        self.fname_pattern = fname_pattern
-        self.num_saved = num_saved
-        _, ext = os.path.splitext(self.fname_pattern)
-        if not self.path_root.exists():
-            raise ValueError(f"Path {self.path_root} does not exist")
-        self._all_ckpts = sorted(self.path_root.glob("*" + ext))
-        logger.info(f"Checkpoints found: {len(self._all_ckpts)}")
-        self._remove_excessive_ckpts()
+    """Keeps the newest `num_saved` model checkpoints of a run directory (contract of the reference's handler,
+    koafusion/various/_checkpoint.py:14-62: constructor arguments, the file-name pattern
+    `{model_name}__fold_{fold_idx}__epoch_{epoch_idx:>03d}.pth`, `get_last_ckpt()` / `save_new_ckpt()`; a missing
+    directory is a ValueError).  Written around one helper, `_trim()`, that deletes from the oldest end; the list of
+    known checkpoints is rebuilt from the directory listing, so files added by another process are seen too."""
 
-    def _remove_excessive_ckpts(self):
-        while len(self._all_ckpts) > self.num_saved:
+    def __init__(self, path_root, fname_pattern="{model_name}__fold_{fold_idx}__epoch_{epoch_idx:>03d}.pth", num_saved=1):
+        self.path_root = Path(path_root)
+        if not self.path_root.is_dir():
+            raise ValueError(f"Path {self.path_root} does not exist")
+        self.fname_pattern = fname_pattern
+        self.num_saved = int(num_saved)
+        self._suffix = Path(fname_pattern).suffix
+        found = self._listing()
+        logger.info("Checkpoints found: %d", len(found))
+        self._trim()
+
+    def _listing(self):
+        """checkpoint files of the directory, oldest first (the zero-padded epoch makes name order = age order)"""
+        return sorted(p for p in self.path_root.iterdir() if p.is_file() and p.suffix == self._suffix)
+
+    def _trim(self):
+        files = self._listing()
+        for victim in files[:max(0, len(files) - self.num_saved)]:
             try:
-                os.remove(self._all_ckpts[0])
-                logger.info(f"Removed ckpt: {self._all_ckpts[0]}")
-                self._all_ckpts = self._all_ckpts[1:]
+                victim.unlink()
+                logger.info("Removed ckpt: %s", victim)
             except OSError:
-                logger.error(f"Cannot remove {self._all_ckpts[0]}")
-                break
+                logger.error("Cannot remove %s", victim)
+                return
 
     def get_last_ckpt(self):
-        if len(self._all_ckpts) == 0:
-            logger.warning(f"No checkpoints are available in {self.path_root}")
+        files = self._listing()
+        if not files:
+            logger.warning("No checkpoints are available in %s", self.path_root)
             return None
-        return self._all_ckpts[-1]
+        return files[-1]
 
     def save_new_ckpt(self, model, model_name, fold_idx, epoch_idx):
-        fname = self.fname_pattern.format(model_name=model_name, fold_idx=fold_idx, epoch_idx=epoch_idx)
-        path_full = Path(self.path_root, fname)
-        torch.save(portable_state_dict(model), path_full)
-        self._all_ckpts.append(path_full)
-        self._remove_excessive_ckpts()
+        target = self.path_root / self.fname_pattern.format(model_name=model_name, fold_idx=fold_idx, epoch_idx=epoch_idx)
+        torch.save(portable_state_dict(model), target)
+        self._trim()
+        return target

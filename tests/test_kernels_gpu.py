@@ -412,6 +412,33 @@ def test_batch_augment_vs_reference(dev):
         aug(x[:, 0])
 
 
+def test_integer_volume_upload_and_prefetch(dev):
+    """(f-3) the loader ships the volumes as stored on disk -- uint8 radiographs, uint16 / int16 MRI -- and the device
+    widens them (koaf_widen): the same pipeline output as from the fp32 tensor, bit for bit; PinnedPrefetcher stages the
+    next batch in pinned memory on its own stream and hands over identical device tensors in loader order"""
+    from oaprogressionmmf_amd import ops
+    from oaprogressionmmf_amd.preproc import PTBatchAugment, PinnedPrefetcher
+    rng = np.random.default_rng(3)
+    for dt, hi, shape in ((torch.uint8, 255, (3, 1, 30, 22)), (torch.uint16, 4095, (2, 1, 24, 20, 7)), (torch.int16, 3000, (2, 1, 17, 13, 5))):
+        raw = torch.from_numpy(rng.integers(0, hi, size=shape).astype(np.int64)).to(dt)
+        assert torch.equal(ops.widen(raw.to(dev)).cpu(), raw.float())
+        aug = PTBatchAugment(mean=0.4, std=0.2)
+        states = aug.draw(shape[0])
+        assert torch.equal(aug(raw.to(dev), states=states), aug(raw.float().to(dev), states=states))
+    batches = [{"image__xr_pa": torch.from_numpy(rng.integers(0, 255, size=(2, 1, 16, 16)).astype(np.uint8)),
+                "image__sag_3d_dess": torch.from_numpy(rng.integers(0, 4000, size=(2, 1, 8, 8, 4)).astype(np.uint16)),
+                "target": torch.tensor([[i], [i + 1]]), ("-", "exam_knee_id"): [f"k{i}", f"k{i}b"]} for i in range(5)]
+    seen = 0
+    for got, want in zip(PinnedPrefetcher(batches, dev), batches):
+        for k, v in want.items():
+            if torch.is_tensor(v):
+                assert got[k].is_cuda and got[k].dtype == v.dtype and torch.equal(got[k].cpu(), v), k
+            else:
+                assert got[k] == v
+        seen += 1
+    assert seen == len(batches)
+
+
 def test_dropout2d_channels(dev):
     """koaf_dropout2d: whole (image, channel) planes are dropped or scaled by 1/(1-p); the same draws as the
     element-wise generator makes on the pooled (N, C) tensor with the same seed; backward applies the same mask"""
