@@ -54,7 +54,9 @@ typedef struct KoafOperand {
     int32_t KH, KW, stride, pad; /* pad = row (y) padding */
     int32_t pad_w;               /* column (x) padding (set = pad for square padding) */
     int32_t _pad1;
-    int32_t tf;       /* 0 none; 1 relu(sc[c]*x + sh[c]) on load (c = source channel) */
+    int32_t tf;       /* transform on load (c = source channel): 0 none; 1 relu(sc[c]*x + sh[c]); 2 (A operand, fmt 1, vector
+                         path) sc[c]*x + sh[c] - sc2[c]*x2 with x2 read from ptr2 (same layout and strides as ptr): the
+                         BatchNorm-backward apply formed on load, see koaf_bn_bwd_finalize */
     int32_t tf_bs;    /* channel offset of sc/sh per batch index z1 (grouped-conv slabs) */
     const float* sc;
     const float* sh;
@@ -73,6 +75,8 @@ typedef struct KoafOperand {
     const float* amax;
     float fscale;
     int32_t _pad4;
+    const float* ptr2;  /* tf 2: second source tensor */
+    const float* sc2;   /* tf 2: its per-channel coefficient */
 } KoafOperand;
 
 typedef struct KoafGemm {
@@ -118,6 +122,7 @@ typedef struct KoafGemm {
     const float* bnb2_mean;
     const float* bnb2_invstd;
     float* bnb_part;
+    float* bnb_amax;       /* nullable: device scalar raised (atomic max; zero it beforehand) to the largest |dz| stored */
     /* row-space origin of this launch (mixed-height tiling: one GEMM = a 128-row-tile launch over rows
        [0, M1) + a 64-row-tile launch over [M1, M)); partial-statistics rows continue at part_row0 */
     int32_t m_base, part_row0;
@@ -161,6 +166,14 @@ typedef struct KoafWImg {
     const uint16_t* d;      /* D image or NULL */
     const float* amax;      /* max |w| the images were scaled by */
 } KoafWImg;
+/* dy given as its BatchNorm-backward apply (KoafOperand.tf 2): dy = coef0*dz + coef3 - coef2*c with coef [4][Cout] and amax
+ * from koaf_bn_bwd_finalize; dz and c are [N,OH,OW,Cout] like dy.  Needs the fp16 scheme (amax; for dgrad also wimg). */
+typedef struct KoafBnApply {
+    const float* dz;
+    const float* c;
+    const float* coef;
+    const float* amax;
+} KoafBnApply;
 
 /* ---- Convolution (nn.Conv2d, bias-free; _torchvision.py:23-31) as implicit GEMM on NHWC -------
  * x [N,H,W,Cin], w packed [Cout,KH,KW,Cin] (the memory of a channels_last (Cout,Cin,KH,KW)
@@ -180,15 +193,18 @@ int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t
 int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout);
 /* dx [N,H,W,Cin] = conv_transpose(dy [N,OH,OW,Cout], w) (+residual: the other branch's gradient);
  * w is read K-major in place (no re-packed copy).  With wimg AND dy_amax (device scalar: max |dy|, e.g. from
- * koaf_bn_bwd_apply) the contraction runs on the fp16 scheme, the weight tiles DMA'd from wimg->d.  */
+ * koaf_bn_bwd_apply) the contraction runs on the fp16 scheme, the weight tiles DMA'd from wimg->d.  dy_apply (nullable, needs
+ * wimg->d; dy may then be NULL): dy is formed on load from (dz, c), see KoafBnApply.  */
 int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
                       int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride,
-                      int32_t pad, const float* residual, const KoafWImg* wimg, const float* dy_amax, void* stream);
+                      int32_t pad, const float* residual, const KoafWImg* wimg, const float* dy_amax,
+                      const KoafBnApply* dy_apply, void* stream);
 /* Same, with the BatchNorm(+ReLU) backward reduction of the layer that PRODUCED x fused into the epilogue (see
  * KoafGemm.bnb_*): dx receives the masked gradient dz; part [*part_rows][nsum][Cin] (nsum = 2, or 3 with c2) feeds
  * koaf_bn_bwd_finalize.  koaf_conv2d_dgrad_bnb_rows() bounds *part_rows for sizing. */
 typedef struct KoafBnb {
     int32_t mode, _pad;     /* 1: mask y > 0; 2: mask sc*c+sh > 0 */
+    float* dz_amax;         /* nullable: device scalar set to max |dz| (zeroed by the call) -> koaf_bn_bwd_finalize */
     const float* c;
     const float* y;
     const float* sc;
@@ -203,7 +219,7 @@ int32_t koaf_conv2d_dgrad_bnb_rows(int32_t N, int32_t H, int32_t W, int32_t Cin,
 int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
                           int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                           const float* residual, const KoafBnb* bnb, float* part, int32_t* part_rows,
-                          const KoafWImg* wimg, const float* dy_amax, void* stream);
+                          const KoafWImg* wimg, const float* dy_amax, const KoafBnApply* dy_apply, void* stream);
 /* dw packed [Cout,KH,KW,Cin] = sum_pixels dy^T x, x optionally transformed on load.  Deterministic
  * split-K: slabs = workspace of koaf_conv2d_wgrad_ws() floats (0 = none needed).  dy_amax (nullable): max |dy| on the
  * device -> fp16 scheme.  */
@@ -212,7 +228,7 @@ int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t Cin, int32
 int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int32_t N, int32_t H, int32_t W,
                       int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride,
                       int32_t pad, const float* in_sc, const float* in_sh, float* slabs,
-                      const float* dy_amax, void* stream);
+                      const float* dy_amax, const KoafBnApply* dy_apply, void* stream);
 
 /* ---- Grouped 3x3 convolution (ResNeXt 32x4d; _torchvision.py:110,327-330) -------------------
  * Runs on the same MFMA GEMM as 64-channel block-diagonal slabs: packed weights [C][3][3][C/groups]
@@ -272,19 +288,25 @@ int koaf_bn_relu(const float* c, const float* sc, const float* sh, float* y, int
                  int32_t C, void* stream);
 /* backward reduce: dz = g * mask, partial sums of dz and dz*(c-mean)*invstd.
  * mask_mode 0: none; 1: y>0 from tensor `ymask`; 2: sc*c+sh>0 recomputed.  If dz_out != NULL
- * writes the masked gradient.  part [*part_rows][2][C] (koaf_colpart_rows rows). */
+ * writes the masked gradient.  part [*part_rows][2][C] (koaf_colpart_rows rows).  dz_amax (nullable): device scalar set to
+ * max |dz| (for koaf_bn_bwd_finalize's bound). */
 int koaf_bn_bwd_reduce(const float* g, const float* c, const float* ymask, const float* sc,
                        const float* sh, const float* mean, const float* invstd, int32_t mask_mode,
                        float* dz_out, float* part, int32_t* part_rows, int64_t rows, int32_t C,
-                       void* stream);
+                       float* dz_amax, void* stream);
 /* part [rows][nsum][C] -> dgamma (= sum index i1), dbeta (= sum index 0), and apply coefficients
- * coef [3][C] = {sc, dbeta/M, sc*invstd*dgamma/M}.  (nsum, i1) = (2, 1) for the plain layout.  amax_reset (nullable): a
- * device scalar set to 0 (the accumulator koaf_bn_bwd_apply raises). */
+ * coef [3][C] = {sc, dbeta/M, sc*invstd*dgamma/M}.  (nsum, i1) = (2, 1) for the plain layout.
+ * With mean: coef is [4][C], the fourth row = coef2*mean - coef0*coef1, so that dc = coef0*dz + coef3 - coef2*c -- the form
+ * the GEMM loaders evaluate on load (KoafOperand.tf 2: the dgrad / wgrad convolutions then read dz and c and dc is never
+ * written).  amax (nullable, needs mean): device scalar set to a guaranteed bound of max |dc|, the scale of that operand on
+ * the fp16 scheme: max_c |coef0| (dz_amax + |coef1|) + |coef2| sqrt(M - 1) / invstd  (dz_amax: device scalar max |dz| from
+ * koaf_bn_bwd_reduce / KoafBnb.dz_amax; no sample lies further than sqrt(M - 1) standard deviations from its mean). */
 int koaf_bn_bwd_finalize(const float* part, int32_t part_rows, int32_t C, int64_t count,
                          const float* sc, const float* invstd, float* dgamma, float* dbeta,
-                         float* coef, int32_t nsum, int32_t i1, double* ws, float* amax_reset, void* stream);
-/* dc = coef0*(dz - coef1) - coef2*(c - mean).  amax (nullable): device scalar raised to max |dc| (atomic max; it must be
- * zero beforehand: hand it to koaf_bn_bwd_finalize as amax_reset) -- the scale of dc as an operand of the fp16 scheme. */
+                         float* coef, int32_t nsum, int32_t i1, double* ws, const float* mean,
+                         const float* dz_amax, float* amax, void* stream);
+/* dc = coef0*(dz - coef1) - coef2*(c - mean), materialised (consumers that are not GEMMs: the stem's weight gradient; GEMMs
+ * without scale information).  amax (nullable): device scalar raised to max |dc| (atomic max; zero it beforehand). */
 int koaf_bn_bwd_apply(const float* dz, const float* c, const float* mean, const float* coef,
                       float* dc, int64_t rows, int32_t C, float* amax, void* stream);
 

@@ -45,6 +45,8 @@ class KoafOperand(ctypes.Structure):
         ("amax", ctypes.c_void_p),
         ("fscale", ctypes.c_float),
         ("_pad4", ctypes.c_int32),
+        ("ptr2", ctypes.c_void_p),
+        ("sc2", ctypes.c_void_p),
     ]
 
 
@@ -94,6 +96,7 @@ class KoafGemm(ctypes.Structure):
         ("bnb2_mean", ctypes.c_void_p),
         ("bnb2_invstd", ctypes.c_void_p),
         ("bnb_part", ctypes.c_void_p),
+        ("bnb_amax", ctypes.c_void_p),
         ("m_base", ctypes.c_int32),
         ("part_row0", ctypes.c_int32),
         ("stats_shift", ctypes.c_void_p),
@@ -104,6 +107,7 @@ class KoafBnb(ctypes.Structure):
     _fields_ = [
         ("mode", ctypes.c_int32),
         ("_pad", ctypes.c_int32),
+        ("dz_amax", ctypes.c_void_p),
         ("c", ctypes.c_void_p),
         ("y", ctypes.c_void_p),
         ("sc", ctypes.c_void_p),
@@ -135,6 +139,10 @@ class KoafWImg(ctypes.Structure):
     _fields_ = [("f", ctypes.c_void_p), ("d", ctypes.c_void_p), ("amax", ctypes.c_void_p)]
 
 
+class KoafBnApply(ctypes.Structure):
+    _fields_ = [("dz", ctypes.c_void_p), ("c", ctypes.c_void_p), ("coef", ctypes.c_void_p), ("amax", ctypes.c_void_p)]
+
+
 _SCALARS = {
     "int": ctypes.c_int,
     "int32_t": ctypes.c_int32,
@@ -154,6 +162,8 @@ def _ctype(decl: str):
             return ctypes.POINTER(KoafBnb)
         if base == "KoafWImg":
             return ctypes.POINTER(KoafWImg)
+        if base == "KoafBnApply":
+            return ctypes.POINTER(KoafBnApply)
         if base == "char":
             return ctypes.c_char_p
         return ctypes.c_void_p

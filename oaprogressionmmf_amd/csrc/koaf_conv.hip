@@ -258,8 +258,16 @@ extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t
 // upper bound of the statistics rows koaf_conv2d_fwd writes for M output pixels (64-row tiles everywhere)
 extern "C" int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout) { return (int32_t)cdiv64(M, 64); }
 
+// A operand = dy formed on load from (dz, c): dy = coef0 * dz + coef3 - coef2 * c (koaf_bn_bwd_finalize)
+static void set_apply(KoafOperand* a, const KoafBnApply* ap, int C) {
+    a->ptr = ap->dz; a->ptr2 = ap->c; a->tf = 2;
+    a->sc = ap->coef; a->sc2 = ap->coef + 2 * (int64_t)C; a->sh = ap->coef + 3 * (int64_t)C;
+    a->amax = ap->amax;
+}
+
 static void set_bnb(KoafGemm* g, const KoafBnb* b, float* part) {
     if (!b) return;
+    g->bnb_amax = b->dz_amax;
     g->bnb_mode = b->mode;
     g->bnb_c = b->c; g->bnb_y = b->y; g->bnb_sc = b->sc; g->bnb_sh = b->sh;
     g->bnb_mean = b->mean; g->bnb_invstd = b->invstd;
@@ -281,8 +289,16 @@ extern "C" int32_t koaf_conv2d_dgrad_bnb_rows(int32_t N, int32_t H, int32_t W, i
 extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
                                      int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                                      const float* residual, const KoafBnb* bnb, float* part, int32_t* part_rows,
-                                     const KoafWImg* wimg, const float* dy_amax, void* stream) {
-    KOAF_REQUIRE(dy && w && dx && N > 0 && Cout % 32 == 0 && Cin % 4 == 0, "koaf_conv2d_dgrad: bad args");
+                                     const KoafWImg* wimg, const float* dy_amax, const KoafBnApply* dy_apply,
+                                     void* stream) {
+    KOAF_REQUIRE((dy || dy_apply) && w && dx && N > 0 && Cout % 32 == 0 && Cin % 4 == 0, "koaf_conv2d_dgrad: bad args");
+    KOAF_REQUIRE(!dy_apply || (dy_apply->dz && dy_apply->c && dy_apply->coef && dy_apply->amax && wimg && wimg->amax && wimg->d),
+                 "koaf_conv2d_dgrad: dy_apply needs dz / c / coef / amax and the weight's D plane image");
+    if (dy_apply) { dy = dy_apply->dz; dy_amax = dy_apply->amax; }
+    if (bnb && bnb->dz_amax && hipMemsetAsync(bnb->dz_amax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) {
+        koaf_set_error("koaf_conv2d_dgrad_bnb: memset failed");
+        return KOAF_ELAUNCH;
+    }
     // fp16 scheme when both operands' magnitudes are known; the weight tiles then come from the D image [2][Cin][KH*KW*Cout]
     // (rows = input channels, k = (tap, output channel): the k order of the gathered dy) if it is there
     const bool f16 = wimg && wimg->amax && dy_amax;
@@ -312,6 +328,7 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
                 g.prec = 1;
                 if (f16) { g.fmt = 1; g.A.amax = dy_amax; g.B.amax = wimg->amax; }
                 g.A.ptr = dy; g.A.kind = 0; g.A.gather = 2;
+                if (dy_apply) set_apply(&g.A, dy_apply, Cout);
                 g.A.H = OH; g.A.W = OW; g.A.C = Cout; g.A.CS = Cout;
                 g.A.PH = Hc; g.A.PW = Wc;
                 g.A.KH = nkh > 0 ? nkh : 1; g.A.KW = nkw > 0 ? nkw : 1; g.A.stride = 1; g.A.pad = offy; g.A.pad_w = offx;
@@ -342,6 +359,7 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
     if (f16) { g.fmt = 1; g.A.amax = dy_amax; g.B.amax = wimg->amax; }
     g.A.ptr = dy;
     g.A.kind = 0;
+    if (dy_apply) set_apply(&g.A, dy_apply, Cout);
     g.B.ptr = w;
     g.B.kind = 1;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {
@@ -377,9 +395,10 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
 
 extern "C" int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
                                  int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
-                                 const float* residual, const KoafWImg* wimg, const float* dy_amax, void* stream) {
+                                 const float* residual, const KoafWImg* wimg, const float* dy_amax,
+                                 const KoafBnApply* dy_apply, void* stream) {
     return koaf_conv2d_dgrad_bnb(dy, w, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, residual, nullptr, nullptr,
-                                 nullptr, wimg, dy_amax, stream);
+                                 nullptr, wimg, dy_amax, dy_apply, stream);
 }
 
 extern "C" int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH,
@@ -392,8 +411,11 @@ extern "C" int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t
 extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int32_t N, int32_t H, int32_t W,
                                  int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                                  const float* in_sc, const float* in_sh, float* slabs, const float* dy_amax,
-                                 void* stream) {
-    KOAF_REQUIRE(dy && x && dw && N > 0 && Cin % 64 == 0 && Cout % 4 == 0, "koaf_conv2d_wgrad: bad args");
+                                 const KoafBnApply* dy_apply, void* stream) {
+    KOAF_REQUIRE((dy || dy_apply) && x && dw && N > 0 && Cin % 64 == 0 && Cout % 4 == 0, "koaf_conv2d_wgrad: bad args");
+    KOAF_REQUIRE(!dy_apply || (dy_apply->dz && dy_apply->c && dy_apply->coef && dy_apply->amax),
+                 "koaf_conv2d_wgrad: dy_apply needs dz / c / coef / amax");
+    if (dy_apply) { dy = dy_apply->dz; dy_amax = dy_apply->amax; }
     KOAF_REQUIRE((in_sc == nullptr) == (in_sh == nullptr), "koaf_conv2d_wgrad: in_sc/in_sh come together");
     const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
     const int64_t P = (int64_t)N * OH * OW;
@@ -406,6 +428,7 @@ extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int
     g.prec = 1;
     if (dy_amax) { g.fmt = 1; g.A.amax = dy_amax; g.B.fscale = KOAF_ACT_SCALE; }   // fp16 scheme: dy at its own scale, x fixed
     g.A.ptr = dy; g.A.kind = 1; g.A.ld = Cout;
+    if (dy_apply) set_apply(&g.A, dy_apply, Cout);
     g.B.ptr = x; g.B.kind = 1;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {
         g.B.gather = 0;

@@ -249,8 +249,9 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, int mask_mode,
                                                             float* __restrict__ dz_out, int64_t rows, int C,
-                                                            ColGeom geo, float* __restrict__ part) {
+                                                            ColGeom geo, float* __restrict__ part, float* dz_amax) {
     const int t = threadIdx.x, cvx = t % geo.CV, ry = t / geo.CV;
+    float am = 0.f;
     const int c0 = blockIdx.y * geo.CW + 4 * cvx;
     const int64_t rbeg = (int64_t)blockIdx.x * geo.rpb;
     const int64_t rend = min(rows, rbeg + (int64_t)geo.rpb);
@@ -273,8 +274,10 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
         if (dz_out) *(v4f*)&dz_out[o] = gv;
         s[0] += gv;
         s[1] += gv * ((cvv - mu) * is);
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(gv[0]), fabsf(gv[1]))), fmaxf(fabsf(gv[2]), fabsf(gv[3])));
     }
     col_block_reduce<2>(s, part, blockIdx.x, C, blockIdx.y * geo.CW, geo.CV, geo.RP);
+    if (dz_amax) block_amax_raise(am, dz_amax);
 }
 
 template <typename T>
@@ -282,9 +285,11 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const T* __restri
                                                                double inv_count, const float* __restrict__ sc,
                                                                const float* __restrict__ invstd, float* dgamma,
                                                                float* dbeta, float* coef, int nsum, int i1,
-                                                               float* amax_reset) {
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ dz_amax, double sqrt_nm1,
+                                                               float* amax) {
     __shared__ double red[2][16][64];
-    if (amax_reset && blockIdx.x == 0 && threadIdx.x == 0) *amax_reset = 0.f;   // the accumulator bn_bwd_apply raises
+    float bound = 0.f;
     const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     double a = 0.0, b = 0.0;
@@ -301,10 +306,19 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const T* __restri
         for (int j = 0; j < 16; ++j) { s1 += red[0][j][cx]; s2 += red[1][j][cx]; }
         if (dbeta) dbeta[c] = (float)s1;
         if (dgamma) dgamma[c] = (float)s2;
-        coef[c] = sc[c];
-        coef[C + c] = (float)(s1 * inv_count);
-        coef[2 * C + c] = (float)((double)sc[c] * (double)invstd[c] * s2 * inv_count);
+        const float k0 = sc[c], k1 = (float)(s1 * inv_count), k2 = (float)((double)sc[c] * (double)invstd[c] * s2 * inv_count);
+        coef[c] = k0;
+        coef[C + c] = k1;
+        coef[2 * C + c] = k2;
+        if (mean) {
+            // dc = k0 * (dz - k1) - k2 * (x - mean) = k0 * dz + k3 - k2 * x: the form the GEMM loaders evaluate (KoafOperand.tf 2)
+            coef[3 * C + c] = k2 * mean[c] - k0 * k1;
+            // |dc| <= |k0| (max|dz| + |k1|) + |k2| max|x - mean|, and no sample of n lies further than sqrt(n - 1) standard
+            // deviations from its mean (Samuelson): a guaranteed bound of the tensor's largest magnitude without a pass
+            if (amax) bound = fabsf(k0) * ((dz_amax ? *dz_amax : 0.f) + fabsf(k1)) + fabsf(k2) * (float)(sqrt_nm1 / (double)invstd[c]);
+        }
     }
+    if (amax && mean) block_amax_raise(bound, amax);
 }
 
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ c,
@@ -950,29 +964,40 @@ extern "C" int32_t koaf_colpart_rows(int64_t rows, int32_t C) {
 
 extern "C" int koaf_bn_bwd_reduce(const float* g, const float* c, const float* ymask, const float* sc, const float* sh,
                                   const float* mean, const float* invstd, int32_t mask_mode, float* dz_out, float* part,
-                                  int32_t* part_rows, int64_t rows, int32_t C, void* stream) {
+                                  int32_t* part_rows, int64_t rows, int32_t C, float* dz_amax, void* stream) {
     ColGeom geo;
     KOAF_REQUIRE(g && c && mean && invstd && part && part_rows && rows > 0, "koaf_bn_bwd_reduce: bad args");
     KOAF_REQUIRE(mask_mode != 1 || ymask, "koaf_bn_bwd_reduce: mask_mode 1 needs ymask");
     KOAF_REQUIRE(mask_mode != 2 || (sc && sh), "koaf_bn_bwd_reduce: mask_mode 2 needs sc/sh");
     KOAF_REQUIRE(col_geom(rows, C, 1024, &geo), "koaf_bn_bwd_reduce: unsupported C=%d", C);
+    if (dz_amax && hipMemsetAsync(dz_amax, 0, sizeof(float), STREAM) != hipSuccess) {
+        koaf_set_error("koaf_bn_bwd_reduce: memset failed");
+        return KOAF_ELAUNCH;
+    }
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(geo.nblk, geo.nchunk), dim3(256), 0, STREAM, g, c, ymask, sc, sh,
-                       mean, invstd, mask_mode, dz_out, rows, C, geo, part);
+                       mean, invstd, mask_mode, dz_out, rows, C, geo, part, dz_amax);
     *part_rows = geo.nblk;
     return koaf_check_launch("koaf_bn_bwd_reduce");
 }
 extern "C" int koaf_bn_bwd_finalize(const float* part, int32_t part_rows, int32_t C, int64_t count, const float* sc,
                                     const float* invstd, float* dgamma, float* dbeta, float* coef, int32_t nsum,
-                                    int32_t i1, double* ws, float* amax_reset, void* stream) {
+                                    int32_t i1, double* ws, const float* mean, const float* dz_amax, float* amax,
+                                    void* stream) {
     KOAF_REQUIRE(part && part_rows > 0 && C > 0 && count > 0 && sc && invstd && coef, "koaf_bn_bwd_finalize: bad args");
     KOAF_REQUIRE(nsum >= 2 && i1 >= 1 && i1 < nsum, "koaf_bn_bwd_finalize: bad (nsum, i1)");
+    KOAF_REQUIRE(!amax || mean, "koaf_bn_bwd_finalize: amax needs mean (coef gets its fourth row)");
+    if (amax && hipMemsetAsync(amax, 0, sizeof(float), STREAM) != hipSuccess) {
+        koaf_set_error("koaf_bn_bwd_finalize: memset failed");
+        return KOAF_ELAUNCH;
+    }
+    const double sq = sqrt((double)(count > 1 ? count - 1 : 1));
     const int S = part_reduce(part, part_rows, C, nsum, i1, ws, STREAM);
     if (S)
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, ws, S, C,
-                           1.0 / (double)count, sc, invstd, dgamma, dbeta, coef, 2, 1, amax_reset);
+                           1.0 / (double)count, sc, invstd, dgamma, dbeta, coef, 2, 1, mean, dz_amax, sq, amax);
     else
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, part, part_rows, C,
-                           1.0 / (double)count, sc, invstd, dgamma, dbeta, coef, nsum, i1, amax_reset);
+                           1.0 / (double)count, sc, invstd, dgamma, dbeta, coef, nsum, i1, mean, dz_amax, sq, amax);
     return koaf_check_launch("koaf_bn_bwd_finalize");
 }
 extern "C" int koaf_bn_bwd_apply(const float* dz, const float* c, const float* mean, const float* coef, float* dc,

@@ -113,19 +113,24 @@ enum { M_KC = 0,     // K-contiguous rows, dense
 };
 __host__ __device__ constexpr bool mode_is_kc(int m) { return m < 3; }
 
-template <int ROWS, int MODE, bool TF, bool VEC>
+// TF = transform on load (KoafOperand.tf): 0 none; 1 relu(sc[c] * x + sh[c]) -- the producer's BatchNorm + ReLU; 2 the
+// BatchNorm-BACKWARD apply dc = sc[c] * dz + sh[c] - sc2[c] * c_raw of TWO source tensors (x = dz at ptr, c_raw at ptr2, same
+// layout): the gradient w.r.t. a conv output is formed in the loaders of the dgrad / wgrad GEMMs that consume it and never
+// written to HBM.  (TF 2 needs the vector path.)
+template <int ROWS, int MODE, int TF, bool VEC>
 struct TileLoader {
     static constexpr int NU = ROWS / 32;
     static constexpr bool KC = mode_is_kc(MODE);
-    // registers of one k-tile in flight; two slots so that the tile after next can be on its way while the next one
+    static constexpr int NU2 = (TF == 2) ? NU : 1;
     // registers of one k-tile in flight
     struct Slot {
         v4f r[NU];
+        v4f r2[NU2];   // TF 2: the second source
         unsigned vm;   // validity bits: VEC 1 bit / unit, else 4 bits / unit
-        v4f ts4, th4;  // transform coefficients of the tile (KC operands: they depend on k)
+        v4f ts4, th4, tk4;  // transform coefficients of the tile (KC operands: they depend on k)
     };
     Slot sa, sb;
-    v4f kts4, kth4;    // transform coefficients of this thread's columns (KM operands: fixed)
+    v4f kts4, kth4, ktk4;    // transform coefficients of this thread's columns (KM operands: fixed)
     // KC state (ext-vector values, not arrays: arrays of per-unit state were left in scratch by hipcc and
     // every scratch reload drained the in-flight global loads through the in-order vmcnt)
     v4l base;          // element offset of each unit's row / image from the operand pointer
@@ -150,7 +155,7 @@ struct TileLoader {
     __device__ __forceinline__ void init(const KoafOperand& op, int r0, int R, int z1) {
         const int t = threadIdx.x;
         sa.vm = sb.vm = 0;
-        sa.ts4 = sa.th4 = sb.ts4 = sb.th4 = kts4 = kth4 = (v4f){0.f, 0.f, 0.f, 0.f};
+        sa.ts4 = sa.th4 = sb.ts4 = sb.th4 = kts4 = kth4 = sa.tk4 = sb.tk4 = ktk4 = (v4f){0.f, 0.f, 0.f, 0.f};
         rvm = cvm = 0;
         base = (v4l){0, 0, 0, 0};
         iy0 = ix0 = toff = (v4i){0, 0, 0, 0};
@@ -193,11 +198,15 @@ struct TileLoader {
                 kh_ = tap / op.KW;
                 kw_ = tap - kh_ * op.KW;
             }
-            if constexpr (TF) {
+            if constexpr (TF != 0) {
                 const float* sc = op.sc + z1 * op.tf_bs;
                 const float* sh = op.sh + z1 * op.tf_bs;
                 if (VEC) {
-                    if (cvm & 1u) { kts4 = *(const v4f*)(sc + cc); kth4 = *(const v4f*)(sh + cc); }
+                    if (cvm & 1u) {
+                        kts4 = *(const v4f*)(sc + cc);
+                        kth4 = *(const v4f*)(sh + cc);
+                        if constexpr (TF == 2) ktk4 = *(const v4f*)(op.sc2 + z1 * op.tf_bs + cc);
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -254,6 +263,7 @@ struct TileLoader {
     // s_waitcnt lands in finish(), after the MFMAs of the tile currently in LDS.
     __device__ __forceinline__ void issue(Slot& s, const KoafOperand& op, const float* ptr, int k0, int kend, int z1) {
         const int t = threadIdx.x;
+        [[maybe_unused]] const float* ptr2 = (TF == 2) ? op.ptr2 + (ptr - op.ptr) : nullptr;   // (same batch offset)
         s.vm = 0;
         if constexpr (KC) {
             const int kk = k0 + 4 * (t & 7);
@@ -303,13 +313,14 @@ struct TileLoader {
                     }
                 }
             }
-            if constexpr (TF) {
+            if constexpr (TF != 0) {
                 const float* sc = op.sc + z1 * op.tf_bs;
                 const float* sh = op.sh + z1 * op.tf_bs;
                 if (VEC) {
                     const int c = kok ? ch : 0;
                     s.ts4 = *(const v4f*)(sc + c);
                     s.th4 = *(const v4f*)(sh + c);
+                    if constexpr (TF == 2) s.tk4 = *(const v4f*)(op.sc2 + z1 * op.tf_bs + c);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -326,6 +337,7 @@ struct TileLoader {
                     if (VEC) {
                         const bool ok = rok && kok;
                         s.r[i] = *(const v4f*)(ptr + (ok ? base[i] + k0 : 0));
+                        if constexpr (TF == 2) s.r2[i] = *(const v4f*)(ptr2 + (ok ? base[i] + k0 : 0));
                         s.vm |= (ok ? 1u : 0u) << i;
                     } else {
 #pragma unroll
@@ -338,6 +350,7 @@ struct TileLoader {
                 } else {
                     const bool ok = kok && ((tvm >> i) & 1u);
                     s.r[i] = *(const v4f*)(ptr + (ok ? base[i] + (toff[i] + coff) : 0));
+                    if constexpr (TF == 2) s.r2[i] = *(const v4f*)(ptr2 + (ok ? base[i] + (toff[i] + coff) : 0));
                     s.vm |= (ok ? 1u : 0u) << i;
                 }
             }
@@ -382,6 +395,7 @@ struct TileLoader {
                 if (VEC) {
                     ok = ok && (cvm & 1u);
                     s.r[i] = *(const v4f*)(ptr + (ok ? off : 0));
+                    if constexpr (TF == 2) s.r2[i] = *(const v4f*)(ptr2 + (ok ? off : 0));
                     s.vm |= (ok ? 1u : 0u) << i;
                 } else {
 #pragma unroll
@@ -398,11 +412,13 @@ struct TileLoader {
     // transform + zero-fill of the tile issued by issue(); first consumer of the loaded registers
     __device__ __forceinline__ void finish_unit(Slot& s, int i) {
         const v4f a = KC ? s.ts4 : kts4, b = KC ? s.th4 : kth4;
+        [[maybe_unused]] const v4f k = KC ? s.tk4 : ktk4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool ok = VEC ? ((s.vm >> i) & 1u) : ((s.vm >> (4 * i + j)) & 1u);
             float x = s.r[i][j];
-            if constexpr (TF) x = fmaxf(x * a[j] + b[j], 0.f);
+            if constexpr (TF == 1) x = fmaxf(x * a[j] + b[j], 0.f);
+            if constexpr (TF == 2) x = fmaf(a[j], x, fmaf(-k[j], s.r2[i < NU2 ? i : 0][j], b[j]));
             s.r[i][j] = ok ? x : 0.f;
         }
     }
@@ -522,7 +538,7 @@ __device__ __forceinline__ v4i frag_load_ps(const unsigned* P, int row0, int g, 
 template <int BM, int BN, bool HAS_R, int MODE, bool HAS_C2>
 __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs, int ldcs, float* Cp, int64_t ldc,
                                               const float* Rp, int m0, int col, int c4, int rr, v4f bv, v4f mu, v4f is,
-                                              v4f ms, v4f mh, v4f mu2, v4f is2, v4f& q1, v4f& q2, v4f& q3) {
+                                              v4f ms, v4f mh, v4f mu2, v4f is2, v4f& q1, v4f& q2, v4f& q3, v4f& qm) {
     constexpr int C4 = BN / 4, RPP = 256 / C4, U = 4;
     static_assert((BM / RPP) % U == 0, "rows per thread must be a multiple of the batch");
 #pragma unroll 1
@@ -552,6 +568,8 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
                 q1 += v;
                 q2 += v * ((cv[u] - mu) * is);
                 if constexpr (HAS_C2) q3 += v * ((c2v[u] - mu2) * is2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qm[j] = fmaxf(qm[j], fabsf(v[j]));
             }
             *(v4f*)(Cp + orow * ldc + col) = v;
         }
@@ -560,8 +578,9 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
 
 
 // F16 = KoafGemm.fmt == 1 (two fp16 planes per operand, three products); else three bf16 planes, six products
-template <int BM, int BN, int AM, int BMD, bool TFA, bool TFB, bool VEC, bool F16>
+template <int BM, int BN, int AM, int BMD, int TFA, int TFB, bool VEC, bool F16>
 __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
+    static_assert((TFA != 2 && TFB != 2) || VEC, "the two-source prologue needs the vector path");
     constexpr int NPL = F16 ? 2 : 3;
     static_assert(BMD != M_PS || F16, "plane images are fp16");
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -757,6 +776,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         const int col = n0 + 4 * c4;
         const bool bnb = (p.bnb_mode != 0) && !slab;
         v4f q1 = {0.f, 0.f, 0.f, 0.f}, q2 = q1, q3 = q1;   // fused BN-backward column sums of this thread's rows
+        v4f qm = q1;                                       // and the largest |dz| it stored (KoafGemm.bnb_amax)
         if (col < p.N) {                         // N % 4 == 0 on this path
             v4f bv = {0.f, 0.f, 0.f, 0.f};
             if (bias) bv = *(const v4f*)(bias + col);
@@ -772,7 +792,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
                 const bool hr = Rp != nullptr, h2 = bnb && p.bnb2_c != nullptr;
                 const int mode = bnb ? p.bnb_mode : 0;
 #define KOAF_EPI(R_, M_, C2_) epi_rows_full<BM, BN, R_, M_, C2_>(p, Cs, LDC_S, Cp, ldc, Rp, m0, col, c4, rr, bv, mu, is, \
-                                                                 ms, mh, mu2, is2, q1, q2, q3)
+                                                                 ms, mh, mu2, is2, q1, q2, q3, qm)
                 if (mode == 0) { if (hr) KOAF_EPI(true, 0, false); else KOAF_EPI(false, 0, false); }
                 else if (mode == 1) {
                     if (hr) { if (h2) KOAF_EPI(true, 1, true); else KOAF_EPI(true, 1, false); }
@@ -810,6 +830,8 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
                         }
                         q1 += v;
                         q2 += v * ((cv - mu) * is);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) qm[j] = fmaxf(qm[j], fabsf(v[j]));
                         if (p.bnb2_c) {
                             const v4f c2 = *(const v4f*)(p.bnb2_c + orow * ldc + col);
                             q3 += v * ((c2 - mu2) * is2);
@@ -820,6 +842,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
             }
         }
         if (bnb) {
+            if (p.bnb_amax) block_amax_raise(fmaxf(fmaxf(qm[0], qm[1]), fmaxf(qm[2], qm[3])), p.bnb_amax);
             // column sums over the block's rows: RPP row-threads per column vector -> LDS -> one partial row
             __syncthreads();                     // Cs fully consumed
             v4f* red4 = reinterpret_cast<v4f*>(smem);   // [3][RPP][C4]
@@ -946,6 +969,7 @@ bool operand_vec_ok(const KoafOperand& o, int R, int K) {
         if (o.gather == 1 && ((o.C & 3) || (o.CS & 3))) return false;
     }
     if (o.tf && (!aligned16(o.sc) || !aligned16(o.sh))) return false;
+    if (o.tf == 2 && (!aligned16(o.sc2) || !aligned16(o.ptr2))) return false;
     return true;
 }
 
@@ -964,22 +988,27 @@ int operand_mode(const KoafOperand& o) {
 template <int BM, int BN, bool VEC, bool F16>
 int launch_modes(const KoafGemm& g, dim3 grid, hipStream_t s) {
     const int am = operand_mode(g.A), bm = operand_mode(g.B);
-    const bool ta = g.A.tf != 0, tb = g.B.tf != 0;
-    if (am == M_KC && bm == M_KC && !tb) { if (ta) { KOAF_LAUNCH(M_KC, M_KC, true, false); } else { KOAF_LAUNCH(M_KC, M_KC, false, false); } }
-    if (am == M_KC && bm == M_KM && !ta && !tb) { KOAF_LAUNCH(M_KC, M_KM, false, false); }
-    if (am == M_KM && bm == M_KM && !ta) { if (tb) { KOAF_LAUNCH(M_KM, M_KM, false, true); } else { KOAF_LAUNCH(M_KM, M_KM, false, false); } }
+    const int ta = g.A.tf, tb = g.B.tf;
+    if (am == M_KC && bm == M_KC && !tb) { if (ta == 1) { KOAF_LAUNCH(M_KC, M_KC, 1, 0); } else if (!ta) { KOAF_LAUNCH(M_KC, M_KC, 0, 0); } }
+    if (am == M_KC && bm == M_KM && !ta && !tb) { KOAF_LAUNCH(M_KC, M_KM, 0, 0); }
+    if (am == M_KM && bm == M_KM && !ta) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM, 0, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM, 0, 0); } }
     if constexpr (VEC) {
-        if (am == M_KC_G1 && bm == M_KC && !tb) { if (ta) { KOAF_LAUNCH(M_KC_G1, M_KC, true, false); } else { KOAF_LAUNCH(M_KC_G1, M_KC, false, false); } }
-        if (am == M_KC_G2 && bm == M_KM_G3 && !ta && !tb) { KOAF_LAUNCH(M_KC_G2, M_KM_G3, false, false); }
-        if (am == M_KM && bm == M_KM_G1 && !ta) { if (tb) { KOAF_LAUNCH(M_KM, M_KM_G1, false, true); } else { KOAF_LAUNCH(M_KM, M_KM_G1, false, false); } }
+        if (am == M_KC_G1 && bm == M_KC && !tb) { if (ta == 1) { KOAF_LAUNCH(M_KC_G1, M_KC, 1, 0); } else if (!ta) { KOAF_LAUNCH(M_KC_G1, M_KC, 0, 0); } }
+        if (am == M_KC_G2 && bm == M_KM_G3 && !ta && !tb) { KOAF_LAUNCH(M_KC_G2, M_KM_G3, 0, 0); }
+        if (am == M_KM && bm == M_KM_G1 && !ta) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM_G1, 0, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM_G1, 0, 0); } }
         if constexpr (F16) {
-            if (am == M_KC && bm == M_PS) { if (ta) { KOAF_LAUNCH(M_KC, M_PS, true, false); } else { KOAF_LAUNCH(M_KC, M_PS, false, false); } }
-            if (am == M_KC_G1 && bm == M_PS) { if (ta) { KOAF_LAUNCH(M_KC_G1, M_PS, true, false); } else { KOAF_LAUNCH(M_KC_G1, M_PS, false, false); } }
-            if (am == M_KC_G2 && bm == M_PS && !ta) { KOAF_LAUNCH(M_KC_G2, M_PS, false, false); }
+            if (am == M_KC && bm == M_PS) {
+                if (ta == 1) { KOAF_LAUNCH(M_KC, M_PS, 1, 0); } else if (ta == 2) { KOAF_LAUNCH(M_KC, M_PS, 2, 0); } else { KOAF_LAUNCH(M_KC, M_PS, 0, 0); }
+            }
+            if (am == M_KC_G1 && bm == M_PS && ta != 2) { if (ta) { KOAF_LAUNCH(M_KC_G1, M_PS, 1, 0); } else { KOAF_LAUNCH(M_KC_G1, M_PS, 0, 0); } }
+            if (am == M_KC_G2 && bm == M_PS && ta != 1) { if (ta) { KOAF_LAUNCH(M_KC_G2, M_PS, 2, 0); } else { KOAF_LAUNCH(M_KC_G2, M_PS, 0, 0); } }
+            // weight gradient with the BatchNorm-backward apply formed in the A loader (dy = sc * dz + sh - sc2 * c)
+            if (am == M_KM && bm == M_KM && ta == 2) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM, 2, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM, 2, 0); } }
+            if (am == M_KM && bm == M_KM_G1 && ta == 2) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM_G1, 2, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM_G1, 2, 0); } }
         }
     }
-    koaf_set_error("koaf_gemm: operand mode pair (%d,%d) tf=(%d,%d) fmt=%d vec=%d is not instantiated", am, bm, (int)ta,
-                   (int)tb, (int)F16, (int)VEC);
+    koaf_set_error("koaf_gemm: operand mode pair (%d,%d) tf=(%d,%d) fmt=%d vec=%d is not instantiated", am, bm, ta, tb,
+                   (int)F16, (int)VEC);
     return KOAF_EINVAL;
 }
 
@@ -1066,6 +1095,9 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
                  "koaf_gemm: tapped gather needs a K-major operand");
     KOAF_REQUIRE(!(g.B.kind == 0 && g.B.gather), "koaf_gemm: K-contiguous B cannot be gathered");
     KOAF_REQUIRE(g.fmt == 0 || g.fmt == 1, "koaf_gemm: fmt must be 0 (bf16 x 3) or 1 (fp16 x 2)");
+    KOAF_REQUIRE(g.A.tf >= 0 && g.A.tf <= 2 && g.B.tf >= 0 && g.B.tf <= 1, "koaf_gemm: tf is 0 | 1 (A, B) | 2 (A)");
+    KOAF_REQUIRE(g.A.tf != 2 || (g.A.ptr2 && g.A.sc && g.A.sh && g.A.sc2 && g.fmt == 1),
+                 "koaf_gemm: the two-source prologue needs ptr2 / sc / sh / sc2 and the fp16 scheme");
     if (g.B.kind == 2) {
         KOAF_REQUIRE(g.fmt == 1 && g.B.amax, "koaf_gemm: plane images are fp16 pieces of B * scale(*B.amax): fmt 1, amax required");
         KOAF_REQUIRE(g.A.kind == 0 && !g.B.tf, "koaf_gemm: a pre-split B pairs with a K-contiguous A and takes no transform");

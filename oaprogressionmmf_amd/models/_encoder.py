@@ -164,14 +164,23 @@ class _SideStream:
         self.held = []
 
 
+# The BatchNorm-backward "apply" (dc = coef0*dz + coef3 - coef2*c) is formed in the loaders of the dgrad / wgrad GEMMs that
+# consume dc (ops.BnApply, koaf.h KoafOperand.tf 2) instead of being written out by an element-wise pass.  KOAF_FUSE_APPLY=0
+# (or convolutions off the fp16 scheme) materialises dc as before.
+FUSE_APPLY = os.environ.get("KOAF_FUSE_APPLY", "1") != "0"
+
+
 def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True, side=None, bnb=None):
     """weight gradient (x transformed on load by in_saved) and data gradient of one conv.  dc comes out of a BatchNorm
-    backward (_bn_bwd*), which left max |dc| on the device (dc._koaf_amax): with it both contractions run on the fp16
-    scheme (koaf.h: KoafGemm.fmt 1)."""
+    backward (_bn_bwd*): either an ops.BnApply -- the recipe of dc, evaluated by the GEMM loaders -- or a tensor carrying
+    max |dc| (dc._koaf_amax); both put the two contractions on the fp16 scheme (koaf.h: KoafGemm.fmt 1)."""
     w = packed_weight(conv.weight)
-    amax = getattr(dc, "_koaf_amax", None)
     cin, cout = conv.in_channels, conv.out_channels
     k, s, p, g = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.groups
+    wimg = weight_planes(conv.weight) if g == 1 else None
+    if isinstance(dc, ops.BnApply) and (g != 1 or (need_dx and wimg is None)):
+        dc = dc.materialize(want_amax=(g == 1))        # grouped 3x3 / no weight plane images: the element-wise pass
+    amax = getattr(dc, "_koaf_amax", None)
     sc, sh = (in_saved[2], in_saved[3]) if in_saved is not None else (None, None)
     gw, acc = grad_target(conv.weight)
 
@@ -187,42 +196,46 @@ def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True,
     dx = None
     if need_dx:
         if g == 1:
-            dx = ops.conv2d_dgrad(dc, w, N, H, W, cin, cout, k, k, s, p, residual=residual, bnb=bnb,
-                                  wimg=weight_planes(conv.weight), dy_amax=amax)
+            dx = ops.conv2d_dgrad(dc, w, N, H, W, cin, cout, k, k, s, p, residual=residual, bnb=bnb, wimg=wimg, dy_amax=amax)
         else:
             assert residual is None and bnb is None
             dx = ops.gconv3x3_dgrad(dc, wexp, N, H, W, cin, s)
     if side is not None:
         # enqueued BEHIND the sibling dgrad: the side stream starts this wgrad when the dgrad is done, so it
         # overlaps the HBM-bound BatchNorm backward of the next layer instead of fighting the dgrad for MFMAs
-        side.run((dc, x, in_saved, amax), wgrad, conv.weight, gw, acc)
+        held = dc.tensors() if isinstance(dc, ops.BnApply) else (dc, amax)
+        side.run(held + (x, in_saved), wgrad, conv.weight, gw, acc)
     return dx
 
 
-def _bn_bwd(bn, g, c, saved, rows, mask_mode, ymask=None, dz_out=None, dc_out=None, amax=True):
-    """-> dc; with amax the device scalar max |dc| rides on the tensor object as dc._koaf_amax (see _conv_bwd)"""
+def _bn_bwd(bn, g, c, saved, rows, mask_mode, ymask=None, dz_out=None, dc_out=None, fused=None):
+    """-> dc of a BatchNorm(+ReLU mask): an ops.BnApply when the consumers can form it on load (fused), else the tensor"""
     C = bn.num_features
     gg, ag = grad_target(bn.weight)
     gb, ab = grad_target(bn.bias)
-    amax = amax and ops.CONV_F16
-    dc = ops.bn_bwd(g, c, saved, rows, C, rows, gg, gb, mask_mode, ymask=ymask, dz_out=dz_out, dc_out=dc_out, want_amax=amax)
-    if amax:
-        dc, a = dc
-        dc._koaf_amax = a
+    if fused is None:
+        fused = ops.CONV_F16
+        dc = ops.bn_bwd(g, c, saved, rows, C, rows, gg, gb, mask_mode, ymask=ymask, dz_out=dz_out, fused=fused)
+        if fused and not FUSE_APPLY:
+            dc = dc.materialize(out=dc_out, want_amax=True)      # (A/B switch: dc written out, with its exact max |dc|)
+    else:
+        dc = ops.bn_bwd(g, c, saved, rows, C, rows, gg, gb, mask_mode, ymask=ymask, dz_out=dz_out,
+                        dc_out=None if fused else dc_out, fused=fused)
     deliver_grad(bn.weight, gg, ag)
     deliver_grad(bn.bias, gb, ab)
     return dc
 
 
-def _bn_bwd_part(bn, part, nsum, i1, dz, c, saved, rows, dc_out=None):
-    """BatchNorm backward whose reduction was fused into the producing dgrad's epilogue."""
+def _bn_bwd_part(bn, part, nsum, i1, dz, c, saved, rows, dc_out=None, dzmax=None):
+    """BatchNorm backward whose reduction was fused into the producing dgrad's epilogue (dzmax: the max |dz| it left)."""
     C = bn.num_features
     gg, ag = grad_target(bn.weight)
     gb, ab = grad_target(bn.bias)
-    dc = ops.bn_bwd_from_part(part, nsum, i1, dz, c, saved, rows, C, rows, gg, gb, dc_out=dc_out, want_amax=ops.CONV_F16)
-    if ops.CONV_F16:
-        dc, a = dc
-        dc._koaf_amax = a
+    fused = ops.CONV_F16 and dzmax is not None
+    dc = ops.bn_bwd_from_part(part, nsum, i1, dz, c, saved, rows, C, rows, gg, gb, dc_out=None if fused else dc_out,
+                              fused=fused, dzmax=dzmax)
+    if fused and not FUSE_APPLY:
+        dc = dc.materialize(out=dc_out, want_amax=True)
     deliver_grad(bn.weight, gg, ag)
     deliver_grad(bn.bias, gb, ab)
     return dc
@@ -236,7 +249,7 @@ def _tail_bnb(prev):
     if prev is None or not FUSE_BNB:
         return None
     c_last, s_last = (prev.c3, prev.s3) if prev.kind == "bottleneck" else (prev.c2, prev.s2)
-    d = dict(mode=1, c=c_last, y=prev.y, saved=s_last)
+    d = dict(mode=1, c=c_last, y=prev.y, saved=s_last, dz_amax=ops.CONV_F16)
     if prev.cd is not None:
         d["c2"], d["saved2"] = prev.cd, prev.sd
     return d
@@ -388,36 +401,41 @@ class EncoderFn(torch.autograd.Function):
             if pend is None:
                 dcl = _bn_bwd(tail_bn, dy, tail_c, tail_s, rows_o, 1, ymask=r.y, dz_out=dy)
             else:
-                dcl = _bn_bwd_part(tail_bn, pend[0], pend[1], 1, dy, tail_c, tail_s, rows_o)
+                dcl = _bn_bwd_part(tail_bn, pend[0], pend[1], 1, dy, tail_c, tail_s, rows_o, dzmax=pend[2])
             dz = dy
             inner = FUSE_BNB
+            want_max = ops.CONV_F16
+
+            def split(res):
+                """(dz, part, dzmax or None) of a dgrad that carried a fused BatchNorm-backward reduction"""
+                return res if len(res) == 3 else (res[0], res[1], None)
             if bott:
                 g2 = blk.conv2.groups == 1 and inner
                 res = _conv_bwd(blk.conv3, dcl, r.c2, N, OH, OW, r.s2, None, side=side,
-                                bnb=dict(mode=2, c=r.c2, saved=r.s2) if inner else None)
+                                bnb=dict(mode=2, c=r.c2, saved=r.s2, dz_amax=want_max) if inner else None)
                 del dcl
                 if inner:
-                    da2, part2 = res
-                    dc2 = _bn_bwd_part(blk.bn2, part2, 2, 1, da2, r.c2, r.s2, rows_o, dc_out=da2)
+                    da2, part2, mx2 = split(res)
+                    dc2 = _bn_bwd_part(blk.bn2, part2, 2, 1, da2, r.c2, r.s2, rows_o, dc_out=da2, dzmax=mx2)
                 else:
                     da2 = res
                     dc2 = _bn_bwd(blk.bn2, da2, r.c2, r.s2, rows_o, 2, dc_out=da2)
                 res = _conv_bwd(blk.conv2, dc2, r.c1, N, Hi, Wi, r.s1, r.wexp, side=side,
-                                bnb=dict(mode=2, c=r.c1, saved=r.s1) if g2 else None)
+                                bnb=dict(mode=2, c=r.c1, saved=r.s1, dz_amax=want_max) if g2 else None)
                 del dc2, da2
                 if g2:
-                    da1, part1 = res
-                    dc1 = _bn_bwd_part(blk.bn1, part1, 2, 1, da1, r.c1, r.s1, rows_i, dc_out=da1)
+                    da1, part1, mx1 = split(res)
+                    dc1 = _bn_bwd_part(blk.bn1, part1, 2, 1, da1, r.c1, r.s1, rows_i, dc_out=da1, dzmax=mx1)
                 else:
                     da1 = res
                     dc1 = _bn_bwd(blk.bn1, da1, r.c1, r.s1, rows_i, 2, dc_out=da1)
             else:
                 res = _conv_bwd(blk.conv2, dcl, r.c1, N, OH, OW, r.s1, None, side=side,
-                                bnb=dict(mode=2, c=r.c1, saved=r.s1) if inner else None)
+                                bnb=dict(mode=2, c=r.c1, saved=r.s1, dz_amax=want_max) if inner else None)
                 del dcl
                 if inner:
-                    da1, part1 = res
-                    dc1 = _bn_bwd_part(blk.bn1, part1, 2, 1, da1, r.c1, r.s1, rows_o, dc_out=da1)
+                    da1, part1, mx1 = split(res)
+                    dc1 = _bn_bwd_part(blk.bn1, part1, 2, 1, da1, r.c1, r.s1, rows_o, dc_out=da1, dzmax=mx1)
                 else:
                     da1 = res
                     dc1 = _bn_bwd(blk.bn1, da1, r.c1, r.s1, rows_o, 2, dc_out=da1)
@@ -427,7 +445,7 @@ class EncoderFn(torch.autograd.Function):
                 if pend is None:
                     dcd = _bn_bwd(blk.downsample[1], dz, r.cd, r.sd, rows_o, 0, dc_out=dz)
                 else:
-                    dcd = _bn_bwd_part(blk.downsample[1], pend[0], pend[1], 2, dz, r.cd, r.sd, rows_o, dc_out=dz)
+                    dcd = _bn_bwd_part(blk.downsample[1], pend[0], pend[1], 2, dz, r.cd, r.sd, rows_o, dc_out=dz, dzmax=pend[2])
                 resid = _conv_bwd(blk.downsample[0], dcd, r.yin, N, Hi, Wi, None, None, side=side)
             else:
                 resid = dz
@@ -435,8 +453,8 @@ class EncoderFn(torch.autograd.Function):
             bnb = _tail_bnb(prev)
             res = _conv_bwd(first, dc1, r.yin, N, Hi, Wi, None, None, residual=resid, side=side, bnb=bnb)
             if bnb is not None:
-                dy, part = res
-                pend = (part, 3 if "c2" in bnb else 2)
+                dy, part, mx = split(res)
+                pend = (part, 3 if "c2" in bnb else 2, mx)
             else:
                 dy, pend = res, None
             del dc1, da1, dz, resid, r
@@ -502,7 +520,7 @@ class EncoderFn(torch.autograd.Function):
         c0 = S["c0"]
         if c0 is None:
             c0 = ops.stem_fwd(S["x"], ops.stem_fold_w(packed_weight(conv1.weight)), N, H, W)
-        dc0 = _bn_bwd(bn1, da0, c0, S["s0"], N * H1 * W1, 2, dc_out=da0, amax=False)    # (the stem is not a GEMM)
+        dc0 = _bn_bwd(bn1, da0, c0, S["s0"], N * H1 * W1, 2, dc_out=da0, fused=False)    # (the stem's wgrad is not a GEMM)
         gw, acc = grad_target(conv1.weight)
         ops.stem_wgrad(dc0, S["x"], gw, N, H, W)
         deliver_grad(conv1.weight, gw, acc)

@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from ._lib import KoafBnb, KoafGemm, KoafError, KoafWImg, check, lib
+from ._lib import KoafBnApply, KoafBnb, KoafGemm, KoafError, KoafWImg, check, lib
 
 _i32 = ctypes.c_int32
 
@@ -69,6 +69,39 @@ def _img(wimg):
                                  amax=_ptr(amax)))
 
 
+class BnApply(object):
+    """A gradient w.r.t. a conv output that exists only as its BatchNorm-backward recipe: dc = coef0*dz + coef3 - coef2*c
+    (coef [4][C] and the scale bound `amax` from koaf_bn_bwd_finalize).  conv2d_dgrad / conv2d_wgrad take it in place of the
+    dy tensor and form dc in their loaders (koaf.h KoafOperand.tf 2), so dc never travels through HBM; materialize()
+    writes it out for consumers that are not such GEMMs."""
+    __slots__ = ("dz", "c", "coef", "amax", "mean", "rows", "C")
+
+    def __init__(self, dz, c, coef, amax, mean, rows, C):
+        self.dz, self.c, self.coef, self.amax, self.mean, self.rows, self.C = dz, c, coef, amax, mean, rows, C
+
+    def struct(self):
+        return ctypes.byref(KoafBnApply(dz=_ptr(self.dz), c=_ptr(self.c), coef=_ptr(self.coef), amax=_ptr(self.amax)))
+
+    def tensors(self):
+        return (self.dz, self.c, self.coef, self.amax)
+
+    def materialize(self, out=None, want_amax=False):
+        dc = out if out is not None else torch.empty_like(self.c)
+        amax = torch.zeros(1, device=self.c.device, dtype=torch.float32) if want_amax else None
+        check(lib().koaf_bn_bwd_apply(_ptr(self.dz), _ptr(self.c), _ptr(self.mean), _ptr(self.coef), _ptr(dc), self.rows, self.C,
+                                      _ptr(amax), _stream()), "bn_bwd_apply")
+        if want_amax:
+            dc._koaf_amax = amax
+        return dc
+
+
+def _dy_args(dy, dy_amax):
+    """(dy pointer, dy_amax pointer, KoafBnApply* or None, reference tensor) of a gradient given as a tensor or as a BnApply"""
+    if isinstance(dy, BnApply):
+        return None, None, dy.struct(), dy.dz
+    return _ptr(dy), _ptr(dy_amax), None, dy
+
+
 def _empty(shape, like, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
 
@@ -106,48 +139,58 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
 def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, bnb=None, wimg=None, dy_amax=None):
     """dx = conv_transpose(dy, w) (+residual).  bnb = dict(mode, c, saved[, y][, c2, saved2]): fuse the
     BatchNorm(+ReLU)-backward reduction of the layer that produced x into the epilogue; then returns
-    (dz, part [rows][nsum][Cin]) instead of dx.  wimg + dy_amax (device scalar max |dy|, from bn_bwd*): fp16 scheme."""
+    (dz, part [rows][nsum][Cin]) instead of dx (+ the device scalar max |dz| as a third element when bnb has "dz_amax": True).
+    wimg + dy_amax (device scalar max |dy|): fp16 scheme.  dy may be a BnApply (needs wimg with its D image)."""
     L = lib()
-    dx = _empty((N, H, W, Cin), dy)
+    dyp, amp, app, like = _dy_args(dy, dy_amax)
+    dx = _empty((N, H, W, Cin), like)
     fl = 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin
     tag = f"conv_dgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}"
     el = N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout + Cout * KH * KW * Cin + N * H * W * Cin
     el += N * H * W * Cin if residual is not None else 0
-    mpp = 3 if (wimg is not None and dy_amax is not None) else 6
+    mpp = 3 if (wimg is not None and (dy_amax is not None or app is not None)) else 6
+    if app is not None:
+        el += N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout      # (dz and c are both read)
+        tag += " apply"
     if bnb is None:
         e0 = _prof_begin()
-        check(L.koaf_conv2d_dgrad(_ptr(dy), _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
-                                  _ptr(residual), _img(wimg), _ptr(dy_amax), _stream()), "conv2d_dgrad")
+        check(L.koaf_conv2d_dgrad(dyp, _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                  _ptr(residual), _img(wimg), amp, app, _stream()), "conv2d_dgrad")
         _prof_end(e0, "gemm", fl, tag, el, mpp=mpp)
         return dx
     sv, sv2 = bnb["saved"], bnb.get("saved2")
-    kb = KoafBnb(mode=bnb["mode"], c=_ptr(bnb["c"]), y=_ptr(bnb.get("y")), sc=_ptr(sv[2]), sh=_ptr(sv[3]),
+    dzmax = _empty((1,), like) if bnb.get("dz_amax") else None
+    kb = KoafBnb(mode=bnb["mode"], dz_amax=_ptr(dzmax), c=_ptr(bnb["c"]), y=_ptr(bnb.get("y")), sc=_ptr(sv[2]), sh=_ptr(sv[3]),
                  mean=_ptr(sv[0]), invstd=_ptr(sv[1]), c2=_ptr(bnb.get("c2")),
                  mean2=_ptr(sv2[0]) if sv2 is not None else None, invstd2=_ptr(sv2[1]) if sv2 is not None else None)
     nsum = 3 if bnb.get("c2") is not None else 2
-    part = _empty((L.koaf_conv2d_dgrad_bnb_rows(N, H, W, Cin, stride), nsum, Cin), dy)
+    part = _empty((L.koaf_conv2d_dgrad_bnb_rows(N, H, W, Cin, stride), nsum, Cin), like)
     rows = _i32(0)
     e0 = _prof_begin()
-    check(L.koaf_conv2d_dgrad_bnb(_ptr(dy), _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
+    check(L.koaf_conv2d_dgrad_bnb(dyp, _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
                                   _ptr(residual), ctypes.byref(kb), _ptr(part), ctypes.addressof(rows), _img(wimg),
-                                  _ptr(dy_amax), _stream()), "conv2d_dgrad_bnb")
+                                  amp, app, _stream()), "conv2d_dgrad_bnb")
     el += N * H * W * Cin * (1 + (bnb.get("y") is not None) + (bnb.get("c2") is not None))
     _prof_end(e0, "gemm", fl, tag + " +bnb", el, mpp=mpp)
+    if dzmax is not None:
+        return dx, part[:rows.value], dzmax
     return dx, part[:rows.value]
 
 
 def conv2d_wgrad(dy, x, dw, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, dy_amax=None):
-    """writes dw (packed [Cout,KH,KW,Cin] memory); dy_amax (device scalar max |dy|): fp16 scheme"""
+    """writes dw (packed [Cout,KH,KW,Cin] memory); dy_amax (device scalar max |dy|): fp16 scheme; dy may be a BnApply"""
     L = lib()
+    dyp, amp, app, like = _dy_args(dy, dy_amax)
     ws = L.koaf_conv2d_wgrad_ws(N, H, W, Cin, Cout, KH, KW, stride, pad)
-    slabs = _empty((ws,), dy) if ws > 0 else None
+    slabs = _empty((ws,), like) if ws > 0 else None
     e0 = _prof_begin()
-    check(L.koaf_conv2d_wgrad(_ptr(dy), _ptr(x), _ptr(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
-                              _ptr(in_sh), _ptr(slabs), _ptr(dy_amax), _stream()), "conv2d_wgrad")
-    _prof_end(e0, "gemm", 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin,
-              f"conv_wgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}",
-              N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout + N * H * W * Cin + Cout * KH * KW * Cin,
-              mpp=3 if dy_amax is not None else 6)
+    check(L.koaf_conv2d_wgrad(dyp, _ptr(x), _ptr(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
+                              _ptr(in_sh), _ptr(slabs), amp, app, _stream()), "conv2d_wgrad")
+    npx = N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad)
+    _prof_end(e0, "gemm", 2.0 * npx * Cout * KH * KW * Cin,
+              f"conv_wgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}" + (" apply" if app is not None else ""),
+              npx * Cout * (2 if app is not None else 1) + N * H * W * Cin + Cout * KH * KW * Cin,
+              mpp=3 if (dy_amax is not None or app is not None) else 6)
     return dw
 
 
@@ -262,42 +305,44 @@ def bn_add_relu(c, saved, rows, C, idt=None, idsaved=None, out=None):
     return y
 
 
-def bn_bwd(g, c, saved, rows, C, count, dgamma, dbeta, mask_mode, ymask=None, dz_out=None, dc_out=None, want_amax=False):
-    """Full BatchNorm(+ReLU mask) backward: returns dc -- or (dc, amax) with want_amax: amax = device scalar max |dc|, the
-    scale of dc as an operand of the fp16 contraction scheme.  g is the upstream gradient; with a mask the
-    masked gradient dz is written to dz_out (default: in place over g)."""
+def bn_bwd(g, c, saved, rows, C, count, dgamma, dbeta, mask_mode, ymask=None, dz_out=None, dc_out=None, fused=False):
+    """Full BatchNorm(+ReLU mask) backward: reduce -> finalize -> dc.  g is the upstream gradient; with a mask the masked
+    gradient dz is written to dz_out (default: in place over g).  fused=False: dc is written out (koaf_bn_bwd_apply) and
+    returned; fused=True: returns a BnApply -- the recipe of dc for the GEMM loaders -- and nothing is written."""
     L = lib()
     if mask_mode != 0 and dz_out is None:
         dz_out = g  # mask in place
     part = _empty((L.koaf_colpart_rows(rows, C), 2, C), g)
     r = _i32(0)
+    dzmax = _empty((1,), g) if fused else None
     check(L.koaf_bn_bwd_reduce(_ptr(g), _ptr(c), _ptr(ymask), _ptr(saved[2]), _ptr(saved[3]), _ptr(saved[0]),
                                _ptr(saved[1]), mask_mode, _ptr(dz_out), _ptr(part), ctypes.addressof(r), rows, C,
-                               _stream()), "bn_bwd_reduce")
-    coef = _empty((3, C), g)
-    amax = _empty((1,), g) if want_amax else None
-    check(L.koaf_bn_bwd_finalize(_ptr(part), r.value, C, count, _ptr(saved[2]), _ptr(saved[1]), _ptr(dgamma),
-                                 _ptr(dbeta), _ptr(coef), 2, 1, _ptr(_reduce_ws(r.value, C, g)), _ptr(amax), _stream()),
-          "bn_bwd_finalize")
+                               _ptr(dzmax), _stream()), "bn_bwd_reduce")
     dz = dz_out if dz_out is not None else g
-    dc = dc_out if dc_out is not None else torch.empty_like(c)
-    check(L.koaf_bn_bwd_apply(_ptr(dz), _ptr(c), _ptr(saved[0]), _ptr(coef), _ptr(dc), rows, C, _ptr(amax), _stream()),
-          "bn_bwd_apply")
-    return (dc, amax) if want_amax else dc
+    return _bn_bwd_tail(part[:r.value], 2, 1, dz, c, saved, rows, C, count, dgamma, dbeta, dc_out, fused, dzmax)
 
 
-def bn_bwd_from_part(part, nsum, i1, dz, c, saved, rows, C, count, dgamma, dbeta, dc_out=None, want_amax=False):
-    """BatchNorm backward when the reduction already happened in a dgrad epilogue: finalize + apply."""
+def _bn_bwd_tail(part, nsum, i1, dz, c, saved, rows, C, count, dgamma, dbeta, dc_out, fused, dzmax):
     L = lib()
-    coef = _empty((3, C), dz)
-    amax = _empty((1,), dz) if want_amax else None
+    coef = _empty((4 if fused else 3, C), dz)
+    amax = _empty((1,), dz) if fused else None
     check(L.koaf_bn_bwd_finalize(_ptr(part), part.shape[0], C, count, _ptr(saved[2]), _ptr(saved[1]), _ptr(dgamma),
-                                 _ptr(dbeta), _ptr(coef), nsum, i1, _ptr(_reduce_ws(part.shape[0], C, dz)), _ptr(amax),
-                                 _stream()), "bn_bwd_finalize")
+                                 _ptr(dbeta), _ptr(coef), nsum, i1, _ptr(_reduce_ws(part.shape[0], C, dz)),
+                                 _ptr(saved[0]) if fused else None, _ptr(dzmax), _ptr(amax), _stream()), "bn_bwd_finalize")
+    if fused:
+        return BnApply(dz, c, coef, amax, saved[0], rows, C)
     dc = dc_out if dc_out is not None else torch.empty_like(c)
-    check(L.koaf_bn_bwd_apply(_ptr(dz), _ptr(c), _ptr(saved[0]), _ptr(coef), _ptr(dc), rows, C, _ptr(amax), _stream()),
+    check(L.koaf_bn_bwd_apply(_ptr(dz), _ptr(c), _ptr(saved[0]), _ptr(coef), _ptr(dc), rows, C, None, _stream()),
           "bn_bwd_apply")
-    return (dc, amax) if want_amax else dc
+    return dc
+
+
+def bn_bwd_from_part(part, nsum, i1, dz, c, saved, rows, C, count, dgamma, dbeta, dc_out=None, fused=False, dzmax=None):
+    """BatchNorm backward when the reduction already happened in a dgrad epilogue: finalize (+ apply unless fused; fused
+    needs dzmax, the device scalar max |dz| that epilogue left)."""
+    if fused and dzmax is None:
+        raise KoafError("bn_bwd_from_part(fused=True) needs dzmax (conv2d_dgrad with bnb['dz_amax'])")
+    return _bn_bwd_tail(part, nsum, i1, dz, c, saved, rows, C, count, dgamma, dbeta, dc_out, fused, dzmax)
 
 
 def maxpool_fwd(c, saved, N, H, W, C):

@@ -547,15 +547,49 @@ def test_fp16_scheme_scales(dev, gs, ws):
     assert rel_err(dw.cpu().permute(0, 3, 1, 2), wd.grad) < BWD
 
 
-def test_fp16_scheme_bn_backward_amax(dev):
-    """koaf_bn_bwd_finalize zeroes and koaf_bn_bwd_apply raises the device scalar max |dc|"""
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,s,p", [(3, 19, 17, 64, 128, 3, 1, 1), (2, 20, 20, 128, 64, 3, 2, 1),
+                                                  (5, 13, 11, 256, 64, 1, 1, 0), (2, 14, 14, 64, 256, 1, 2, 0)])
+def test_bn_backward_apply_formed_in_the_gemm_loaders(dev, N, H, W, Cin, Cout, k, s, p):
+    """ops.BnApply: dc = coef0*dz + coef3 - coef2*c evaluated on load by the dgrad / wgrad GEMMs (KoafOperand.tf 2) == the
+    same convolutions on the materialised dc (koaf_bn_bwd_apply), to fp32 rounding of the different evaluation order, and
+    both == the float64 BatchNorm + convolution backward; the scale bound koaf_bn_bwd_finalize leaves is >= max |dc|"""
     from oaprogressionmmf_amd import ops
-    rows, C = 5000, 128
-    g, c = rnd(rows, C).to(dev) * 1e-5, rnd(rows, C).to(dev)
-    gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
-    rm, rv, nbt = torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
-    saved = ops.bn_finalize(ops.colstats(c, rows, C), C, rows, gamma, beta, rm, rv, nbt, 0.1, 1e-5, True)
-    dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
-    for _ in range(2):                               # twice: the accumulator is reset by every finalize
-        dc, amax = ops.bn_bwd(g.clone(), c, saved, rows, C, rows, dg, db, 0, want_amax=True)
-        assert float(amax) == float(dc.abs().max()) > 0
+    OH, OW = ops.conv_out(H, k, s, p), ops.conv_out(W, k, s, p)
+    rows = N * OH * OW
+    x = rnd(N, Cin, H, W)
+    w = rnd(Cout, Cin, k, k, scale=(Cin * k * k) ** -0.5)
+    c = rnd(N, Cout, OH, OW) * 1.5 + 0.3                   # the conv output whose BatchNorm is back-propagated
+    g = rnd(N, Cout, OH, OW) * 1e-3                        # gradient w.r.t. relu(bn(c))
+    gamma, beta = rnd(Cout) * 0.2 + 1.0, rnd(Cout) * 0.1
+    # float64 reference: y = relu(bn_train(c)); dc = d/dc; then dx, dw of conv(x, w) given dc
+    cd = c.double().requires_grad_(True)
+    yb = torch.relu(F.batch_norm(cd, None, None, gamma.double(), beta.double(), True, 0.0, 1e-5))
+    (yb * g.double()).sum().backward()
+    dc_ref = cd.grad
+    xd64, wd64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    F.conv2d(xd64, wd64, stride=s, padding=p).backward(dc_ref)
+    # device: statistics of c, then the fused recipe
+    cdv, gdv = nhwc(c).to(dev), nhwc(g).to(dev)
+    rm, rv, nbt = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+    saved = ops.bn_finalize(ops.colstats(cdv, rows, Cout), Cout, rows, gamma.to(dev), beta.to(dev), rm, rv, nbt, 0.1, 1e-5, True)
+    dg, db = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
+    ap = ops.bn_bwd(gdv.clone(), cdv, saved, rows, Cout, rows, dg, db, 2, fused=True)
+    assert isinstance(ap, ops.BnApply)
+    dc = ap.materialize(want_amax=True)
+    assert rel_err(nchw(dc.cpu()), dc_ref) < 1e-5
+    assert float(ap.amax) >= float(dc._koaf_amax) > 0        # a bound of the largest magnitude, never under it
+    assert float(ap.amax) < 3e4 * float(dc._koaf_amax)       # ... and within the range the fp16 pieces have to spare
+    xdv, wp = nhwc(x).to(dev), packw(w).to(dev)
+    img = ops.build_weight_planes(wp, Cout, k * k, Cin)
+    dx_f = ops.conv2d_dgrad(ap, wp, N, H, W, Cin, Cout, k, k, s, p, wimg=img)
+    dx_m = ops.conv2d_dgrad(dc, wp, N, H, W, Cin, Cout, k, k, s, p, wimg=img, dy_amax=dc._koaf_amax)
+    assert rel_err(dx_f, dx_m.double()) < 2e-6
+    assert rel_err(nchw(dx_f.cpu()), xd64.grad) < 1e-5
+    dw_f, dw_m = torch.empty(Cout, k, k, Cin, device=dev), torch.empty(Cout, k, k, Cin, device=dev)
+    ops.conv2d_wgrad(ap, xdv, dw_f, N, H, W, Cin, Cout, k, k, s, p)
+    ops.conv2d_wgrad(dc, xdv, dw_m, N, H, W, Cin, Cout, k, k, s, p, dy_amax=dc._koaf_amax)
+    assert rel_err(dw_f, dw_m.double()) < 2e-6
+    assert rel_err(dw_f.cpu().permute(0, 3, 1, 2), wd64.grad) < 1e-5
+
+
+
