@@ -218,34 +218,6 @@ def case_f1_attention_feat(km, **_):
     print("  wrote f1_attention_feat.npz")
 
 
-def case_f2_bottleneck(tv, **_):
-    out = {}
-    for tag, inpl, planes, stride, groups, bw in (("s1", 256, 64, 1, 1, 64), ("s2ds", 256, 128, 2, 1, 64),
-                                                  ("g32", 256, 128, 1, 32, 4), ("g32s2ds", 256, 256, 2, 32, 4)):
-        torch.manual_seed(0)
-        ds = None
-        if stride != 1 or inpl != planes * 4:
-            ds = torch.nn.Sequential(tv.conv1x1(inpl, planes * 4, stride), torch.nn.BatchNorm2d(planes * 4))
-        blk = tv.Bottleneck(inpl, planes, stride, ds, groups, bw)
-        P.fill_state_dict(blk.state_dict())
-        x = torch.relu(t(P.make_input("blk" + tag, (4, inpl, 20, 20))))
-        blk.eval()
-        with torch.no_grad():
-            ye = blk(x).numpy()
-        blk.train()
-        xr = x.clone().requires_grad_(True)
-        y = blk(xr)
-        (y * t(P.make_input("blkg" + tag, tuple(y.shape)))).sum().backward()
-        out.update({tag + ":" + k: v for k, v in P.summarize_tensors(
-            {"eval": ye, "train": y.detach().numpy(), "dx": xr.grad.numpy()}, k=512).items()})
-        out.update({tag + ":" + k: v for k, v in P.summarize_tensors(
-            {"grad:" + k: p.grad.numpy() for k, p in blk.named_parameters()}).items()})
-        out.update({tag + ":" + k: v for k, v in P.summarize_tensors(
-            {"buf:" + k: b.numpy() for k, b in blk.named_buffers()}).items()})
-    np.savez_compressed(HERE / "f2_bottleneck.npz", **out)
-    print("  wrote f2_bottleneck.npz")
-
-
 def case_f3_trunk(tv, **_):
     out = {}
     for arch, shape in (("resnet50", (4, 1, 160, 160)), ("resnet50", (2, 1, 96, 112)), ("resnext50_32x4d", (2, 1, 130, 130)),
@@ -493,7 +465,7 @@ def case_f14_fullsize(km, tv, losses, **_):
 
 
 CASES = {
-    "f1": case_f1_attention_feat, "f2": case_f2_bottleneck, "f3": case_f3_trunk, "f4": case_f4_xr1cnn,
+    "f1": case_f1_attention_feat, "f3": case_f3_trunk, "f4": case_f4_xr1cnn,
     "f5": case_f5_mr, "f5g": case_f5_nogap, "f6": case_f6_full, "f7": case_f7_focal, "f8": case_f8_interp, "f9": case_f9_sched,
     "f11": case_f11_bookkeeping, "f12": case_f12_augment, "f13": case_f13_modal_abl, "f14": case_f14_fullsize,
 }

@@ -1,6 +1,6 @@
 """GPU: the three registry extensions (XR1C1Cnn, MR1C1CnnTrf, XR1MR3C1CnnTrf -- BASELINE.json configs without a
 reference class) against the oracle's statement of the same definitions.  No reference fixture can exist for
-them; the oracle's blocks are the reference-pinned ones (F2-F8).  Bar: eval/train logits and loss within 2e-4
+them; the oracle's blocks are the reference-pinned ones (F1, F3-F8).  Bar: eval/train logits and loss within 2e-4
 (BASELINE: 1e-3), the set of gradient-less parameters exact, BatchNorm running statistics within 2e-4, gradients
 against the oracle in float64 under common.check_grads_branchy (1e-4 above the encoders; ReLU-branch noise level
 inside them -- see there why no tighter bar is meaningful without a reference-recorded noise table)."""

@@ -1,7 +1,12 @@
 """GPU: the product models (HIP kernels through the C ABI) against the golden vectors of the imported
 reference -- same procedural weights, same seeded inputs.  Bar from BASELINE.json: logits within 1e-3
 relative fp32; bookkeeping (which parameters get no gradient, num_batches_tracked) exact.  Tolerances
-written at each assert: we hold 2e-4 on logits / loss and 2e-3 on every parameter-gradient summary."""
+written at each assert: 2e-4 on logits / loss / BatchNorm buffers.  Gradients: through ~50 train-mode BatchNorm layers the
+reference's OWN float32 gradients sit 1e-4 ... 2e-2 (per tensor) from its float64 run (`e32` in the fixtures), so the bar is
+stated against that noise: (1) against the float64 truth, median over parameters of err / (e32 + 1e-4) <= 2 and no tensor
+beyond 10x (common.check_grads_vs_truth, which also explains the ReLU-branch unit); (2) directly against the fixture's
+float32 gradient norms: median relative difference <= 5e-3, no tensor beyond max(5e-2, 5 x its own e32).  The achieved
+figures of both are printed (run with -s)."""
 import json
 
 import numpy as np
@@ -68,7 +73,16 @@ def run_case(fname, dev, adam_steps=0):
     assert rel(logits.detach().cpu().numpy(), lg64.numpy()) < 3 * float(gold["e32_logits"]) + 1e-5
     truth = {k: p.grad.numpy() for k, p in om.named_parameters() if p.grad is not None}
     mine = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None}
-    check_grads_vs_truth(mine, truth, e32_table(gold), fname, n_top=top_relu_elems(cfg, B))
+    e32 = e32_table(gold)
+    med_ratio, worst_ratio = check_grads_vs_truth(mine, truth, e32, fname, n_top=top_relu_elems(cfg, B))
+    # the fixture's float32 gradient norms, directly
+    nd = {k[5:-5]: abs(float(got[k]) - float(gold[k])) / max(abs(float(gold[k])), 1e-30)
+          for k in gold.files if k.startswith("grad:") and k.endswith(":norm")}
+    wk = max(nd, key=lambda k: nd[k] / max(5e-2, 5 * e32.get(k, 0.0)))
+    print(f"\n[{fname}] gradients vs float64 truth: median err/(e32+1e-4) = {med_ratio:.2f}, worst = {worst_ratio:.2f}; "
+          f"norms vs the reference's float32: median {np.median(list(nd.values())):.2e}, worst {nd[wk]:.2e} ({wk}, its e32 {e32.get(wk, 0.0):.2e})")
+    assert np.median(list(nd.values())) <= 5e-3, "median gradient-norm difference to the reference's float32 run"
+    assert nd[wk] <= max(5e-2, 5 * e32.get(wk, 0.0)), (wk, nd[wk])
     nbt = [b.item() for k, b in m.named_buffers() if k.endswith("num_batches_tracked")]
     assert nbt == gold["num_batches_tracked"].tolist()
     if adam_steps:
