@@ -71,6 +71,7 @@ __device__ __forceinline__ void split3v(const v4f x, unsigned out[3][2]) {
 }
 
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 // power of two that brings a tensor whose largest magnitude is amax to [2^14, 2^15) (1 for amax == 0); koaf_wplanes_build
@@ -84,20 +85,18 @@ __device__ __forceinline__ float operand_scale(const KoafOperand& o) {
     return o.amax ? scale_of_amax(*o.amax) : (o.fscale != 0.f ? o.fscale : 1.f);
 }
 
-// four fp32 values -> (hi, lo) pairs of dwords holding 4 packed fp16 each, of x * scale (scale = a power of two chosen so
-// that the operand's largest magnitude sits near 2^14; values are clamped to the fp16 range): hi = fp16(x'), lo =
-// fp16(x' - hi), both round-to-nearest, so x' = hi + lo to 2^-24 relative (lo carries a sign) down to |x'| = 2^-2 and to
-// 2^-25 absolute below that (fp16 subnormal spacing 2^-24).
-__device__ __forceinline__ void split2h(const v4f x, float scale, unsigned out[2][2]) {
-    float xs[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) xs[e] = __builtin_amdgcn_fmed3f(x[e] * scale, -65504.f, 65504.f);
+// four fp32 values x' (already multiplied by the operand's scale and clamped to the fp16 range by the loader's finish()) ->
+// (hi, lo) pairs of dwords holding 4 packed fp16 each: hi = fp16(x'), lo = fp16(x' - hi), both round-to-nearest, so
+// x' = hi + lo to 2^-24 relative (lo carries a sign) down to |x'| = 2^-2 and to 2^-25 absolute below that (fp16 subnormal
+// spacing 2^-24).  The residual is taken from the PACKED hi, so one v_cvt_pk_f16_f32 serves storage and residual.
+__device__ __forceinline__ void split2h(const v4f x, unsigned out[2][2]) {
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-        const h16x2 hv = {(_Float16)xs[2 * d], (_Float16)xs[2 * d + 1]};
-        const h16x2 lv = {(_Float16)(xs[2 * d] - (float)hv[0]), (_Float16)(xs[2 * d + 1] - (float)hv[1])};
-        out[0][d] = __builtin_bit_cast(unsigned, hv);
-        out[1][d] = __builtin_bit_cast(unsigned, lv);
+        const float a = x[2 * d], b = x[2 * d + 1];
+        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector((v2f){a, b}, h16x2));
+        const h16x2 hv = __builtin_bit_cast(h16x2, hb);
+        out[0][d] = hb;
+        out[1][d] = __builtin_bit_cast(unsigned, __builtin_convertvector((v2f){a - (float)hv[0], b - (float)hv[1]}, h16x2));
     }
 }
 
@@ -117,7 +116,9 @@ __host__ __device__ constexpr bool mode_is_kc(int m) { return m < 3; }
 // BatchNorm-BACKWARD apply dc = sc[c] * dz + sh[c] - sc2[c] * c_raw of TWO source tensors (x = dz at ptr, c_raw at ptr2, same
 // layout): the gradient w.r.t. a conv output is formed in the loaders of the dgrad / wgrad GEMMs that consume it and never
 // written to HBM.  (TF 2 needs the vector path.)
-template <int ROWS, int MODE, int TF, bool VEC>
+// F16: the operand feeds the fp16 scheme: finish() also multiplies by the operand's scale `fsc` (folded into the transform
+// coefficients where there is a transform) and clamps to the fp16 range (relu and clamp are one v_med3 for TF 1).
+template <int ROWS, int MODE, int TF, bool VEC, bool F16>
 struct TileLoader {
     static constexpr int NU = ROWS / 32;
     static constexpr bool KC = mode_is_kc(MODE);
@@ -131,6 +132,7 @@ struct TileLoader {
     };
     Slot sa, sb;
     v4f kts4, kth4, ktk4;    // transform coefficients of this thread's columns (KM operands: fixed)
+    float fsc;               // F16: operand scale (a power of two)
     // KC state (ext-vector values, not arrays: arrays of per-unit state were left in scratch by hipcc and
     // every scratch reload drained the in-flight global loads through the in-order vmcnt)
     v4l base;          // element offset of each unit's row / image from the operand pointer
@@ -152,8 +154,9 @@ struct TileLoader {
     int g_cs, g_bs, g_pws, g_phs, g_sxlim, g_sylim;
     int64_t g_d0, g_d1, g_d2;
 
-    __device__ __forceinline__ void init(const KoafOperand& op, int r0, int R, int z1) {
+    __device__ __forceinline__ void init(const KoafOperand& op, int r0, int R, int z1, float scale) {
         const int t = threadIdx.x;
+        fsc = scale;
         sa.vm = sb.vm = 0;
         sa.ts4 = sa.th4 = sb.ts4 = sb.th4 = kts4 = kth4 = sa.tk4 = sb.tk4 = ktk4 = (v4f){0.f, 0.f, 0.f, 0.f};
         rvm = cvm = 0;
@@ -212,6 +215,7 @@ struct TileLoader {
                     for (int j = 0; j < 4; ++j)
                         if ((cvm >> j) & 1u) { kts4[j] = sc[cc + j]; kth4[j] = sh[cc + j]; }
                 }
+                if constexpr (F16) { kts4 *= fsc; kth4 *= fsc; ktk4 *= fsc; }
             }
         }
     }
@@ -410,21 +414,29 @@ struct TileLoader {
     }
 
     // transform + zero-fill of the tile issued by issue(); first consumer of the loaded registers
-    __device__ __forceinline__ void finish_unit(Slot& s, int i) {
-        const v4f a = KC ? s.ts4 : kts4, b = KC ? s.th4 : kth4;
-        [[maybe_unused]] const v4f k = KC ? s.tk4 : ktk4;
+    __device__ __forceinline__ void finish_unit(Slot& s, int i, v4f a, v4f b, v4f k) {
+        constexpr float HMAX = 65504.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool ok = VEC ? ((s.vm >> i) & 1u) : ((s.vm >> (4 * i + j)) & 1u);
             float x = s.r[i][j];
-            if constexpr (TF == 1) x = fmaxf(x * a[j] + b[j], 0.f);
-            if constexpr (TF == 2) x = fmaf(a[j], x, fmaf(-k[j], s.r2[i < NU2 ? i : 0][j], b[j]));
+            if constexpr (TF == 1) {
+                x = x * a[j] + b[j];
+                x = F16 ? __builtin_amdgcn_fmed3f(x, 0.f, HMAX) : fmaxf(x, 0.f);
+            } else if constexpr (TF == 2) {
+                x = fmaf(a[j], x, fmaf(-k[j], s.r2[i < NU2 ? i : 0][j], b[j]));
+                if constexpr (F16) x = __builtin_amdgcn_fmed3f(x, -HMAX, HMAX);
+            } else if constexpr (F16) {
+                x = __builtin_amdgcn_fmed3f(x * fsc, -HMAX, HMAX);
+            }
             s.r[i][j] = ok ? x : 0.f;
         }
     }
     __device__ __forceinline__ void finish(Slot& s) {
+        v4f a = KC ? s.ts4 : kts4, b = KC ? s.th4 : kth4, k = KC ? s.tk4 : ktk4;
+        if constexpr (F16 && KC && TF != 0) { a *= fsc; b *= fsc; k *= fsc; }     // (KM coefficients were scaled once in init)
 #pragma unroll
-        for (int i = 0; i < NU; ++i) finish_unit(s, i);
+        for (int i = 0; i < NU; ++i) finish_unit(s, i, a, b, k);
     }
     // LDS dword offset (within a plane) of unit i of this thread
     __device__ __forceinline__ int plane_off(int i) const {
@@ -438,14 +450,14 @@ struct TileLoader {
         }
     }
 
-    template <int NPL, bool F16>
-    __device__ __forceinline__ void store(const Slot& s, float* Sf, float scale) const {
+    template <int NPL>
+    __device__ __forceinline__ void store(const Slot& s, float* Sf) const {
         unsigned* S = (unsigned*)Sf;
         constexpr int P = plane_dwords(ROWS, KC);
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             unsigned pl[NPL][2];
-            if constexpr (F16) split2h(s.r[i], scale, pl);
+            if constexpr (F16) split2h(s.r[i], pl);
             else split3v(s.r[i], pl);
             const int off = plane_off(i);
 #pragma unroll
@@ -621,17 +633,17 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     const float* Bp = BPS ? nullptr : p.B.ptr + z0 * p.B.bs0 + z1 * p.B.bs1;
     const unsigned short* Bpl = BPS ? p.B.planes + z0 * p.B.bs0 + z1 * p.B.bs1 : nullptr;
 
-    TileLoader<BM, AM, TFA, VEC> la;
+    TileLoader<BM, AM, TFA, VEC, F16> la;
     // (the unused one of the two B loaders is dead code to the compiler)
-    TileLoader<BN, BPS ? M_KC : BMD, TFB, VEC> lb;
+    TileLoader<BN, BPS ? M_KC : BMD, TFB, VEC, F16> lb;
     PlaneLoader<BN> lp;
-    la.init(p.A, m0, p.M, z1);
+    la.init(p.A, m0, p.M, z1, sca);
     la.seek(p.A, kbeg);
     if constexpr (BPS) {
         lp.init(p.B, n0, p.N);
         lp.seek(p.B, kbeg);
     } else {
-        lb.init(p.B, n0, p.N, z1);
+        lb.init(p.B, n0, p.N, z1, scb);
         lb.seek(p.B, kbeg);
     }
 
@@ -654,10 +666,10 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         la.issue(la.sa, p.A, Ap, kbeg, kend, z1);
         if constexpr (!BPS) lb.issue(lb.sa, p.B, Bp, kbeg, kend, z1);
         la.finish(la.sa);
-        la.template store<NPL, F16>(la.sa, smem, sca);
+        la.template store<NPL>(la.sa, smem);
         if constexpr (!BPS) {
             lb.finish(lb.sa);
-            lb.template store<NPL, F16>(lb.sa, Bs0, scb);
+            lb.template store<NPL>(lb.sa, Bs0);
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
         }
@@ -718,10 +730,10 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         else __syncthreads();
         if (more) {
             la.finish(la.sa);
-            la.template store<NPL, F16>(la.sa, smem, sca);
+            la.template store<NPL>(la.sa, smem);
             if constexpr (!BPS) {
                 lb.finish(lb.sa);
-                lb.template store<NPL, F16>(lb.sa, Bs0, scb);
+                lb.template store<NPL>(lb.sa, Bs0);
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 cur ^= 1;
@@ -1225,7 +1237,13 @@ __global__ void __launch_bounds__(256) wplanes_build_kernel(const float* __restr
     const int t = threadIdx.x, ty = t >> 3, tx = t & 7;
     const int r = w.rt * 32 + ty, c = w.ct * 32 + 4 * tx;
     unsigned pl[2][2];
-    split2h(wtile_load(base, w, r, c), scale_of_amax(amax[w.idx]), pl);
+    {
+        v4f x = wtile_load(base, w, r, c);
+        const float sc = scale_of_amax(amax[w.idx]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = __builtin_amdgcn_fmed3f(x[j] * sc, -65504.f, 65504.f);
+        split2h(x, pl);
+    }
     if (d.f_off >= 0 && r < d.R) {
         // (c + 3 < Kp always: Kp and c are multiples of 4, the tile covers C rounded up to 32 only when taps == 1)
         unsigned short* f = planes + d.f_off + (int64_t)r * d.Kp + (int64_t)w.tap * d.C + c;

@@ -1,0 +1,68 @@
+"""Reduce the two rocprofv3 --pmc passes of scripts/collect_sq_counters.sh to per-kernel averages ->
+profiles/r02_gemm_sq_counters.json.  Usage: python scripts/sq_counters_summary.py gpurun_out/<dir>
+Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves;
+SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
+import collections
+import csv
+import json
+import re
+import sys
+from pathlib import Path
+
+O = Path(sys.argv[1])
+ROOT = Path(__file__).resolve().parent.parent
+LABEL = {
+    "128, 128, 0, 0, 0, 0, true, false": "dense forward 4096^3, bf16 x 3 (6 MFMAs per product)",
+    "128, 128, 1, 6, 1, 0, true, true": "conv 3x3 256->256 forward, fp16 x 2 (3 MFMAs): BN prologue, weight tiles by LDS-DMA",
+    "128, 128, 2, 6, 2, 0, true, true": "conv 3x3 256->256 data gradient, fp16 x 2: dy formed from (dz, c) on load, weight tiles by LDS-DMA",
+    "128, 128, 3, 4, 2, 1, true, true": "conv 3x3 256->256 weight gradient, fp16 x 2: dy formed on load, x through its BN prologue",
+    "128, 128, 1, 0, 1, 0, true, false": "conv 3x3 256->256 forward, bf16 x 3 (the round-1 scheme)",
+}
+
+
+def load(tag):
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    name, dur = {}, {}
+    with open(O / f"{tag}_counter_collection.csv") as fh:
+        for r in csv.DictReader(fh):
+            m = re.search(r"koaf_gemm_kernel<([^>]*)>", r["Kernel_Name"])
+            if not m:
+                continue
+            d = r["Dispatch_Id"]
+            per[d][r["Counter_Name"]] += float(r["Counter_Value"])
+            name[d] = m.group(1)
+            dur[d] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    return per, name, dur
+
+
+out = []
+pa, na, da = load("a")
+pb, nb, db = load("b")
+for key, label in LABEL.items():
+    A = [pa[d] for d in pa if na[d] == key][2:]          # (the first launches of a series warm the caches / clocks)
+    B = [pb[d] for d in pb if nb[d] == key][2:]
+    us = [da[d] for d in pa if na[d] == key][2:]
+    if not A or not B:
+        continue
+    avg = lambda L, c: sum(x[c] for x in L) / len(L)      # noqa: E731
+    t_us = sum(us) / len(us)
+    clock = avg(A, "GRBM_GUI_ACTIVE") / 8 / t_us / 1e3    # GHz
+    mfma = avg(B, "SQ_INSTS_MFMA") if avg(B, "SQ_INSTS_MFMA") else (avg(B, "SQ_INSTS_VALU_MFMA_MOPS_F16") + avg(B, "SQ_INSTS_VALU_MFMA_MOPS_BF16")) / 512
+    wave = avg(A, "SQ_WAVE_CYCLES")
+    out.append({
+        "kernel": label, "template": f"koaf_gemm_kernel<{key}>", "us": round(t_us, 1), "clock_ghz": round(clock, 2),
+        "mfma_busy_frac_at_clock": round(avg(A, "SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / (t_us * clock * 1e3), 3),
+        "valu_per_mfma": round((avg(A, "SQ_INSTS_VALU") - mfma) / mfma, 2),
+        "lds_per_mfma": round(avg(B, "SQ_INSTS_LDS") / mfma, 2), "vmem_rd_per_mfma": round(avg(B, "SQ_INSTS_VMEM_RD") / mfma, 3),
+        "salu_per_mfma": round(avg(B, "SQ_INSTS_SALU") / mfma, 2),
+        "wait_any": round(avg(A, "SQ_WAIT_ANY") / wave, 3), "wait_inst_any": round(avg(A, "SQ_WAIT_INST_ANY") / wave, 3),
+        "active_inst_any": round(avg(A, "SQ_ACTIVE_INST_ANY") / wave, 3),
+    })
+doc = {"command": "bash scripts/collect_sq_counters.sh <dir> (two rocprofv3 --pmc passes, --kernel-trace --output-format csv, no other "
+                  "trace domain, over scripts/bench_gemm_pmc.py 20), reduced by scripts/sq_counters_summary.py",
+       "note": "averages over 18 launches per kernel on random operands; *_per_mfma are wave-instruction counts per matrix instruction; "
+               "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (duration x clock); wait_* / active_* are shares of SQ_WAVE_CYCLES",
+       "kernels": out}
+json.dump(doc, open(ROOT / "profiles" / "r02_gemm_sq_counters.json", "w"), indent=1)
+for k in out:
+    print(k)

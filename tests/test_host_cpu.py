@@ -254,8 +254,8 @@ def test_bench_workloads_are_constructible():
     spec.loader.exec_module(bench)
     names = ("native3", "eval3", "native", "syn", "syn3", "xr1cnn", "xr1c1", "mr1", "mr1c1")
     for name in names:
-        cfg, b = bench.workload_cfg(name)
-        assert b >= 1 and bench.algorithmic_train_gflop_per_sample(name) > 0
+        cfg, b, policy = bench.workload_cfg(name)
+        assert b >= 1 and isinstance(policy, str) and bench.algorithmic_train_gflop_per_sample(name) > 0
         shapes = cfg.pop("_tensor_shapes", None)
         if name not in ("syn", "syn3", "mr1c1", "native3", "eval3", "native"):        # (the big ones: ~0.4-0.6 G parameters each)
             m = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None)

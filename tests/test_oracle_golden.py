@@ -147,6 +147,36 @@ def test_oracle_trunks():
         check_summary(got, g, tag + ":buf:", 1e-5, tag)
 
 
+def test_oracle_fullsize_fixtures():
+    """the oracle against the full-size fixtures F14 it can afford on the CPU suite: the ResNet-50 trunk forward on 2 x 384 x 384
+    (eval and train outputs) and FeaT at 482 + 1 tokens (outputs, states, attention, every gradient); the 160-slice MR1CnnTrf
+    fixture takes minutes and 45 GB and is checked on the GPU side only (tests/test_fullsize_values_gpu.py)"""
+    g = load("f14_trunk384.npz")
+    arch, shape = "resnet50", (2, 1, 384, 384)
+    tag = f"{arch}_{shape[0]}x{shape[2]}x{shape[3]}"
+    spec = O.trunk_spec("t", arch)
+    sd = {k: t(P.fill_value(k[2:], s, dt == torch.int64)).reshape(s) for k, s, dt in spec}
+    x = t(P.make_input("trunk", shape))
+    with torch.no_grad():
+        assert rel(O.trunk(x, sd, "t", arch, False).numpy(), g[tag + ":eval"]) < 1e-5
+        assert rel(O.trunk(x, {k: v.clone() for k, v in sd.items()}, "t", arch, True).numpy(), g[tag + ":train"]) < 1e-5
+    g = load("f14_feat483.npz")
+    spec = O.feat_spec("f", 482, 2048, 4, 2048, 2, True)
+    sd = {k: t(P.fill_value(k[2:], s, dt == torch.int64)) for k, s, dt in spec}
+    for k in sd:
+        if O.is_param(k):
+            sd[k].requires_grad_(True)
+    xf = t(P.make_input("feat483", (2, 482, 2048))).requires_grad_(True)
+    o, st, att = O.feat(xf, sd, "f", 4, 8, True)
+    ((o * t(P.make_input("feat483go", tuple(o.shape)))).sum() + (st * t(P.make_input("feat483gs", tuple(st.shape)))).sum() * 1e-2).backward()
+    assert rel(o.detach().numpy(), g["outputs"]) < 1e-5
+    got = P.summarize_tensors({"states": st.detach().numpy(), "attn0": att[0].detach().numpy(),
+                               "attn3": att[3].detach().numpy(), "dx": xf.grad.numpy()}, k=64)
+    got.update(P.summarize_tensors({"grad:" + k[2:]: v.grad.numpy() for k, v in sd.items() if O.is_param(k) and v.grad is not None}))
+    for key in ("states:", "attn0:", "attn3:", "dx:", "grad:"):
+        check_summary(got, g, key, 1e-4 if key == "grad:" else 1e-5, "FeaT n=483 " + key)
+
+
 def test_oracle_focal_interp_sched():
     g = load("f7_focal.npz")
     lt = t(g["logits"]).requires_grad_(True)
