@@ -45,7 +45,7 @@ typedef struct KoafOperand {
     int64_t bs0, bs1; /* batch strides (elements) for batch index z = z0*nb1 + z1 */
     int64_t tap_stride;   /* gather 3 (K-major weights [C][taps][rows]): offset between taps in a tap row */
     int64_t tap_stride_h; /* gather 3: offset between tap rows; tap index = th*KW + tw */
-    int32_t kind;     /* 0 = KC, 1 = KM, 2 = pre-split fp16 plane images (B operand only; see `planes`) */
+    int32_t kind;     /* 0 = KC, 1 = KM, 2 = pre-split fp16 plane images (B: weights, see `planes`; A: activations, see `zeros`) */
     int32_t gather;   /* 0 none; 1 conv forward gather; 2 transposed-conv (dgrad) gather;
                          3 (KM only) tapped weights: k = (tap, c), element at c*ld + tap*tap_stride + r */
     int32_t H, W, C;  /* source NHWC tensor dims for a gathered operand (C = channels per tap) */
@@ -77,6 +77,12 @@ typedef struct KoafOperand {
     int32_t _pad4;
     const float* ptr2;  /* tf 2: second source tensor */
     const float* sc2;   /* tf 2: its per-channel coefficient */
+    /* kind 2 with gather 1 | 2 (A operand): ACTIVATION plane images cut by koaf_act_planes -- the two fp16 piece planes
+       [pixel][CS] of an NHWC tensor (plane q at planes + q*plane_stride), transform already applied (tf must be 0), scaled
+       by the operand's scale (amax / fscale as above).  Gathered like the fp32 operand of the same `gather`; padding taps
+       and rows past M read `zeros` (16 B of zeros, 16-B aligned: koaf_act_planes leaves them at planes + 2*plane_stride).
+       C % 32 == 0, CS % 8 == 0; needs a pre-split B (kind 2), fmt 1, K % 32 == 0, no split-K. */
+    const uint16_t* zeros;
 } KoafOperand;
 
 typedef struct KoafGemm {
@@ -160,6 +166,22 @@ typedef struct KoafWPlane {
 } KoafWPlane;
 int koaf_wplanes_build(const float* base, uint16_t* planes, float* amax, const KoafWPlane* table_dev, int32_t n,
                        int64_t ntiles, void* stream);
+/* Activation plane images (KoafOperand.kind 2 on the A side): planes[q][pixel][C], q = 0 (hi), 1 (lo), of
+ *   tf 0: x          tf 1: relu(sc[c]*x + sh[c])          tf 2: sc[c]*x + sh[c] - sc2[c]*x2
+ * times the operand scale (scale(*amax) if amax != NULL, else fscale), clamped to +-65504, cut like the GEMM's own loader
+ * cuts them (bit-identical), followed by the 16-B zero chunk.  `planes` holds koaf_act_planes_elems(npix, C) 16-bit
+ * elements.  One HBM pass (read 4 or 8 B, write 4 B per element) that saves the convolution's k-loop the KH*KW-fold
+ * conversion of every element. */
+/* Gathered 3x3 / stride 1 / pad 1 convolutions over activation plane images (image rows up to 96 pixels) run the HALO
+ * kernel: 256-pixel tiles in raster order whose source pixels for all nine taps are one contiguous range kept in LDS, so
+ * the input tile is fetched 1.8 times instead of nine (k runs (channel chunk, tap, channel): the sums are reassociated
+ * against the per-tap gather kernel, same accuracy).  koaf_set_conv3x3_halo(0) sends them through the gather kernel
+ * instead (tests / A-B measurements); returns the previous setting.  Process-wide; not meant to be flipped while other
+ * threads launch. */
+int koaf_set_conv3x3_halo(int on);
+int64_t koaf_act_planes_elems(int64_t npix, int32_t C);
+int koaf_act_planes(const float* x, const float* x2, int64_t npix, int32_t C, int32_t tf, const float* sc, const float* sh,
+                    const float* sc2, const float* amax, float fscale, uint16_t* planes, void* stream);
 /* what the convolution entry points take for a weight whose images are current (all device pointers) */
 typedef struct KoafWImg {
     const uint16_t* f;      /* F image or NULL */
@@ -183,22 +205,27 @@ typedef struct KoafBnApply {
  * that BatchNorm's running_mean and hand the same pointer to koaf_bn_finalize).  wimg (nullable): plane images of w
  * (koaf_wplanes_build; they must be current): the contraction then runs on the fp16 scheme (KoafGemm.fmt 1) with the
  * activations at the fixed scale KOAF_ACT_SCALE and the weight tiles DMA'd from wimg->f (wimg->f NULL: weight split in
- * the kernel with the same scale -- bit-identical, slower).  */
+ * the kernel with the same scale -- bit-identical, slower).  x_planes (nullable; needs wimg->f, Cin % 32 == 0): activation
+ * plane images of the TRANSFORMED input (koaf_act_planes: tf 1 with in_sc / in_sh, or tf 0; fscale KOAF_ACT_SCALE): the
+ * gathered input tiles are then DMA'd as well and x / in_sc / in_sh are not read -- bit-identical, and what the 3x3
+ * convolutions use: their fp32 loader converts every element nine times.  */
 #define KOAF_ACT_SCALE 16.0f   /* activations are O(1) behind BatchNorm: |x| * 16 clamps at 65504, 2^-29 absolute resolution */
 int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W,
                     int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                     const float* in_sc, const float* in_sh, float* stats, int32_t* stats_rows,
-                    const float* stats_shift, const KoafWImg* wimg, void* stream);
+                    const float* stats_shift, const KoafWImg* wimg, const uint16_t* x_planes, void* stream);
 /* rows of the stats buffer koaf_conv2d_fwd writes for M output pixels */
 int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout);
 /* dx [N,H,W,Cin] = conv_transpose(dy [N,OH,OW,Cout], w) (+residual: the other branch's gradient);
  * w is read K-major in place (no re-packed copy).  With wimg AND dy_amax (device scalar: max |dy|, e.g. from
  * koaf_bn_bwd_apply) the contraction runs on the fp16 scheme, the weight tiles DMA'd from wimg->d.  dy_apply (nullable, needs
- * wimg->d; dy may then be NULL): dy is formed on load from (dz, c), see KoafBnApply.  */
+ * wimg->d; dy may then be NULL): dy is formed on load from (dz, c), see KoafBnApply.  dy_planes (nullable; needs wimg->d,
+ * dy_amax, Cout % 32 == 0): activation plane images of dy (koaf_act_planes with amax = dy_amax; tf 2 for an applied dy):
+ * dy / dy_apply are then not read.  */
 int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
                       int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride,
                       int32_t pad, const float* residual, const KoafWImg* wimg, const float* dy_amax,
-                      const KoafBnApply* dy_apply, void* stream);
+                      const KoafBnApply* dy_apply, const uint16_t* dy_planes, void* stream);
 /* Same, with the BatchNorm(+ReLU) backward reduction of the layer that PRODUCED x fused into the epilogue (see
  * KoafGemm.bnb_*): dx receives the masked gradient dz; part [*part_rows][nsum][Cin] (nsum = 2, or 3 with c2) feeds
  * koaf_bn_bwd_finalize.  koaf_conv2d_dgrad_bnb_rows() bounds *part_rows for sizing. */
@@ -219,7 +246,8 @@ int32_t koaf_conv2d_dgrad_bnb_rows(int32_t N, int32_t H, int32_t W, int32_t Cin,
 int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
                           int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                           const float* residual, const KoafBnb* bnb, float* part, int32_t* part_rows,
-                          const KoafWImg* wimg, const float* dy_amax, const KoafBnApply* dy_apply, void* stream);
+                          const KoafWImg* wimg, const float* dy_amax, const KoafBnApply* dy_apply,
+                          const uint16_t* dy_planes, void* stream);
 /* dw packed [Cout,KH,KW,Cin] = sum_pixels dy^T x, x optionally transformed on load.  Deterministic
  * split-K: slabs = workspace of koaf_conv2d_wgrad_ws() floats (0 = none needed).  dy_amax (nullable): max |dy| on the
  * device -> fp16 scheme.  */

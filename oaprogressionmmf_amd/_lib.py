@@ -47,6 +47,7 @@ class KoafOperand(ctypes.Structure):
         ("_pad4", ctypes.c_int32),
         ("ptr2", ctypes.c_void_p),
         ("sc2", ctypes.c_void_p),
+        ("zeros", ctypes.c_void_p),
     ]
 
 

@@ -23,6 +23,12 @@ inline void set_fimg(KoafGemm* g, const KoafWImg* w, int R, int64_t K) {
     g->B.planes = w->f; g->B.ld = rup32(K); g->B.plane_stride = (int64_t)R * g->B.ld;
 }
 
+// A operand from activation plane images (koaf_act_planes): the transform is in the image
+inline void set_aplanes(KoafOperand* a, const uint16_t* planes, int64_t plane_elems) {
+    a->kind = 2; a->planes = planes; a->plane_stride = plane_elems; a->zeros = planes + 2 * plane_elems;
+    a->ptr = nullptr; a->ptr2 = nullptr; a->tf = 0; a->sc = a->sh = a->sc2 = nullptr;
+}
+
 // split-K plan for weight gradients: M x N output, K = pixels.  ~1024 blocks, >= 512 k-rows per split.
 struct WgradPlan { int bm, bn, splitk; };
 inline WgradPlan wgrad_plan(int M, int N, int64_t K, int ctap, int batch) {
@@ -222,8 +228,8 @@ __global__ void __launch_bounds__(256) gconv_compress_kernel(const float* __rest
 extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W, int32_t Cin,
                                int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, const float* in_sc,
                                const float* in_sh, float* stats, int32_t* stats_rows, const float* stats_shift,
-                               const KoafWImg* wimg, void* stream) {
-    KOAF_REQUIRE(x && w && y && N > 0 && Cin % 32 == 0 && Cout % 4 == 0, "koaf_conv2d_fwd: bad args (Cin=%d Cout=%d)",
+                               const KoafWImg* wimg, const uint16_t* x_planes, void* stream) {
+    KOAF_REQUIRE((x || x_planes) && w && y && N > 0 && Cin % 32 == 0 && Cout % 4 == 0, "koaf_conv2d_fwd: bad args (Cin=%d Cout=%d)",
                  Cin, Cout);
     KOAF_REQUIRE((in_sc == nullptr) == (in_sh == nullptr), "koaf_conv2d_fwd: in_sc/in_sh come together");
     const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
@@ -248,6 +254,10 @@ extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t
     g.B.ld = (int64_t)KH * KW * Cin;
     g.M = (int)M; g.N = Cout; g.K = KH * KW * Cin;
     if (wimg && wimg->amax) set_fimg(&g, wimg, Cout, g.K);
+    if (x_planes) {
+        KOAF_REQUIRE(g.A.gather == 1 && g.B.kind == 2, "koaf_conv2d_fwd: x_planes serve the gathered kernels and need wimg->f");
+        set_aplanes(&g.A, x_planes, (int64_t)N * H * W * Cin);
+    }
     g.C = y; g.ldc = Cout;
     g.stats = stats;
     g.stats_shift = stats ? stats_shift : nullptr;
@@ -290,8 +300,10 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
                                      int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                                      const float* residual, const KoafBnb* bnb, float* part, int32_t* part_rows,
                                      const KoafWImg* wimg, const float* dy_amax, const KoafBnApply* dy_apply,
-                                     void* stream) {
-    KOAF_REQUIRE((dy || dy_apply) && w && dx && N > 0 && Cout % 32 == 0 && Cin % 4 == 0, "koaf_conv2d_dgrad: bad args");
+                                     const uint16_t* dy_planes, void* stream) {
+    KOAF_REQUIRE(!dy_planes || (wimg && wimg->amax && wimg->d && (dy_amax || dy_apply) && KH * KW > 1),
+                 "koaf_conv2d_dgrad: dy_planes need the weight's D plane image, dy_amax and a gathered (KH*KW > 1) kernel");
+    KOAF_REQUIRE((dy || dy_apply || dy_planes) && w && dx && N > 0 && Cout % 32 == 0 && Cin % 4 == 0, "koaf_conv2d_dgrad: bad args");
     KOAF_REQUIRE(!dy_apply || (dy_apply->dz && dy_apply->c && dy_apply->coef && dy_apply->amax && wimg && wimg->amax && wimg->d),
                  "koaf_conv2d_dgrad: dy_apply needs dz / c / coef / amax and the weight's D plane image");
     if (dy_apply) { dy = dy_apply->dz; dy_amax = dy_apply->amax; }
@@ -340,6 +352,7 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
                     g.B.planes = w_dimg + ((int64_t)khs * KW + kws) * Cout; g.B.ld = dld; g.B.plane_stride = dps;
                     g.B.tap_stride = 2ll * Cout; g.B.tap_stride_h = 2ll * KW * Cout;
                 }
+                if (dy_planes && nkh > 0 && nkw > 0) set_aplanes(&g.A, dy_planes, (int64_t)N * OH * OW * Cout);
                 g.M = N * Hc * Wc; g.N = Cin; g.K = nkh * nkw * Cout;
                 g.C = dx; g.ldc = Cin;
                 g.residual = residual; g.ldr = Cin;
@@ -383,6 +396,7 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
         g.B.kind = 2; g.B.gather = 0; g.B.C = 0; g.B.tap_stride = g.B.tap_stride_h = 0;
         g.B.planes = w_dimg; g.B.ld = dld; g.B.plane_stride = dps;
     }
+    if (dy_planes) set_aplanes(&g.A, dy_planes, (int64_t)N * OH * OW * Cout);
     g.M = (int)M; g.N = Cin; g.K = KH * KW * Cout;
     g.C = dx; g.ldc = Cin;
     g.residual = residual; g.ldr = Cin;
@@ -396,9 +410,9 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
 extern "C" int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
                                  int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                                  const float* residual, const KoafWImg* wimg, const float* dy_amax,
-                                 const KoafBnApply* dy_apply, void* stream) {
+                                 const KoafBnApply* dy_apply, const uint16_t* dy_planes, void* stream) {
     return koaf_conv2d_dgrad_bnb(dy, w, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, residual, nullptr, nullptr,
-                                 nullptr, wimg, dy_amax, dy_apply, stream);
+                                 nullptr, wimg, dy_amax, dy_apply, dy_planes, stream);
 }
 
 extern "C" int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH,

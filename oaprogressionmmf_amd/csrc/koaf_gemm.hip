@@ -108,9 +108,17 @@ enum { M_KC = 0,     // K-contiguous rows, dense
        M_KM = 3,     // K-major, dense
        M_KM_G1 = 4,  // K-major, conv gather on the k index (wgrad activations)
        M_KM_G3 = 5,  // K-major, tapped weights (dgrad)
-       M_PS = 6      // pre-split bf16 plane images, K-contiguous rows, optionally tapped (weights: forward and dgrad)
+       M_PS = 6,     // pre-split fp16 plane images, K-contiguous rows, optionally tapped (weights: forward and dgrad)
+       M_PA1 = 7,    // pre-split fp16 plane images of an NHWC activation, conv forward gather (A operand)
+       M_PA2 = 8,    // the same, transposed-conv (dgrad) gather
+       M_PH = 9      // the same images, 3x3 / stride 1 / pad 1: the tile's pixel rows + halo stay in LDS for all nine taps
 };
 __host__ __device__ constexpr bool mode_is_kc(int m) { return m < 3; }
+__host__ __device__ constexpr bool mode_is_pa(int m) { return m == M_PA1 || m == M_PA2; }
+// halo kernel (M_PH): widest image row kept in LDS (BM + 2 W + 2 pixels of 32 channels, two buffers) and the number of
+// weight-tile stages, chosen per column-tile width so that everything fits 160 KiB
+__host__ __device__ constexpr int halo_max_w(int bn) { return bn == 64 ? 96 : 64; }
+__host__ __device__ constexpr int halo_b_stages(int bn) { return bn == 64 ? 4 : 3; }
 
 // TF = transform on load (KoafOperand.tf): 0 none; 1 relu(sc[c] * x + sh[c]) -- the producer's BatchNorm + ReLU; 2 the
 // BatchNorm-BACKWARD apply dc = sc[c] * dz + sh[c] - sc2[c] * c_raw of TWO source tensors (x = dz at ptr, c_raw at ptr2, same
@@ -421,7 +429,7 @@ struct TileLoader {
             const bool ok = VEC ? ((s.vm >> i) & 1u) : ((s.vm >> (4 * i + j)) & 1u);
             float x = s.r[i][j];
             if constexpr (TF == 1) {
-                x = x * a[j] + b[j];
+                x = fmaf(x, a[j], b[j]);
                 x = F16 ? __builtin_amdgcn_fmed3f(x, 0.f, HMAX) : fmaxf(x, 0.f);
             } else if constexpr (TF == 2) {
                 x = fmaf(a[j], x, fmaf(-k[j], s.r2[i < NU2 ? i : 0][j], b[j]));
@@ -487,6 +495,40 @@ __device__ __forceinline__ v4i frag_load(const unsigned* P, int row0, int g, int
     }
 }
 
+// v & m as four opaque v_and_b32 (written in C++, hipcc turns the masked fragment load into a branch around the ds_read --
+// or, with a plain vector AND, fails in instruction selection on this kernel)
+__device__ __forceinline__ v4i and_mask(v4i v, int m) {
+    v4i r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int x;
+        asm("v_and_b32 %0, %1, %2" : "=v"(x) : "v"(v[e]), "v"(m));
+        r[e] = x;
+    }
+    return r;
+}
+
+// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to the 1 KiB at LDS byte address `lds_addr`
+// (wave-uniform), lane-linear.
+// Issued as inline assembly, not through __builtin_amdgcn_global_load_lds: the compiler's wait-count pass treats every
+// LDS read after a builtin LDS-DMA as possibly aliasing it and puts s_waitcnt vmcnt(0) in front of the ds_reads of the k-loop
+// -- which drains the prefetch of the NEXT tiles before the current one is multiplied and was the largest single stall
+// of the DMA kernels.  The kernels order DMA against LDS reads themselves (counted s_waitcnt vmcnt + s_barrier); no
+// compiler-tracked vector memory operation is in flight while these are (the loops hold only DMA, and they drain it
+// before the epilogue).
+// (m0 is a reserved register to clang, which warns that it does not preserve it around the statement: nothing else in
+// these kernels lives in m0 -- gfx9 LDS instructions do not read it and there is no indirect register indexing.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_addr) {
+    const int la = __builtin_amdgcn_readfirstlane((int)lds_addr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(la) : "memory", "m0");
+}
+// LDS byte address of a __shared__ array (taken ONCE, on the array itself, where the cast folds: converting the
+// generic pointers computed later back to LDS addresses left a null check on the aperture register that hipcc could not select)
+#define KOAF_LDS_ADDR(arr) ((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(arr))
+#pragma clang diagnostic pop
+
 // Pre-split operand (M_PS): bf16 plane images [plane][row][K] cut in HBM by koaf_wplanes_build, moved global -> LDS by
 // global_load_lds_dwordx4.  One wave instruction fills 1 KiB = 16 rows x 64 B of one plane; the LDS image is linear
 // (DMA writes land at wave base + 16 * lane), so its 16-B chunks are XOR-swizzled through the SOURCE address: lane l
@@ -517,9 +559,7 @@ struct PlaneLoader {
     }
     // DMA of the k-tile at the running position into the plane images at `lds` (one buffer = NPL * PLANE_BYTES)
     template <int NPL>
-    __device__ __forceinline__ void issue(const KoafOperand& op, const unsigned short* planes, float* lds) {
-        typedef const __attribute__((address_space(1))) void* gptr_t;
-        typedef __attribute__((address_space(3))) void* lptr_t;
+    __device__ __forceinline__ void issue(const KoafOperand& op, const unsigned short* planes, unsigned lds) {
         const int w = threadIdx.x >> 6;
         const int64_t koff = u_kh * op.tap_stride_h + u_kw * op.tap_stride + u_coff;
         u_coff += BK;
@@ -527,13 +567,11 @@ struct PlaneLoader {
             u_coff -= op.C;
             if (++u_kw == op.KW) { u_kw = 0; ++u_kh; }
         }
-        char* base = reinterpret_cast<char*>(lds);
 #pragma unroll
         for (int q = 0; q < NPL; ++q)
 #pragma unroll
             for (int j = 0; j < PPW; ++j)
-                __builtin_amdgcn_global_load_lds((gptr_t)(planes + q * op.plane_stride + src[j] + koff),
-                                                 (lptr_t)(base + q * PLANE_BYTES + (w + 4 * j) * 1024), 16, 0, 0);
+                lds_dma16(planes + q * op.plane_stride + src[j] + koff, lds + q * PLANE_BYTES + (w + 4 * j) * 1024);
     }
 };
 
@@ -543,15 +581,117 @@ __device__ __forceinline__ v4i frag_load_ps(const unsigned* P, int row0, int g, 
     return *(const v4i*)&P[row * 16 + 4 * ((2 * g + (lane >> 5)) ^ ((row >> 2) & 3))];
 }
 
+// Pre-split ACTIVATION operand (M_PA1 / M_PA2): the two fp16 piece planes [plane][pixel][CS] of an NHWC tensor, cut once
+// by koaf_act_planes (BatchNorm + ReLU prologue or BatchNorm-backward apply included), gathered global -> LDS by
+// global_load_lds_dwordx4 exactly like PlaneLoader: a lane moves the 16 B = 8 channels of ONE source pixel, so the im2col
+// gather costs address arithmetic only (once per filter tap) -- no conversion, no split, no VGPR staging in the k-loop,
+// where the fp32 loader redoes the split of every element for each of the KH*KW taps that touch it.  Padding taps and
+// rows past M fetch the image's zero chunk (KoafOperand.zeros).  G = 1: conv forward gather; 2: transposed (dgrad).
+template <int ROWS, int G>
+struct PlaneGatherLoader {
+    static constexpr int NPIECE = ROWS / 16;
+    static constexpr int PPW = NPIECE / 4;
+    static_assert(PPW >= 1 && PPW <= 4, "1..4 pieces per wave");
+    static constexpr int PLANE_BYTES = ROWS * 64;
+    v4l base;          // element offset of the piece row's image + this lane's swizzled chunk
+    v4i iy0, ix0;
+    v4i toff;          // per-image element offset of the current tap's source pixel
+    unsigned rvm, tvm;
+    int u_coff, u_kh, u_kw;
+    bool fresh;
+
+    __device__ __forceinline__ void init(const KoafOperand& op, int r0, int R) {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        base = (v4l){0, 0, 0, 0};
+        iy0 = ix0 = toff = (v4i){0, 0, 0, 0};
+        rvm = tvm = 0;
+        const int ppi = op.PH * op.PW;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int row = r0 + 16 * (w + 4 * j) + (lane >> 2);
+            rvm |= (row < R ? 1u : 0u) << j;
+            const int n = row / ppi;
+            const int rem = row - n * ppi;
+            const int py = rem / op.PW;
+            const int px = rem - py * op.PW;
+            base[j] = (int64_t)n * op.H * op.W * op.CS + 8 * ((lane & 3) ^ ((lane >> 4) & 3));
+            if constexpr (G == 1) {
+                iy0[j] = py * op.stride - op.pad;
+                ix0[j] = px * op.stride - op.pad_w;
+            } else {
+                iy0[j] = py + op.pad;
+                ix0[j] = px + op.pad_w;
+            }
+        }
+        u_coff = u_kh = u_kw = 0;
+        fresh = true;
+    }
+    __device__ __forceinline__ void seek(const KoafOperand& op, int k0) {
+        const int tap = k0 / op.C;
+        u_coff = k0 - tap * op.C;
+        u_kh = tap / op.KW;
+        u_kw = tap - u_kh * op.KW;
+        fresh = true;
+    }
+    __device__ __forceinline__ void issue(const KoafOperand& op, const unsigned short* planes, unsigned lds) {
+        const int w = threadIdx.x >> 6;
+        if (fresh || u_coff == 0) {        // wave-uniform: a new filter tap -> new source pixel / bounds of every piece row
+            fresh = false;
+            tvm = 0;
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                int sy, sx;
+                bool ok = (rvm >> j) & 1u;
+                if constexpr (G == 1) {
+                    sy = iy0[j] + u_kh;
+                    sx = ix0[j] + u_kw;
+                } else {
+                    const int ny = iy0[j] - u_kh, nx = ix0[j] - u_kw;
+                    ok = ok && ny >= 0 && nx >= 0;
+                    if (op.stride == 1) {
+                        sy = ny;
+                        sx = nx;
+                    } else if (op.stride == 2) {
+                        sy = ny >> 1;
+                        sx = nx >> 1;
+                        ok = ok && (((ny | nx) & 1) == 0);
+                    } else {
+                        sy = ny / op.stride;
+                        sx = nx / op.stride;
+                        ok = ok && (sy * op.stride == ny) && (sx * op.stride == nx);
+                    }
+                }
+                ok = ok && (unsigned)sy < (unsigned)op.H && (unsigned)sx < (unsigned)op.W;
+                toff[j] = (sy * op.W + sx) * op.CS;
+                tvm |= (ok ? 1u : 0u) << j;
+            }
+        }
+        const int coff = u_coff;
+        u_coff += BK;
+        if (u_coff >= op.C) {
+            u_coff = 0;
+            if (++u_kw == op.KW) { u_kw = 0; ++u_kh; }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                const bool ok = (tvm >> j) & 1u;
+                const unsigned short* src = ok ? planes + q * op.plane_stride + base[j] + (toff[j] + coff) : op.zeros;
+                lds_dma16(src, lds + q * PLANE_BYTES + (w + 4 * j) * 1024);
+            }
+    }
+};
+
 // Row loop of the vector epilogue for a FULL tile without row map, specialised on what is fused (residual, BatchNorm-
 // backward mode, second BatchNorm) so that it is branch-free: the loads of four rows go out together before the first
 // is consumed (the generic loop below tests every row and ends up with one load in flight at a time, which held the
 // HBM-bound 1x1-dgrad epilogues at 2-3 TB/s).
-template <int BM, int BN, bool HAS_R, int MODE, bool HAS_C2>
+template <int BM, int BN, int NT, bool HAS_R, int MODE, bool HAS_C2>
 __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs, int ldcs, float* Cp, int64_t ldc,
                                               const float* Rp, int m0, int col, int c4, int rr, v4f bv, v4f mu, v4f is,
                                               v4f ms, v4f mh, v4f mu2, v4f is2, v4f& q1, v4f& q2, v4f& q3, v4f& qm) {
-    constexpr int C4 = BN / 4, RPP = 256 / C4, U = 4;
+    constexpr int C4 = BN / 4, RPP = NT / C4, U = 4;
     static_assert((BM / RPP) % U == 0, "rows per thread must be a multiple of the batch");
 #pragma unroll 1
     for (int row = rr; row < BM; row += RPP * U) {
@@ -590,19 +730,24 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
 
 
 // F16 = KoafGemm.fmt == 1 (two fp16 planes per operand, three products); else three bf16 planes, six products
-template <int BM, int BN, int AM, int BMD, int TFA, int TFB, bool VEC, bool F16>
-__global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
+// NT = threads per block: 256 (waves 2 x 2) or 512 (waves 4 x 2: the 256-row tiles of the halo kernel)
+template <int BM, int BN, int AM, int BMD, int TFA, int TFB, bool VEC, bool F16, int NT = 256>
+__global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
     static_assert((TFA != 2 && TFB != 2) || VEC, "the two-source prologue needs the vector path");
     constexpr int NPL = F16 ? 2 : 3;
     static_assert(BMD != M_PS || F16, "plane images are fp16");
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr bool AKC = mode_is_kc(AM), BKC = mode_is_kc(BMD), BPS = (BMD == M_PS);
-    constexpr int A_PL = plane_dwords(BM, AKC), B_PL = BPS ? BN * 16 : plane_dwords(BN, BKC);
+    constexpr int NW = NT / 64, WGM = NW / 2;                        // waves: WGM along M x 2 along N
+    constexpr int WM = BM / WGM, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr bool AKC = mode_is_kc(AM), BKC = mode_is_kc(BMD), BPS = (BMD == M_PS), APS = mode_is_pa(AM), AH = (AM == M_PH);
+    static_assert(!(APS || AH) || (BPS && TFA == 0), "a pre-split A pairs with a pre-split B and carries its transform in the image");
+    static_assert(NT == 256 || AH, "only the halo kernel runs 512 threads (the fp32 loaders are laid out for 256)");
+    constexpr int HP_MAX = (BM + 2 * halo_max_w(BN) + 2 + 15) / 16;  // 16-pixel (1 KiB) pieces of a halo plane
+    constexpr int A_PL = AH ? HP_MAX * 256 : (APS ? BM * 16 : plane_dwords(BM, AKC)), B_PL = BPS ? BN * 16 : plane_dwords(BN, BKC);
     constexpr int A_ELEMS = NPL * A_PL, B_ELEMS = NPL * B_PL;
-    constexpr int NBB = BPS ? 2 : 1;                                 // LDS buffers of the B operand (DMA target: two)
+    constexpr int NBA = (APS || AH) ? 2 : 1, NBB = AH ? halo_b_stages(BN) : (BPS ? 2 : 1);   // LDS buffers per operand
     constexpr int LDC_S = BN + 4;                                    // epilogue staging row (floats)
     constexpr int C_ELEMS = VEC ? BM * LDC_S : 0;
-    constexpr int OPS = A_ELEMS + NBB * B_ELEMS;
+    constexpr int OPS = NBA * A_ELEMS + NBB * B_ELEMS;
     constexpr int SMEM = (OPS > C_ELEMS) ? OPS : C_ELEMS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
@@ -629,17 +774,26 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     const float scb = F16 ? operand_scale(p.B) : 1.f;
     const float alpha = F16 ? p.alpha / (sca * scb) : p.alpha;
 
-    const float* Ap = p.A.ptr + z0 * p.A.bs0 + z1 * p.A.bs1;
+    const float* Ap = (APS || AH) ? nullptr : p.A.ptr + z0 * p.A.bs0 + z1 * p.A.bs1;
+    const unsigned short* Apl = (APS || AH) ? p.A.planes + z0 * p.A.bs0 + z1 * p.A.bs1 : nullptr;
     const float* Bp = BPS ? nullptr : p.B.ptr + z0 * p.B.bs0 + z1 * p.B.bs1;
     const unsigned short* Bpl = BPS ? p.B.planes + z0 * p.B.bs0 + z1 * p.B.bs1 : nullptr;
 
-    TileLoader<BM, AM, TFA, VEC, F16> la;
-    // (the unused one of the two B loaders is dead code to the compiler)
+    // (the unused ones of the loaders are dead code to the compiler)
+    TileLoader<(APS || AH) ? 128 : BM, (APS || AH) ? M_KC : AM, TFA, VEC, F16> la;
     TileLoader<BN, BPS ? M_KC : BMD, TFB, VEC, F16> lb;
     PlaneLoader<BN> lp;
-    la.init(p.A, m0, p.M, z1, sca);
-    la.seek(p.A, kbeg);
-    if constexpr (BPS) {
+    PlaneGatherLoader<AH ? 128 : BM, AM == M_PA2 ? 2 : 1> lpa;
+    if constexpr (APS) {
+        lpa.init(p.A, m0, p.M);
+        lpa.seek(p.A, kbeg);
+    } else if constexpr (!AH) {
+        la.init(p.A, m0, p.M, z1, sca);
+        la.seek(p.A, kbeg);
+    }
+    if constexpr (AH) {
+        // (the halo loop below addresses both operands itself)
+    } else if constexpr (BPS) {
         lp.init(p.B, n0, p.N);
         lp.seek(p.B, kbeg);
     } else {
@@ -660,40 +814,20 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     const int wm = w >> 1, wn = w & 1;
     const int r = lane & 31, h = lane >> 5;
 
-    float* const Bs0 = smem + A_ELEMS;
-    if (kbeg < kend) {
-        if constexpr (BPS) lp.template issue<NPL>(p.B, Bpl, Bs0);
-        la.issue(la.sa, p.A, Ap, kbeg, kend, z1);
-        if constexpr (!BPS) lb.issue(lb.sa, p.B, Bp, kbeg, kend, z1);
-        la.finish(la.sa);
-        la.template store<NPL>(la.sa, smem);
-        if constexpr (!BPS) {
-            lb.finish(lb.sa);
-            lb.template store<NPL>(lb.sa, Bs0);
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
-        }
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const bool more = (k0 + BK) < kend;
-        const unsigned* Au = (const unsigned*)smem;
-        const unsigned* Bu = (const unsigned*)(Bs0 + cur * B_ELEMS);
-        // the next tile's global loads go out first: in flight under this tile's MFMAs (the DMA into the other B buffer,
-        // which every wave stopped reading at the last barrier)
-        if (more) {
-            if constexpr (BPS) lp.template issue<NPL>(p.B, Bpl, Bs0 + (cur ^ 1) * B_ELEMS);
-            la.issue(la.sa, p.A, Ap, k0 + BK, kend, z1);
-            if constexpr (!BPS) lb.issue(lb.sa, p.B, Bp, k0 + BK, kend, z1);
-        }
+    float* const Bs0 = smem + NBA * A_ELEMS;
+    const unsigned sm0 = KOAF_LDS_ADDR(smem), sb0 = sm0 + NBA * A_ELEMS * 4;     // LDS byte addresses of the A / B buffers
+    // the MFMAs of one k-tile whose plane images sit at Au / Bu
+    auto mma = [&](const unsigned* Au, const unsigned* Bu) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             v4i ap[TM][NPL], bp[NPL];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int q = 0; q < NPL; ++q) ap[i][q] = frag_load<BM, AKC>(Au + q * A_PL, wm * WM + 32 * i, g, lane);
+                for (int q = 0; q < NPL; ++q) {
+                    if constexpr (APS) ap[i][q] = frag_load_ps(Au + q * A_PL, wm * WM + 32 * i, g, lane);
+                    else ap[i][q] = frag_load<BM, AKC>(Au + q * A_PL, wm * WM + 32 * i, g, lane);
+                }
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) {
 #pragma unroll
@@ -702,11 +836,11 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
                     else bp[q] = frag_load<BN, BKC>(Bu + q * B_PL, wn * WN + 32 * jn, g, lane);
                 }
                 // piece products, smallest first.  bf16: the six of weight >= 2^-16.  fp16: lo*hi, hi*lo, hi*hi.
-                constexpr int NT = F16 ? 3 : 6;
+                constexpr int NTERM = F16 ? 3 : 6;
                 constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
                 constexpr int PAH[3] = {1, 0, 0}, PBH[3] = {0, 1, 0};
 #pragma unroll
-                for (int term = 0; term < NT; ++term) {
+                for (int term = 0; term < NTERM; ++term) {
                     const int pa = F16 ? PAH[term] : PA3[term];
                     const int pb = F16 ? PBH[term] : PB3[term];
 #pragma unroll
@@ -723,6 +857,186 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
                 }
             }
         }
+    };
+    if constexpr (AH) {
+        // 3x3 / stride 1 / pad 1 over activation plane images, both operands by LDS-DMA.  The tile's BM output pixels are
+        // consecutive in raster order, so the source pixels of ALL nine taps lie in the contiguous range
+        // [m0 - W - 1, m0 + BM + W + 1): that halo (32 channels of it) is fetched ONCE per channel chunk and tap (dy, dx)
+        // is the same LDS image read W*dy + dx pixels further on -- the input tile travels L2 -> LDS 1.8 times instead of
+        // nine.  Taps that fall off the image (the raster neighbour is then another row or image) are zeroed in the
+        // fragment registers by per-row validity bits.  k runs (chunk, tap, channel); the weight tile of every (chunk, tap)
+        // step is double-buffered as in the loops above, the next chunk's halo arrives in ninths under the nine tap steps.
+        static_assert(2 * HP_MAX <= 9 * NW, "the next halo is spread over the nine tap steps, one piece per wave and step");
+        constexpr int NPB = BN / 16;                        // 1-KiB pieces of a weight plane tile
+        constexpr int BPW = (2 * NPB + NW - 1) / NW;        // weight pieces per wave and step
+        const int Wd = p.A.W, Hd = p.A.H, CSa = p.A.CS, Ca = p.A.C;
+        const bool flip = p.A.gather == 2;
+        const int np2 = 2 * ((BM + 2 * Wd + 2 + 15) >> 4);  // halo pieces per chunk (two planes)
+        const int64_t hbase = (int64_t)m0 - Wd - 1, plast = (int64_t)p.M - 1;
+        const int nchunk = Ca / 32;
+        const int swz = 8 * ((lane & 3) ^ ((lane >> 4) & 3));
+        // validity bits of the nine taps (bit kh*3+kw) and halo pixel of the centre tap for this lane's row of each M tile
+        unsigned vb[TM];
+        int i0[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int lrow = wm * WM + 32 * i + r, row = m0 + lrow;
+            i0[i] = lrow + Wd + 1;
+            vb[i] = 0;
+            if (row < p.M) {
+                const int rem = row % (Hd * Wd), y = rem / Wd, x = rem - y * Wd;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int dy = flip ? 1 - tp / 3 : tp / 3 - 1, dx = flip ? 1 - tp % 3 : tp % 3 - 1;
+                    const bool ok = (unsigned)(y + dy) < (unsigned)Hd && (unsigned)(x + dx) < (unsigned)Wd;
+                    vb[i] |= (ok ? 1u : 0u) << tp;
+                }
+            }
+        }
+        int64_t bsrc[BPW];
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            const int idx = w + NW * j, piece = idx % NPB;
+            const int row = min(n0 + 16 * piece + (lane >> 2), p.N - 1);     // (rows past N: finite values, never stored)
+            bsrc[j] = (int64_t)(idx / NPB) * p.B.plane_stride + (int64_t)row * p.B.ld + swz;
+        }
+        auto issue_halo = [&](int idx, int chunk, unsigned buf) {
+            const int piece = idx >> 1, q = idx & 1;
+            int64_t gp = hbase + 16 * piece + (lane >> 2);
+            gp = gp < 0 ? 0 : (gp > plast ? plast : gp);       // (pixels off the tensor are never valid taps)
+            const unsigned short* src = Apl + q * p.A.plane_stride + gp * CSa + (chunk * 32 + swz);
+            lds_dma16(src, buf + q * (A_PL * 4) + piece * 1024);
+        };
+        auto issue_b = [&](int tap, int chunk, unsigned buf) {
+            const int koff = tap * Ca + chunk * 32;
+#pragma unroll
+            for (int j = 0; j < BPW; ++j) {
+                const int idx = w + NW * j;
+                if (idx < 2 * NPB)
+                    lds_dma16(Bpl + bsrc[j] + koff, buf + (idx / NPB) * (B_PL * 4) + (idx % NPB) * 1024);
+            }
+        };
+        // Pipeline: the weight tile of step s + D (D = NBB - 1 steps ahead) and one halo piece of the NEXT chunk are issued
+        // at step s; loads retire in order, so "the tile of step s has landed" is a counted wait that leaves the younger
+        // loads in flight.  Only the first tap of a chunk drains everything (its halo was completed by the previous step).
+        constexpr int D = NBB - 1;
+        auto step_of = [&](int sidx, int& tp, int& ch) { ch = sidx / 9; tp = sidx - 9 * ch; };
+        const int nstep = 9 * nchunk;
+        for (int idx = w; idx < np2; idx += NW) issue_halo(idx, 0, sm0);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < nstep) { int tp, ch; step_of(d, tp, ch); issue_b(tp, ch, sb0 + d * (B_ELEMS * 4)); }
+        int sb = 0;                 // stage holding the current step's weight tile
+        int ntap = D % 9, nch = D / 9;     // (tap, chunk) of step s + D
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            // (LDS pointers typed as such: left generic, hipcc could not always prove the address space of these reads)
+            typedef const __attribute__((address_space(3))) v4i* lds_v4i;
+            typedef const __attribute__((address_space(3))) unsigned* lds_u;
+            const lds_u Ah = (lds_u)smem + (chunk & 1) * A_ELEMS;
+            const unsigned Anext = sm0 + ((chunk + 1) & 1) * (A_ELEMS * 4);
+            const bool more_chunks = chunk + 1 < nchunk;
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                // in flight behind this step's tile: D - 1 younger tiles (BPW loads each) and, inside a chunk, D halo pieces
+                if (tap == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (more_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * BPW + (D < 9 ? D : 9)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * BPW) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                {
+                    int sd = sb + D;
+                    if (sd >= NBB) sd -= NBB;
+                    // (past the last step: re-fetch the last tile into a stage nobody reads, which keeps the counts uniform)
+                    issue_b(nch < nchunk ? ntap : 8, nch < nchunk ? nch : nchunk - 1, sb0 + sd * (B_ELEMS * 4));
+                    if (++ntap == 9) { ntap = 0; ++nch; }
+                }
+                if (more_chunks) {
+                    const int idx = tap * NW + w;
+                    issue_halo(idx < np2 ? idx : np2 - 1, chunk + 1, Anext);    // (surplus slots repeat the last piece)
+                }
+                const int kh = tap / 3, kw = tap - 3 * kh;
+                const int shift = flip ? (1 - kh) * Wd + (1 - kw) : (kh - 1) * Wd + (kw - 1);
+                const lds_u Bu = (lds_u)smem + NBA * A_ELEMS + sb * B_ELEMS;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    v4i ap[TM][2], bp[2];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int hp = i0[i] + shift;
+                        const int okm = -(int)((vb[i] >> tap) & 1u);       // all ones / zero: the tap's validity as an AND mask
+                        const int off = hp * 16 + 4 * ((2 * g + h) ^ ((hp >> 2) & 3));
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const v4i v = *(lds_v4i)&Ah[q * A_PL + off];
+                            ap[i][q] = and_mask(v, okm);
+                        }
+                    }
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int brow = wn * WN + 32 * jn + (lane & 31);
+                            bp[q] = *(lds_v4i)&Bu[q * B_PL + brow * 16 + 4 * ((2 * g + h) ^ ((brow >> 2) & 3))];   // = frag_load_ps
+                        }
+                        constexpr int PAH[3] = {1, 0, 0}, PBH[3] = {0, 1, 0};
+#pragma unroll
+                        for (int term = 0; term < 3; ++term)
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+                                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ap[i][PAH[term]]),
+                                                                                    __builtin_bit_cast(h16x8, bp[PBH[term]]),
+                                                                                    acc[i][jn], 0, 0, 0);
+                    }
+                }
+                if (++sb == NBB) sb = 0;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the surplus fetches behind the last step)
+        __syncthreads();       // the epilogue reuses the operand buffers
+    } else if constexpr (APS) {
+        // both operands by LDS-DMA, double-buffered: one barrier per k-tile.  At the top of iteration t every wave waits for
+        // its own pieces of tile t (issued one iteration ago, under the MFMAs of tile t-1) and meets the others: tile t is
+        // complete and nobody still reads the buffers of tile t-1, which the DMA of tile t+1 now overwrites.
+        if (kbeg < kend) {
+            lpa.issue(p.A, Apl, sm0);
+            lp.template issue<NPL>(p.B, Bpl, sb0);
+        }
+        int cur = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if ((k0 + BK) < kend) {
+                lpa.issue(p.A, Apl, sm0 + (cur ^ 1) * (A_ELEMS * 4));
+                lp.template issue<NPL>(p.B, Bpl, sb0 + (cur ^ 1) * (B_ELEMS * 4));
+            }
+            mma((const unsigned*)(smem + cur * A_ELEMS), (const unsigned*)(Bs0 + cur * B_ELEMS));
+            cur ^= 1;
+        }
+        __syncthreads();       // the epilogue reuses the operand buffers
+    } else {
+    if (kbeg < kend) {
+        if constexpr (BPS) lp.template issue<NPL>(p.B, Bpl, sb0);
+        la.issue(la.sa, p.A, Ap, kbeg, kend, z1);
+        if constexpr (!BPS) lb.issue(lb.sa, p.B, Bp, kbeg, kend, z1);
+        la.finish(la.sa);
+        la.template store<NPL>(la.sa, smem);
+        if constexpr (!BPS) {
+            lb.finish(lb.sa);
+            lb.template store<NPL>(lb.sa, Bs0);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = (k0 + BK) < kend;
+        // the next tile's global loads go out first: in flight under this tile's MFMAs (the DMA into the other B buffer,
+        // which every wave stopped reading at the last barrier)
+        if (more) {
+            if constexpr (BPS) lp.template issue<NPL>(p.B, Bpl, sb0 + (cur ^ 1) * (B_ELEMS * 4));
+            la.issue(la.sa, p.A, Ap, k0 + BK, kend, z1);
+            if constexpr (!BPS) lb.issue(lb.sa, p.B, Bp, k0 + BK, kend, z1);
+        }
+        mma((const unsigned*)smem, (const unsigned*)(Bs0 + cur * B_ELEMS));
         // every wave is done reading the A image (and this B buffer).  With LDS-DMA in flight __syncthreads() would
         // drain vmcnt here, in the middle of the MFMA stream: a raw barrier behind the LDS-read wait keeps the next
         // tile's loads in flight until finish() needs them.
@@ -740,6 +1054,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
             }
             __syncthreads();
         }
+    }
     }
 
     // ---- epilogue ----
@@ -783,7 +1098,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
                 }
         __syncthreads();
         constexpr int C4 = BN / 4;
-        constexpr int RPP = 256 / C4;          // rows per pass
+        constexpr int RPP = NT / C4;           // rows per pass
         const int c4 = t % C4, rr = t / C4;
         const int col = n0 + 4 * c4;
         const bool bnb = (p.bnb_mode != 0) && !slab;
@@ -803,7 +1118,7 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
             if (full) {
                 const bool hr = Rp != nullptr, h2 = bnb && p.bnb2_c != nullptr;
                 const int mode = bnb ? p.bnb_mode : 0;
-#define KOAF_EPI(R_, M_, C2_) epi_rows_full<BM, BN, R_, M_, C2_>(p, Cs, LDC_S, Cp, ldc, Rp, m0, col, c4, rr, bv, mu, is, \
+#define KOAF_EPI(R_, M_, C2_) epi_rows_full<BM, BN, NT, R_, M_, C2_>(p, Cs, LDC_S, Cp, ldc, Rp, m0, col, c4, rr, bv, mu, is, \
                                                                  ms, mh, mu2, is2, q1, q2, q3, qm)
                 if (mode == 0) { if (hr) KOAF_EPI(true, 0, false); else KOAF_EPI(false, 0, false); }
                 else if (mode == 1) {
@@ -894,8 +1209,8 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
     }
     }
     if (do_stats) {
-        // column sums over this block's BM rows: lanes (r,0)+(r,1), then the two M-waves via LDS
-        float* red = smem;  // [2 wm][2][BN]
+        // column sums over this block's BM rows: lanes (r,0)+(r,1), then the WGM M-waves via LDS
+        float* red = smem;  // [WGM][2][BN]
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
             float a1 = s1[jn] + __shfl_xor(s1[jn], 32, 64);
@@ -908,7 +1223,9 @@ __global__ void __launch_bounds__(256) koaf_gemm_kernel(const KoafGemm p) {
         __syncthreads();
         if (t < BN && (n0 + t) < p.N) {
             float* st = p.stats + (int64_t)(p.part_row0 + tm) * 2 * p.stats_ld + (int64_t)blockIdx.z * p.stats_bs;
-            float a1 = red[0 * BN + t] + red[2 * BN + t], a2 = red[1 * BN + t] + red[3 * BN + t];
+            float a1 = red[0 * BN + t], a2 = red[1 * BN + t];
+#pragma unroll
+            for (int m = 1; m < WGM; ++m) { a1 += red[(2 * m) * BN + t]; a2 += red[(2 * m + 1) * BN + t]; }
             if (p.stats_shift) {
                 // rows of the tile past M were accumulated as zeros: each put (0 - k) and k^2 into the shifted sums
                 const float k = p.stats_shift[(int64_t)blockIdx.z * p.stats_bs + n0 + t];
@@ -964,6 +1281,11 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 bool operand_vec_ok(const KoafOperand& o, int R, int K) {
+    if (o.kind == 2 && o.gather) {
+        // activation plane images: 16-B chunks of 8 channels, k-tiles never straddle a tap
+        return aligned16(o.planes) && aligned16(o.zeros) && o.zeros && !(o.plane_stride & 7) && !(o.bs0 & 7) && !(o.bs1 & 7) &&
+               o.C > 0 && !(o.C & 31) && !(o.CS & 7) && o.KW > 0 && (K % BK) == 0;
+    }
     if (o.kind == 2) {
         // pre-split plane images: rows and taps start on 16-B boundaries, k-tiles never straddle a tap
         if (!aligned16(o.planes) || (o.ld & 7) || (o.plane_stride & 7) || (o.bs0 & 7) || (o.bs1 & 7)) return false;
@@ -986,7 +1308,7 @@ bool operand_vec_ok(const KoafOperand& o, int R, int K) {
 }
 
 int operand_mode(const KoafOperand& o) {
-    if (o.kind == 2) return M_PS;
+    if (o.kind == 2) return o.gather == 0 ? M_PS : (o.gather == 1 ? M_PA1 : M_PA2);
     if (o.kind == 0) return o.gather == 0 ? M_KC : (o.gather == 1 ? M_KC_G1 : M_KC_G2);
     return o.gather == 0 ? M_KM : (o.gather == 1 ? M_KM_G1 : M_KM_G3);
 }
@@ -1014,6 +1336,8 @@ int launch_modes(const KoafGemm& g, dim3 grid, hipStream_t s) {
             }
             if (am == M_KC_G1 && bm == M_PS && ta != 2) { if (ta) { KOAF_LAUNCH(M_KC_G1, M_PS, 1, 0); } else { KOAF_LAUNCH(M_KC_G1, M_PS, 0, 0); } }
             if (am == M_KC_G2 && bm == M_PS && ta != 1) { if (ta) { KOAF_LAUNCH(M_KC_G2, M_PS, 2, 0); } else { KOAF_LAUNCH(M_KC_G2, M_PS, 0, 0); } }
+            if (am == M_PA1 && bm == M_PS) { KOAF_LAUNCH(M_PA1, M_PS, 0, 0); }
+            if (am == M_PA2 && bm == M_PS) { KOAF_LAUNCH(M_PA2, M_PS, 0, 0); }
             // weight gradient with the BatchNorm-backward apply formed in the A loader (dy = sc * dz + sh - sc2 * c)
             if (am == M_KM && bm == M_KM && ta == 2) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM, 2, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM, 2, 0); } }
             if (am == M_KM && bm == M_KM_G1 && ta == 2) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM_G1, 2, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM_G1, 2, 0); } }
@@ -1049,7 +1373,17 @@ extern "C" int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn) 
 }
 
 namespace {
-struct TilePlan { int bm, bn; bool vec; int part_rows; };
+struct TilePlan { int bm, bn; bool vec; int part_rows; bool halo; };
+
+bool g_halo_on = true;      // koaf_set_conv3x3_halo
+
+// 3x3 / stride 1 / pad 1 over activation plane images with the whole pixel range as rows: the halo kernel (M_PH)
+bool halo_ok(const KoafGemm& g) {
+    const KoafOperand& a = g.A;
+    return g_halo_on && a.kind == 2 && (a.gather == 1 || a.gather == 2) && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 &&
+           a.pad_w == 1 && a.PH == a.H && a.PW == a.W && a.W <= halo_max_w(g.N >= 128 ? 128 : 64) && a.H * a.W > 0 && (g.M % (a.H * a.W)) == 0 &&
+           g.nb0 * g.nb1 == 1 && g.m_base == 0 && g.K == 9 * a.C && g.B.kind == 2 && g.fmt == 1 && !g.cmap && g.splitk == 1;
+}
 
 bool gemm_vec_ok(const KoafGemm& g) {
     bool vec = operand_vec_ok(g.A, g.M, g.K) && operand_vec_ok(g.B, g.N, g.K);
@@ -1067,6 +1401,8 @@ TilePlan plan_tiles(const KoafGemm& g) {
     koaf_gemm_pick_tile(&q, &t.bm, &t.bn);
     t.vec = gemm_vec_ok(g);
     if (!t.vec) { t.bm = 64; t.bn = 64; }
+    t.halo = t.vec && halo_ok(g);
+    if (t.halo) { t.bm = 256; t.bn = g.N >= 128 ? 128 : 64; }
     t.part_rows = (int)cdiv64(g.M - g.m_base, t.bm);
     return t;
 }
@@ -1092,7 +1428,8 @@ extern "C" int koaf_gemm_part_rows(const KoafGemm* gp) {
 extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     KoafGemm g = *gp;
     KOAF_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0, "koaf_gemm: bad dims M=%d N=%d K=%d", g.M, g.N, g.K);
-    KOAF_REQUIRE(g.A.ptr && (g.B.kind == 2 ? (const void*)g.B.planes : (const void*)g.B.ptr) && g.C, "koaf_gemm: null operand");
+    KOAF_REQUIRE((g.A.kind == 2 ? (const void*)g.A.planes : (const void*)g.A.ptr) &&
+                 (g.B.kind == 2 ? (const void*)g.B.planes : (const void*)g.B.ptr) && g.C, "koaf_gemm: null operand");
     fill_defaults(g);
     KOAF_REQUIRE(!g.cmap || (g.splitk == 1 && !g.stats), "koaf_gemm: row map excludes split-K / stats");
     KOAF_REQUIRE(!g.bnb_mode || (g.splitk == 1 && !g.stats && g.nb0 * g.nb1 == 1 && g.bnb_c && g.bnb_mean &&
@@ -1102,7 +1439,11 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     KOAF_REQUIRE(g.splitk == 1 || (!g.bias && !g.residual && !g.stats),
                  "koaf_gemm: split-K writes raw slabs (no epilogue)");
     KOAF_REQUIRE((int64_t)g.nb0 * g.nb1 <= 65535 && g.splitk <= 65535, "koaf_gemm: batch/splitk too large");
-    KOAF_REQUIRE(g.A.kind == 0 || (g.A.kind == 1 && g.A.gather == 0), "koaf_gemm: A is K-contiguous fp32, or K-major without gather");
+    KOAF_REQUIRE(g.A.kind == 0 || (g.A.kind == 1 && g.A.gather == 0) || g.A.kind == 2,
+                 "koaf_gemm: A is K-contiguous fp32, K-major without gather, or gathered activation plane images");
+    if (g.A.kind == 2)
+        KOAF_REQUIRE((g.A.gather == 1 || g.A.gather == 2) && g.B.kind == 2 && g.fmt == 1 && !g.A.tf && g.splitk == 1 && g.A.zeros,
+                     "koaf_gemm: activation plane images (A.kind 2) need gather 1|2, a pre-split B, fmt 1, no transform, no split-K");
     KOAF_REQUIRE(!(g.A.kind == 0 && g.A.gather == 3) && !(g.B.kind == 0 && g.B.gather == 3),
                  "koaf_gemm: tapped gather needs a K-major operand");
     KOAF_REQUIRE(!(g.B.kind == 0 && g.B.gather), "koaf_gemm: K-contiguous B cannot be gathered");
@@ -1112,13 +1453,13 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
                  "koaf_gemm: the two-source prologue needs ptr2 / sc / sh / sc2 and the fp16 scheme");
     if (g.B.kind == 2) {
         KOAF_REQUIRE(g.fmt == 1 && g.B.amax, "koaf_gemm: plane images are fp16 pieces of B * scale(*B.amax): fmt 1, amax required");
-        KOAF_REQUIRE(g.A.kind == 0 && !g.B.tf, "koaf_gemm: a pre-split B pairs with a K-contiguous A and takes no transform");
+        KOAF_REQUIRE((g.A.kind == 0 || g.A.kind == 2) && !g.B.tf, "koaf_gemm: a pre-split B pairs with a K-contiguous A and takes no transform");
     }
     const TilePlan tp = plan_tiles(g);
     const bool vec = tp.vec;
-    KOAF_REQUIRE((tp.bm == 64 || tp.bm == 128) && (tp.bn == 64 || tp.bn == 128), "koaf_gemm: tile must be 64|128");
+    KOAF_REQUIRE(((tp.bm == 64 || tp.bm == 128) && (tp.bn == 64 || tp.bn == 128)) || tp.halo, "koaf_gemm: tile must be 64|128");
     if (g.A.gather || g.B.gather) KOAF_REQUIRE(vec, "koaf_gemm: gathered operands need aligned, C%%32==0 tensors");
-    if (g.B.kind == 2) KOAF_REQUIRE(vec, "koaf_gemm: pre-split B needs 16-B aligned operands (and C %% 32 == 0 per tap)");
+    if (g.B.kind == 2 || g.A.kind == 2) KOAF_REQUIRE(vec, "koaf_gemm: pre-split operands need 16-B aligned images (and C %% 32 == 0 per tap)");
     if (g.B.kind == 1 && g.B.gather == 1)
         KOAF_REQUIRE(g.B.C % 4 == 0, "koaf_gemm: gathered K-major operand needs channels per tap (%d) %% 4 == 0", g.B.C);
     KOAF_REQUIRE(!g.cmap || vec, "koaf_gemm: row map needs the vector epilogue");
@@ -1130,6 +1471,11 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     if (tiles <= 0) return KOAF_OK;
     if (tiles >= (1ll << 31)) { koaf_set_error("koaf_gemm: grid too large"); return KOAF_EINVAL; }
     dim3 grid((unsigned)tiles, (unsigned)g.splitk, (unsigned)(g.nb0 * g.nb1));
+    if (tp.halo) {
+        if (tp.bn == 128) hipLaunchKernelGGL((koaf_gemm_kernel<256, 128, M_PH, M_PS, 0, 0, true, true, 512>), grid, dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((koaf_gemm_kernel<256, 64, M_PH, M_PS, 0, 0, true, true, 512>), grid, dim3(512), 0, s, g);
+        return koaf_check_launch("koaf_gemm/halo");
+    }
     if (g.fmt == 1) {
         KOAF_REQUIRE(vec, "koaf_gemm: the fp16 scheme needs the vector path (16-B aligned operands, K %% 4 == 0, N %% 4 == 0)");
         if (tp.bm == 128 && tp.bn == 128) return launch_modes<128, 128, true, true>(g, grid, s);
@@ -1286,4 +1632,74 @@ extern "C" int koaf_wplanes_build(const float* base, uint16_t* planes, float* am
     if (rc != KOAF_OK) return rc;
     hipLaunchKernelGGL(wplanes_build_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, base, planes, table_dev, n, amax);
     return koaf_check_launch("koaf_wplanes_build");
+}
+
+
+// ================================================================================================
+// activation plane images (the M_PA operand): the fp16 piece planes of an NHWC tensor, transform included
+// ================================================================================================
+namespace {
+// TF as in TileLoader (0 none, 1 relu(sc*x+sh), 2 sc*x + sh - sc2*x2); the arithmetic is finish_unit()'s + split2h, so the
+// images hold bit for bit what the fp32 loader of the same operand puts into LDS.
+template <int TF>
+__global__ void __launch_bounds__(256) act_planes_kernel(const float* __restrict__ x, const float* __restrict__ x2, int64_t n8,
+                                                         int C, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                         const float* __restrict__ sc2, const float* __restrict__ amax,
+                                                         float fscale, unsigned short* __restrict__ planes, int64_t ps) {
+    constexpr float HMAX = 65504.f;
+    const float fsc = amax ? scale_of_amax(*amax) : (fscale != 0.f ? fscale : 1.f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *(uint4*)(planes + 2 * ps) = make_uint4(0u, 0u, 0u, 0u);   // the zero chunk
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i * 8) % C);
+        unsigned pl[2][2][2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            v4f v = *(const v4f*)(x + i * 8 + 4 * hf);
+            if constexpr (TF == 1) {
+                const v4f a = *(const v4f*)(sc + c + 4 * hf) * fsc, b = *(const v4f*)(sh + c + 4 * hf) * fsc;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(fmaf(v[j], a[j], b[j]), 0.f, HMAX);
+            } else if constexpr (TF == 2) {
+                const v4f a = *(const v4f*)(sc + c + 4 * hf) * fsc, b = *(const v4f*)(sh + c + 4 * hf) * fsc;
+                const v4f k = *(const v4f*)(sc2 + c + 4 * hf) * fsc;
+                const v4f w = *(const v4f*)(x2 + i * 8 + 4 * hf);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(fmaf(a[j], v[j], fmaf(-k[j], w[j], b[j])), -HMAX, HMAX);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j] * fsc, -HMAX, HMAX);
+            }
+            split2h(v, pl[hf]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            *(uint4*)(planes + q * ps + i * 8) = make_uint4(pl[0][q][0], pl[0][q][1], pl[1][q][0], pl[1][q][1]);
+    }
+}
+}  // namespace
+
+extern "C" int64_t koaf_act_planes_elems(int64_t npix, int32_t C) { return 2 * npix * C + 8; }
+
+extern "C" int koaf_act_planes(const float* x, const float* x2, int64_t npix, int32_t C, int32_t tf, const float* sc,
+                               const float* sh, const float* sc2, const float* amax, float fscale, uint16_t* planes,
+                               void* stream) {
+    KOAF_REQUIRE(x && planes && npix > 0 && C > 0 && (C & 7) == 0 && tf >= 0 && tf <= 2, "koaf_act_planes: bad args (C %% 8 == 0)");
+    KOAF_REQUIRE(tf == 0 || (sc && sh), "koaf_act_planes: tf needs sc / sh");
+    KOAF_REQUIRE(tf != 2 || (x2 && sc2), "koaf_act_planes: tf 2 needs x2 / sc2");
+    KOAF_REQUIRE(aligned16(x) && aligned16(planes) && (tf != 2 || aligned16(x2)) && (tf == 0 || (aligned16(sc) && aligned16(sh))),
+                 "koaf_act_planes: unaligned");
+    const int64_t ps = npix * C, n8 = ps / 8;
+    int64_t blocks = cdiv64(n8, 256);
+    if (blocks > 16384) blocks = 16384;
+    hipStream_t s = (hipStream_t)stream;
+    if (tf == 0) hipLaunchKernelGGL(act_planes_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, x, x2, n8, C, sc, sh, sc2, amax, fscale, planes, ps);
+    else if (tf == 1) hipLaunchKernelGGL(act_planes_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, x, x2, n8, C, sc, sh, sc2, amax, fscale, planes, ps);
+    else hipLaunchKernelGGL(act_planes_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, x, x2, n8, C, sc, sh, sc2, amax, fscale, planes, ps);
+    return koaf_check_launch("koaf_act_planes");
+}
+
+extern "C" int koaf_set_conv3x3_halo(int on) {
+    const int was = g_halo_on ? 1 : 0;
+    g_halo_on = on != 0;
+    return was;
 }

@@ -18,6 +18,9 @@ _i32 = ctypes.c_int32
 # on the bf16 x 3 scheme for A/B runs.
 import os
 CONV_F16 = os.environ.get("KOAF_CONV_FMT", "f16") != "bf16"
+# activation plane images for the gathered (3x3) convolution kernels (koaf_act_planes); KOAF_APLANES=0: fp32 loaders
+APLANES = os.environ.get("KOAF_APLANES", "1") != "0"
+ACT_SCALE = 16.0        # koaf.h KOAF_ACT_SCALE
 
 # Optional live profiler (bench.py): when a list is installed here every MFMA-GEMM based call is bracketed
 # by two events recorded on the stream the kernel is launched on (torch's current stream) and logged as
@@ -113,7 +116,29 @@ def conv_out(h, k, s, p):
 # ------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------
-def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, stats=False, shift=None, wimg=None):
+def act_planes(x, npix, C, tf=0, sc=None, sh=None, x2=None, sc2=None, amax=None, fscale=0.0):
+    """fp16 piece planes [2][npix][C] (+ the zero chunk) of x (tf 0), relu(sc*x+sh) (tf 1) or sc*x + sh - sc2*x2 (tf 2), times
+    the operand scale (scale(*amax) or fscale): the A operand of the gathered convolution kernels (koaf.h koaf_act_planes)."""
+    L = lib()
+    out = torch.empty(L.koaf_act_planes_elems(npix, C), device=x.device, dtype=torch.int16)
+    check(L.koaf_act_planes(_ptr(x), _ptr(x2), npix, C, tf, _ptr(sc), _ptr(sh), _ptr(sc2), _ptr(amax), float(fscale),
+                            out.data_ptr(), _stream()), "act_planes")
+    return out
+
+
+def set_conv3x3_halo(on):
+    """route 3x3 / stride-1 convolutions over plane images through the halo kernel (default) or the per-tap gather kernel;
+    returns the previous setting (koaf.h koaf_set_conv3x3_halo)"""
+    return bool(lib().koaf_set_conv3x3_halo(1 if on else 0))
+
+
+def use_aplanes(wimg, KH, KW, C):
+    """activation plane images pay where a kernel gathers (every element is otherwise converted KH*KW times)"""
+    return APLANES and wimg is not None and KH * KW > 1 and C % 32 == 0
+
+
+def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, stats=False, shift=None, wimg=None,
+               aplanes=None):
     """x [N,H,W,Cin] (any view with that memory), w packed [Cout,KH,KW,Cin] -> y [N,OH,OW,Cout],
     (part, rows) per-tile column statistics if stats, summed about `shift` [Cout] (hand the same tensor to bn_finalize).
     wimg = (F, D, amax) plane images of w (arena.weight_planes) or None: with them the contraction runs on the fp16
@@ -126,9 +151,17 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
         nrows = L.koaf_conv2d_stats_rows(N * OH * OW, Cout)
         part = _empty((nrows, 2, Cout), x)
     e0 = _prof_begin()
+    if aplanes is None:
+        aplanes = use_aplanes(wimg, KH, KW, Cin) and wimg[0] is not None and stride == 1     # (stride 2: the pre-pass
+        #                                           would cut four times the pixels the kernel reads)
+    xpl = None
+    if torch.is_tensor(aplanes):
+        xpl = aplanes                   # images cut by the caller (act_planes with this call's transform and ACT_SCALE)
+    elif aplanes:
+        xpl = act_planes(x, N * H * W, Cin, 1 if in_sc is not None else 0, in_sc, in_sh, fscale=ACT_SCALE)
     check(L.koaf_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
                             _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _ptr(shift) if stats else None,
-                            _img(wimg), _stream()), "conv2d_fwd")
+                            _img(wimg), xpl.data_ptr() if xpl is not None else None, _stream()), "conv2d_fwd")
     _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin, f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}",
               N * H * W * Cin + Cout * KH * KW * Cin + N * OH * OW * Cout, mpp=3 if wimg is not None else 6)
     if stats:
@@ -136,14 +169,29 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     return y, part
 
 
-def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, bnb=None, wimg=None, dy_amax=None):
+def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, bnb=None, wimg=None, dy_amax=None,
+                 aplanes=None):
     """dx = conv_transpose(dy, w) (+residual).  bnb = dict(mode, c, saved[, y][, c2, saved2]): fuse the
     BatchNorm(+ReLU)-backward reduction of the layer that produced x into the epilogue; then returns
     (dz, part [rows][nsum][Cin]) instead of dx (+ the device scalar max |dz| as a third element when bnb has "dz_amax": True).
-    wimg + dy_amax (device scalar max |dy|): fp16 scheme.  dy may be a BnApply (needs wimg with its D image)."""
+    wimg + dy_amax (device scalar max |dy|): fp16 scheme.  dy may be a BnApply (needs wimg with its D image).
+    aplanes (None = where it pays: gathered stride-1 kernels with a D image): dy is cut ONCE into activation plane images
+    (the BatchNorm-backward apply included) and the kernel's input tiles are DMA'd from them."""
     L = lib()
     dyp, amp, app, like = _dy_args(dy, dy_amax)
     dx = _empty((N, H, W, Cin), like)
+    if aplanes is None:
+        aplanes = (use_aplanes(wimg, KH, KW, Cout) and wimg[1] is not None and stride == 1 and
+                   (app is not None or dy_amax is not None))
+    e0 = _prof_begin()
+    dypl = None
+    if aplanes:
+        npo = N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad)
+        if app is not None:
+            dypl = act_planes(dy.dz, npo, Cout, 2, dy.coef[0], dy.coef[3], x2=dy.c, sc2=dy.coef[2], amax=dy.amax)
+        else:
+            dypl = act_planes(dy, npo, Cout, 0, amax=dy_amax)
+    dypp = dypl.data_ptr() if dypl is not None else None
     fl = 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin
     tag = f"conv_dgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}"
     el = N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout + Cout * KH * KW * Cin + N * H * W * Cin
@@ -153,9 +201,8 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, 
         el += N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout      # (dz and c are both read)
         tag += " apply"
     if bnb is None:
-        e0 = _prof_begin()
         check(L.koaf_conv2d_dgrad(dyp, _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
-                                  _ptr(residual), _img(wimg), amp, app, _stream()), "conv2d_dgrad")
+                                  _ptr(residual), _img(wimg), amp, app, dypp, _stream()), "conv2d_dgrad")
         _prof_end(e0, "gemm", fl, tag, el, mpp=mpp)
         return dx
     sv, sv2 = bnb["saved"], bnb.get("saved2")
@@ -166,10 +213,9 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, 
     nsum = 3 if bnb.get("c2") is not None else 2
     part = _empty((L.koaf_conv2d_dgrad_bnb_rows(N, H, W, Cin, stride), nsum, Cin), like)
     rows = _i32(0)
-    e0 = _prof_begin()
     check(L.koaf_conv2d_dgrad_bnb(dyp, _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
                                   _ptr(residual), ctypes.byref(kb), _ptr(part), ctypes.addressof(rows), _img(wimg),
-                                  amp, app, _stream()), "conv2d_dgrad_bnb")
+                                  amp, app, dypp, _stream()), "conv2d_dgrad_bnb")
     el += N * H * W * Cin * (1 + (bnb.get("y") is not None) + (bnb.get("c2") is not None))
     _prof_end(e0, "gemm", fl, tag + " +bnb", el, mpp=mpp)
     if dzmax is not None:

@@ -510,14 +510,58 @@ def test_fp16_scheme_weight_images_bit_identical(dev, N, H, W, Cin, Cout, k, s, 
     noimg = (None, None, img[2])
     for tf in (False, True):
         a = ops.conv2d_fwd(x, w, N, H, W, Cin, Cout, k, k, s, p, sc if tf else None, sh if tf else None, stats=True, wimg=noimg)
-        b = ops.conv2d_fwd(x, w, N, H, W, Cin, Cout, k, k, s, p, sc if tf else None, sh if tf else None, stats=True, wimg=img)
+        b = ops.conv2d_fwd(x, w, N, H, W, Cin, Cout, k, k, s, p, sc if tf else None, sh if tf else None, stats=True, wimg=img,
+                           aplanes=False)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     OH, OW = ops.conv_out(H, k, s, p), ops.conv_out(W, k, s, p)
     dy, res = rnd(N, OH, OW, Cout).to(dev), rnd(N, H, W, Cin).to(dev)
     am = amax_of(dy)
     a = ops.conv2d_dgrad(dy, w, N, H, W, Cin, Cout, k, k, s, p, residual=res, wimg=noimg, dy_amax=am)
-    b = ops.conv2d_dgrad(dy, w, N, H, W, Cin, Cout, k, k, s, p, residual=res, wimg=img, dy_amax=am)
+    b = ops.conv2d_dgrad(dy, w, N, H, W, Cin, Cout, k, k, s, p, residual=res, wimg=img, dy_amax=am, aplanes=False)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,s,p", [(3, 19, 17, 64, 64, 3, 1, 1), (2, 20, 20, 128, 128, 3, 2, 1), (7, 24, 24, 64, 128, 3, 1, 1),
+                                                  (2, 9, 31, 256, 64, 3, 1, 1), (1, 5, 5, 32, 64, 3, 1, 1), (2, 21, 21, 64, 64, 3, 2, 1),
+                                                  (1, 7, 120, 64, 64, 3, 1, 1), (3, 96, 96, 64, 64, 3, 1, 1), (5, 12, 12, 512, 256, 3, 1, 1)])
+def test_activation_plane_images(dev, N, H, W, Cin, Cout, k, s, p):
+    """3x3 conv forward with the INPUT tiles DMA'd from activation plane images (koaf_act_planes: BatchNorm + ReLU prologue
+    cut once into fp16 piece planes).  Per-tap gather kernel (global_load_lds of one pixel's 8 channels per lane, padding
+    from the zero chunk): the same bits -- output and BatchNorm statistics -- as the fp32 loader that converts every element
+    once per filter tap.  Halo kernel (stride 1, rows <= 96 pixels: 256-pixel raster tiles, all nine taps read from one
+    LDS-resident pixel range, off-image taps masked in registers): the same sums reassociated, so equal to fp32 rounding
+    and equally close to float64.  Ragged last tiles, stride 2, images smaller than a tile, rows too wide for the halo."""
+    from oaprogressionmmf_amd import ops
+    x = rnd(N, H, W, Cin).to(dev)
+    w = rnd(Cout, k, k, Cin, scale=(k * k * Cin) ** -0.5).to(dev)
+    sc, sh = (rnd(Cin) * 0.2 + 1).to(dev), (rnd(Cin) * 0.1).to(dev)
+    img = ops.build_weight_planes(w, Cout, k * k, Cin)
+    for tf in (False, True):
+        args = (x, w, N, H, W, Cin, Cout, k, k, s, p, sc if tf else None, sh if tf else None)
+        a = ops.conv2d_fwd(*args, stats=True, wimg=img, aplanes=False)
+        was = ops.set_conv3x3_halo(False)
+        try:
+            b = ops.conv2d_fwd(*args, stats=True, wimg=img, aplanes=True)
+        finally:
+            ops.set_conv3x3_halo(was)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        c = ops.conv2d_fwd(*args, stats=True, wimg=img, aplanes=True)
+        xin = x.double().cpu()
+        if tf:
+            xin = torch.relu(xin * sc.double().cpu() + sh.double().cpu())
+        ref = F.conv2d(xin.permute(0, 3, 1, 2), w.double().cpu().permute(0, 3, 1, 2), stride=s, padding=p).permute(0, 2, 3, 1)
+        ea, ec = rel_err(a[0].cpu(), ref), rel_err(c[0].cpu(), ref)
+        assert ec < 2e-6 and ec < 1.5 * ea + 1e-7, (ea, ec)
+        assert rel_err(c[0].cpu(), a[0].cpu().double()) < 1e-6
+        # statistics: per-tile partial rows differ in count (256-row tiles), their column totals agree
+        assert rel_err(c[1].sum(0).cpu(), a[1].sum(0).cpu().double()) < 1e-5
+    # the images themselves: hi + lo == clamp(relu(sc * x + sh) * 16) to 2^-24 relative, zero chunk behind them
+    pl = ops.act_planes(x, N * H * W, Cin, 1, sc, sh, fscale=ops.ACT_SCALE)
+    n = N * H * W * Cin
+    hi, lo = pl[:n].view(torch.float16).double(), pl[n:2 * n].view(torch.float16).double()
+    ref = (torch.relu(x.double() * sc.double() + sh.double()) * 16.0).clamp(max=65504.0).flatten()
+    assert float(((hi + lo) - ref).abs().max() / ref.abs().max()) < 2.0 ** -22
+    assert int(pl[2 * n:].abs().max()) == 0
 
 
 @pytest.mark.parametrize("gs,ws", [(1e-9, 1e-4), (3e4, 50.0), (1.0, 1.0)])
@@ -581,10 +625,33 @@ def test_bn_backward_apply_formed_in_the_gemm_loaders(dev, N, H, W, Cin, Cout, k
     assert float(ap.amax) < 3e4 * float(dc._koaf_amax)       # ... and within the range the fp16 pieces have to spare
     xdv, wp = nhwc(x).to(dev), packw(w).to(dev)
     img = ops.build_weight_planes(wp, Cout, k * k, Cin)
-    dx_f = ops.conv2d_dgrad(ap, wp, N, H, W, Cin, Cout, k, k, s, p, wimg=img)
-    dx_m = ops.conv2d_dgrad(dc, wp, N, H, W, Cin, Cout, k, k, s, p, wimg=img, dy_amax=dc._koaf_amax)
+    dx_f = ops.conv2d_dgrad(ap, wp, N, H, W, Cin, Cout, k, k, s, p, wimg=img, aplanes=False)
+    dx_m = ops.conv2d_dgrad(dc, wp, N, H, W, Cin, Cout, k, k, s, p, wimg=img, dy_amax=dc._koaf_amax, aplanes=False)
     assert rel_err(dx_f, dx_m.double()) < 2e-6
     assert rel_err(nchw(dx_f.cpu()), xd64.grad) < 1e-5
+    if k > 1:
+        # the same gradients with dy cut once into activation plane images (apply included) and gathered by LDS-DMA: the
+        # per-tap gather kernel (also the four parity classes of stride 2) reproduces the loader's bits, the halo kernel
+        # (stride 1) reassociates the sums; with a residual and the fused BatchNorm-backward epilogue of the producer
+        res = rnd(N, H, W, Cin).to(dev)
+        was = ops.set_conv3x3_halo(False)
+        try:
+            dx_g = ops.conv2d_dgrad(ap, wp, N, H, W, Cin, Cout, k, k, s, p, wimg=img, aplanes=True)
+            dx_gm = ops.conv2d_dgrad(dc, wp, N, H, W, Cin, Cout, k, k, s, p, wimg=img, dy_amax=dc._koaf_amax, aplanes=True)
+        finally:
+            ops.set_conv3x3_halo(was)
+        assert torch.equal(dx_g, dx_f) and torch.equal(dx_gm, dx_m)
+        dx_h = ops.conv2d_dgrad(ap, wp, N, H, W, Cin, Cout, k, k, s, p, wimg=img, aplanes=True)
+        assert rel_err(dx_h, dx_f.double()) < 1e-6 and rel_err(nchw(dx_h.cpu()), xd64.grad) < 1e-5
+        cx = rnd(N, H, W, Cin).to(dev) * 1.5 + 0.3           # the producer's conv output and its BatchNorm
+        savx = ops.bn_finalize(ops.colstats(cx, N * H * W, Cin), Cin, N * H * W, (rnd(Cin) * 0.2 + 1).to(dev), (rnd(Cin) * 0.1).to(dev),
+                               torch.zeros(Cin, device=dev), torch.ones(Cin, device=dev), torch.zeros(1, dtype=torch.int64, device=dev),
+                               0.1, 1e-5, True)
+        bnb = dict(mode=2, c=cx, saved=savx, dz_amax=True)
+        r0 = ops.conv2d_dgrad(ap, wp, N, H, W, Cin, Cout, k, k, s, p, residual=res, bnb=bnb, wimg=img, aplanes=False)
+        r1 = ops.conv2d_dgrad(ap, wp, N, H, W, Cin, Cout, k, k, s, p, residual=res, bnb=bnb, wimg=img, aplanes=True)
+        assert rel_err(r1[0], r0[0].double()) < 1e-6 and rel_err(r1[1].sum(0), r0[1].sum(0).double()) < 1e-4
+        assert abs(float(r1[2]) / float(r0[2]) - 1) < 1e-5
     dw_f, dw_m = torch.empty(Cout, k, k, Cin, device=dev), torch.empty(Cout, k, k, Cin, device=dev)
     ops.conv2d_wgrad(ap, xdv, dw_f, N, H, W, Cin, Cout, k, k, s, p)
     ops.conv2d_wgrad(dc, xdv, dw_m, N, H, W, Cin, Cout, k, k, s, p, dy_amax=dc._koaf_amax)
