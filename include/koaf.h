@@ -45,7 +45,8 @@ typedef struct KoafOperand {
     int64_t bs0, bs1; /* batch strides (elements) for batch index z = z0*nb1 + z1 */
     int64_t tap_stride;   /* gather 3 (K-major weights [C][taps][rows]): offset between taps in a tap row */
     int64_t tap_stride_h; /* gather 3: offset between tap rows; tap index = th*KW + tw */
-    int32_t kind;     /* 0 = KC, 1 = KM, 2 = pre-split fp16 plane images (B: weights, see `planes`; A: activations, see `zeros`) */
+    int32_t kind;     /* 0 = KC, 1 = KM, 2 = pre-split fp16 plane images (B: weights, see `planes`; A: activations, see `zeros`),
+                         3 = activation plane images read K-major (both operands of a weight gradient, see `zeros`) */
     int32_t gather;   /* 0 none; 1 conv forward gather; 2 transposed-conv (dgrad) gather;
                          3 (KM only) tapped weights: k = (tap, c), element at c*ld + tap*tap_stride + r */
     int32_t H, W, C;  /* source NHWC tensor dims for a gathered operand (C = channels per tap) */
@@ -82,6 +83,9 @@ typedef struct KoafOperand {
        by the operand's scale (amax / fscale as above).  Gathered like the fp32 operand of the same `gather`; padding taps
        and rows past M read `zeros` (16 B of zeros, 16-B aligned: koaf_act_planes leaves them at planes + 2*plane_stride).
        C % 32 == 0, CS % 8 == 0; needs a pre-split B (kind 2), fmt 1, K % 32 == 0, no split-K. */
+    /* kind 3 (A and B together, fmt 1): the same images read K-MAJOR -- k = pixel, rows = channels: element (k, r) of plane q
+       at planes + q*plane_stride + k*ld + r (A, gather 0; ld = channels per pixel), or gathered like a kind-1 gather-1 operand
+       (B: column = tap*C + c, k = output pixel -> source pixel by H/W/PH/PW/KH/KW/stride/pad; C % 8 == 0).  Rows % 8 == 0. */
     const uint16_t* zeros;
 } KoafOperand;
 
@@ -250,13 +254,16 @@ int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx, int32_t N,
                           const uint16_t* dy_planes, void* stream);
 /* dw packed [Cout,KH,KW,Cin] = sum_pixels dy^T x, x optionally transformed on load.  Deterministic
  * split-K: slabs = workspace of koaf_conv2d_wgrad_ws() floats (0 = none needed).  dy_amax (nullable): max |dy| on the
- * device -> fp16 scheme.  */
+ * device -> fp16 scheme.  dy_planes + x_planes (nullable, together; need dy_amax or dy_apply, Cin % 8 == 0, Cout % 8 == 0):
+ * activation plane images of dy (amax = dy_amax; tf 2 for an applied dy) and of the transformed x (fscale KOAF_ACT_SCALE):
+ * both operand tiles are then DMA'd, K-major, and dy / x / in_sc / in_sh are not read.  */
 int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                              int32_t KH, int32_t KW, int32_t stride, int32_t pad);
 int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int32_t N, int32_t H, int32_t W,
                       int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride,
                       int32_t pad, const float* in_sc, const float* in_sh, float* slabs,
-                      const float* dy_amax, const KoafBnApply* dy_apply, void* stream);
+                      const float* dy_amax, const KoafBnApply* dy_apply, const uint16_t* dy_planes,
+                      const uint16_t* x_planes, void* stream);
 
 /* ---- Grouped 3x3 convolution (ResNeXt 32x4d; _torchvision.py:110,327-330) -------------------
  * Runs on the same MFMA GEMM as 64-channel block-diagonal slabs: packed weights [C][3][3][C/groups]

@@ -41,6 +41,18 @@ inline WgradPlan wgrad_plan(int M, int N, int64_t K, int ctap, int batch) {
     if (sk > kmax) sk = kmax;
     if (sk < 1) sk = 1;
     if (sk > 4096) sk = 4096;
+    if (sk > 8) {
+        // multiples of 8 (the kernel then keeps all tiles of a k-range on one XCD = one L2); among those between 3/4 and
+        // twice the target, the count that fills whole rounds of the chip's 512 block slots best
+        int64_t best = sk & ~7ll;
+        double beff = 0.0;
+        for (int64_t c = ((sk * 3 / 4) + 7) & ~7ll; c <= 2 * sk && c <= kmax && c <= 4096; c += 8) {
+            const int64_t blocks = tiles * c;
+            const double eff = (double)blocks / (double)(cdiv64(blocks, 512) * 512);
+            if (eff > beff + 0.02) { beff = eff; best = c; }
+        }
+        sk = best;
+    }
     p.splitk = (int)sk;
     return p;
 }
@@ -239,10 +251,10 @@ extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t
     zero_gemm(&g);
     g.A.ptr = x;
     g.A.kind = 0;
-    if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && !x_planes) {
         g.A.gather = 0;
         g.A.ld = Cin;
-    } else {
+    } else {        // (plane images are always addressed as a gather, a 1x1 kernel being its one-tap case)
         g.A.gather = 1;
         g.A.H = H; g.A.W = W; g.A.C = Cin; g.A.CS = Cin;
         g.A.PH = OH; g.A.PW = OW;
@@ -425,8 +437,11 @@ extern "C" int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t
 extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int32_t N, int32_t H, int32_t W,
                                  int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                                  const float* in_sc, const float* in_sh, float* slabs, const float* dy_amax,
-                                 const KoafBnApply* dy_apply, void* stream) {
-    KOAF_REQUIRE((dy || dy_apply) && x && dw && N > 0 && Cin % 64 == 0 && Cout % 4 == 0, "koaf_conv2d_wgrad: bad args");
+                                 const KoafBnApply* dy_apply, const uint16_t* dy_planes, const uint16_t* x_planes,
+                                 void* stream) {
+    KOAF_REQUIRE((dy_planes == nullptr) == (x_planes == nullptr) && (!dy_planes || dy_amax || dy_apply),
+                 "koaf_conv2d_wgrad: dy_planes and x_planes come together, with dy_amax (or dy_apply)");
+    KOAF_REQUIRE((dy || dy_apply || dy_planes) && (x || x_planes) && dw && N > 0 && Cin % 64 == 0 && Cout % 4 == 0, "koaf_conv2d_wgrad: bad args");
     KOAF_REQUIRE(!dy_apply || (dy_apply->dz && dy_apply->c && dy_apply->coef && dy_apply->amax),
                  "koaf_conv2d_wgrad: dy_apply needs dz / c / coef / amax");
     if (dy_apply) { dy = dy_apply->dz; dy_amax = dy_apply->amax; }
@@ -454,6 +469,15 @@ extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int
         g.B.KH = KH; g.B.KW = KW; g.B.stride = stride; g.B.pad = pad; g.B.pad_w = pad;
     }
     if (in_sc) { g.B.tf = 1; g.B.sc = in_sc; g.B.sh = in_sh; }
+    if (dy_planes) {        // both operands from plane images, K-major (the 1x1 case as a one-tap gather)
+        set_aplanes(&g.A, dy_planes, P * Cout);
+        g.A.kind = 3; g.A.ld = Cout;
+        set_aplanes(&g.B, x_planes, (int64_t)N * H * W * Cin);
+        g.B.kind = 3; g.B.gather = 1;
+        g.B.H = H; g.B.W = W; g.B.C = Cin; g.B.CS = Cin;
+        g.B.PH = OH; g.B.PW = OW;
+        g.B.KH = KH; g.B.KW = KW; g.B.stride = stride; g.B.pad = pad; g.B.pad_w = pad;
+    }
     g.M = Cout; g.N = Ntot; g.K = (int)P;
     g.bm = p.bm; g.bn = p.bn; g.splitk = p.splitk;
     g.C = p.splitk > 1 ? slabs : dw;

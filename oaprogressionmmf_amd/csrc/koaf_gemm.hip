@@ -111,7 +111,9 @@ enum { M_KC = 0,     // K-contiguous rows, dense
        M_PS = 6,     // pre-split fp16 plane images, K-contiguous rows, optionally tapped (weights: forward and dgrad)
        M_PA1 = 7,    // pre-split fp16 plane images of an NHWC activation, conv forward gather (A operand)
        M_PA2 = 8,    // the same, transposed-conv (dgrad) gather
-       M_PH = 9      // the same images, 3x3 / stride 1 / pad 1: the tile's pixel rows + halo stay in LDS for all nine taps
+       M_PH = 9,     // the same images, 3x3 / stride 1 / pad 1: the tile's pixel rows + halo stay in LDS for all nine taps
+       M_PK = 10,    // activation plane images read K-major (weight gradient: k = pixel, rows = channels), dense
+       M_PKG = 11    // the same with the conv gather on the k index and the filter tap in the column (wgrad activations)
 };
 __host__ __device__ constexpr bool mode_is_kc(int m) { return m < 3; }
 __host__ __device__ constexpr bool mode_is_pa(int m) { return m == M_PA1 || m == M_PA2; }
@@ -683,6 +685,123 @@ struct PlaneGatherLoader {
     }
 };
 
+// K-major operands from activation plane images (M_PK / M_PKG: the weight gradient, k = pixel): one DMA instruction moves
+// 1 KiB = KPI whole k-rows (pixels) of ROWS channels; the LDS image is plane[32 k][ROWS] fp16, linear, its 16-B chunks
+// XOR-swizzled by k so that the transposing fragment reads (ds_read_b64_tr_b16: 4 k-rows x 32 B per 16-lane group, two
+// groups per LDS cycle) hit 64 distinct banks: chunk ^ 4 (k & 3) for 256-B rows, chunk ^ 4 (k / 2 & 1) for 128-B rows.
+__host__ __device__ constexpr int kmd_swz(int rows, int k) { return rows == 128 ? 4 * (k & 3) : 4 * ((k >> 1) & 1); }
+
+template <int ROWS, bool GATHER>
+struct PlaneKLoader {
+    static_assert(ROWS == 128 || ROWS == 64, "tile rows");
+    static constexpr int CPR = ROWS / 8;          // 16-B chunks per k-row
+    static constexpr int KPI = 64 / CPR;          // k-rows per DMA instruction
+    static constexpr int NPIECE = 32 / KPI;       // instructions per plane and k-tile
+    static constexpr int PPW = NPIECE / 4;        // per wave
+    static constexpr int PLANE_BYTES = ROWS * 64;
+    int col, cc, kh_, kw_;      // first column of this lane's chunk; its channel and filter tap (gather)
+    bool cok;
+    v4i kk;                     // k of each piece of this lane (k-tile origin excluded)
+    // running source pixel of each piece (gather), as in TileLoader's M_KM_G1: advanced by adds and single carries
+    v4i gsx, gsy;
+    v4l goff;
+    int g_cs, g_bs, g_pws, g_phs, g_sxlim, g_sylim;
+    int64_t g_d0, g_d1, g_d2;
+
+    __device__ __forceinline__ void init(const KoafOperand& op, int r0, int R) {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int kl = lane / CPR, phys = lane % CPR;
+        col = r0 + 8 * (phys ^ kmd_swz(ROWS, kl));       // (pieces start on multiples of KPI >= 4 | 8: the swizzle sees kl only)
+        cok = col < R;                                   // R % 8 == 0
+        cc = col; kh_ = kw_ = 0;
+        if constexpr (GATHER) {
+            const int tap = col / op.C;
+            cc = col - tap * op.C;
+            kh_ = tap / op.KW;
+            kw_ = tap - kh_ * op.KW;
+        }
+        kk = (v4i){0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) kk[j] = KPI * (w + 4 * j) + kl;
+        gsx = gsy = (v4i){0, 0, 0, 0};
+        goff = (v4l){0, 0, 0, 0};
+        g_cs = g_bs = g_pws = g_phs = g_sxlim = g_sylim = 0;
+        g_d0 = g_d1 = g_d2 = 0;
+    }
+    __device__ __forceinline__ void seek(const KoafOperand& op, int k0) {
+        if constexpr (GATHER) {
+            const int ppi = op.PH * op.PW;
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                const int k = k0 + kk[j];
+                const int n = k / ppi;
+                const int rem = k - n * ppi;
+                const int py = rem / op.PW;
+                const int px = rem - py * op.PW;
+                gsy[j] = py * op.stride - op.pad + kh_;
+                gsx[j] = px * op.stride - op.pad_w + kw_;
+                goff[j] = ((int64_t)(n * op.H + gsy[j]) * op.W + gsx[j]) * op.CS + cc;
+            }
+            const int a = BK / ppi, r = BK - a * ppi, b = r / op.PW, c = r - b * op.PW;
+            const int64_t wcs = (int64_t)op.W * op.CS, hwcs = (int64_t)op.H * wcs;
+            g_cs = c * op.stride;
+            g_bs = b * op.stride;
+            g_pws = op.PW * op.stride;
+            g_phs = op.PH * op.stride;
+            g_sxlim = g_pws - op.pad_w + kw_;
+            g_sylim = g_phs - op.pad + kh_;
+            g_d0 = a * hwcs + g_bs * wcs + (int64_t)g_cs * op.CS;
+            g_d1 = (int64_t)op.stride * wcs - (int64_t)g_pws * op.CS;
+            g_d2 = hwcs - g_phs * wcs;
+        }
+    }
+    // DMA of the k-tile [k0, k0 + 32) into the two plane images at LDS byte address `lds`
+    __device__ __forceinline__ void issue(const KoafOperand& op, const unsigned short* planes, int k0, int kend, unsigned lds) {
+        const int w = threadIdx.x >> 6;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            bool ok = cok && (k0 + kk[j]) < kend;
+            int64_t off;
+            if constexpr (GATHER) {
+                const int sy = gsy[j], sx = gsx[j];
+                ok = ok && (unsigned)sy < (unsigned)op.H && (unsigned)sx < (unsigned)op.W;
+                off = goff[j];
+                int nsx = sx + g_cs;
+                const bool c1 = nsx >= g_sxlim;
+                nsx -= c1 ? g_pws : 0;
+                int nsy = sy + g_bs + (c1 ? op.stride : 0);
+                const bool c2 = nsy >= g_sylim;
+                nsy -= c2 ? g_phs : 0;
+                gsx[j] = nsx;
+                gsy[j] = nsy;
+                goff[j] = off + g_d0 + (c1 ? g_d1 : (int64_t)0) + (c2 ? g_d2 : (int64_t)0);
+            } else {
+                off = (int64_t)(k0 + kk[j]) * op.ld + col;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned short* src = ok ? planes + q * op.plane_stride + off : op.zeros;
+                lds_dma16(src, lds + q * PLANE_BYTES + (w + 4 * j) * 1024);
+            }
+        }
+    }
+};
+
+// fragment of a k-swizzled K-major plane image written by PlaneKLoader (cf. frag_load's K-major branch)
+template <int ROWS>
+__device__ __forceinline__ v4i frag_load_kmd(const unsigned* P, int row0, int g, int lane) {
+    const int li = lane & 15, q = li >> 2, pp = li & 3;
+    const int rb = row0 + 16 * ((lane >> 4) & 1) + 4 * pp;
+    const int k0 = 16 * g + 8 * (lane >> 5) + q;         // (k0 + 4 has the same swizzle)
+    const int boff = k0 * (ROWS * 2) + (((rb >> 3) ^ kmd_swz(ROWS, k0)) << 4) + ((rb & 7) << 1);
+    typedef __attribute__((address_space(3))) v4s* lds_v4s;
+    const char* Pb = reinterpret_cast<const char*>(P);
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(Pb + boff));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(Pb + boff + 4 * (ROWS * 2)));
+    const v2i l2 = __builtin_bit_cast(v2i, lo), h2 = __builtin_bit_cast(v2i, hi);
+    return (v4i){l2[0], l2[1], h2[0], h2[1]};
+}
+
 // Row loop of the vector epilogue for a FULL tile without row map, specialised on what is fused (residual, BatchNorm-
 // backward mode, second BatchNorm) so that it is branch-free: the loads of four rows go out together before the first
 // is consumed (the generic loop below tests every row and ends up with one load in flight at a time, which held the
@@ -739,12 +858,15 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
     constexpr int NW = NT / 64, WGM = NW / 2;                        // waves: WGM along M x 2 along N
     constexpr int WM = BM / WGM, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr bool AKC = mode_is_kc(AM), BKC = mode_is_kc(BMD), BPS = (BMD == M_PS), APS = mode_is_pa(AM), AH = (AM == M_PH);
+    constexpr bool WPS = (AM == M_PK);               // weight gradient from plane images: both operands K-major by LDS-DMA
+    static_assert(WPS == (BMD == M_PKG || BMD == M_PK), "K-major plane images come in pairs");
     static_assert(!(APS || AH) || (BPS && TFA == 0), "a pre-split A pairs with a pre-split B and carries its transform in the image");
     static_assert(NT == 256 || AH, "only the halo kernel runs 512 threads (the fp32 loaders are laid out for 256)");
     constexpr int HP_MAX = (BM + 2 * halo_max_w(BN) + 2 + 15) / 16;  // 16-pixel (1 KiB) pieces of a halo plane
-    constexpr int A_PL = AH ? HP_MAX * 256 : (APS ? BM * 16 : plane_dwords(BM, AKC)), B_PL = BPS ? BN * 16 : plane_dwords(BN, BKC);
+    constexpr int A_PL = AH ? HP_MAX * 256 : ((APS || WPS) ? BM * 16 : plane_dwords(BM, AKC));
+    constexpr int B_PL = (BPS || WPS) ? BN * 16 : plane_dwords(BN, BKC);
     constexpr int A_ELEMS = NPL * A_PL, B_ELEMS = NPL * B_PL;
-    constexpr int NBA = (APS || AH) ? 2 : 1, NBB = AH ? halo_b_stages(BN) : (BPS ? 2 : 1);   // LDS buffers per operand
+    constexpr int NBA = (APS || AH || WPS) ? 2 : 1, NBB = AH ? halo_b_stages(BN) : ((BPS || WPS) ? 2 : 1);   // LDS buffers per operand
     constexpr int LDC_S = BN + 4;                                    // epilogue staging row (floats)
     constexpr int C_ELEMS = VEC ? BM * LDC_S : 0;
     constexpr int OPS = NBA * A_ELEMS + NBB * B_ELEMS;
@@ -756,7 +878,16 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
     // share an A row tile land on ntn different L2s and the tile is fetched from beyond L2 ntn times.  Bijective remap:
     // XCD x works through one contiguous chunk of the tile order, so a row tile's blocks follow each other on one L2.
     unsigned bid = blockIdx.x;
-    {
+    int split = blockIdx.y;
+    if (gridDim.y > 1 && (gridDim.y & 7) == 0) {
+        // Split-K (weight gradients): the tiles of ONE k-range read the same pixels of both operands, so they should share an
+        // L2 -- left alone, the handful of tiles of a split are dealt to different XCDs and every one of them fetches its
+        // operands from HBM again (a 3x3 weight gradient re-read its inputs 5-9 times).  Dispatch order is x-fastest:
+        // XCD = linear id % 8; XCD x takes the splits = x (mod 8), all tiles of a split in consecutive slots.
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, x = lin & 7, slot = lin >> 3;
+        bid = slot % gridDim.x;
+        split = (int)((slot / gridDim.x) * 8 + x);
+    } else {
         const unsigned nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, x = bid & 7, j = bid >> 3;
         bid = x * q + (x < rem ? x : rem) + j;
     }
@@ -764,7 +895,6 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
     const int tm = bid / ntn;
     const int m0 = p.m_base + tm * BM, n0 = tn * BN;
     const int z0 = blockIdx.z / p.nb1, z1 = blockIdx.z - z0 * p.nb1;
-    const int split = blockIdx.y;
     const int kchunk = (((p.K + p.splitk - 1) / p.splitk + BK - 1) / BK) * BK;
     const int kbeg = split * kchunk;
     const int kend = min(p.K, kbeg + kchunk);
@@ -774,25 +904,32 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
     const float scb = F16 ? operand_scale(p.B) : 1.f;
     const float alpha = F16 ? p.alpha / (sca * scb) : p.alpha;
 
-    const float* Ap = (APS || AH) ? nullptr : p.A.ptr + z0 * p.A.bs0 + z1 * p.A.bs1;
-    const unsigned short* Apl = (APS || AH) ? p.A.planes + z0 * p.A.bs0 + z1 * p.A.bs1 : nullptr;
-    const float* Bp = BPS ? nullptr : p.B.ptr + z0 * p.B.bs0 + z1 * p.B.bs1;
-    const unsigned short* Bpl = BPS ? p.B.planes + z0 * p.B.bs0 + z1 * p.B.bs1 : nullptr;
+    const float* Ap = (APS || AH || WPS) ? nullptr : p.A.ptr + z0 * p.A.bs0 + z1 * p.A.bs1;
+    const unsigned short* Apl = (APS || AH || WPS) ? p.A.planes + z0 * p.A.bs0 + z1 * p.A.bs1 : nullptr;
+    const float* Bp = (BPS || WPS) ? nullptr : p.B.ptr + z0 * p.B.bs0 + z1 * p.B.bs1;
+    const unsigned short* Bpl = (BPS || WPS) ? p.B.planes + z0 * p.B.bs0 + z1 * p.B.bs1 : nullptr;
 
     // (the unused ones of the loaders are dead code to the compiler)
-    TileLoader<(APS || AH) ? 128 : BM, (APS || AH) ? M_KC : AM, TFA, VEC, F16> la;
-    TileLoader<BN, BPS ? M_KC : BMD, TFB, VEC, F16> lb;
+    TileLoader<(APS || AH) ? 128 : BM, (APS || AH || WPS) ? M_KC : AM, TFA, VEC, F16> la;
+    TileLoader<BN, (BPS || WPS) ? M_KC : BMD, TFB, VEC, F16> lb;
+    PlaneKLoader<WPS ? BM : 128, false> wka;
+    PlaneKLoader<BN, BMD == M_PKG> wkb;
     PlaneLoader<BN> lp;
     PlaneGatherLoader<AH ? 128 : BM, AM == M_PA2 ? 2 : 1> lpa;
-    if constexpr (APS) {
+    if constexpr (WPS) {
+        wka.init(p.A, m0, p.M);
+        wka.seek(p.A, kbeg);
+        wkb.init(p.B, n0, p.N);
+        wkb.seek(p.B, kbeg);
+    } else if constexpr (APS) {
         lpa.init(p.A, m0, p.M);
         lpa.seek(p.A, kbeg);
     } else if constexpr (!AH) {
         la.init(p.A, m0, p.M, z1, sca);
         la.seek(p.A, kbeg);
     }
-    if constexpr (AH) {
-        // (the halo loop below addresses both operands itself)
+    if constexpr (AH || WPS) {
+        // (the halo loop below addresses both operands itself; the K-major pair was set up above)
     } else if constexpr (BPS) {
         lp.init(p.B, n0, p.N);
         lp.seek(p.B, kbeg);
@@ -826,6 +963,7 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
                     if constexpr (APS) ap[i][q] = frag_load_ps(Au + q * A_PL, wm * WM + 32 * i, g, lane);
+                    else if constexpr (WPS) ap[i][q] = frag_load_kmd<BM>(Au + q * A_PL, wm * WM + 32 * i, g, lane);
                     else ap[i][q] = frag_load<BM, AKC>(Au + q * A_PL, wm * WM + 32 * i, g, lane);
                 }
 #pragma unroll
@@ -833,6 +971,7 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
                     if constexpr (BPS) bp[q] = frag_load_ps(Bu + q * B_PL, wn * WN + 32 * jn, g, lane);
+                    else if constexpr (WPS) bp[q] = frag_load_kmd<BN>(Bu + q * B_PL, wn * WN + 32 * jn, g, lane);
                     else bp[q] = frag_load<BN, BKC>(Bu + q * B_PL, wn * WN + 32 * jn, g, lane);
                 }
                 // piece products, smallest first.  bf16: the six of weight >= 2^-16.  fp16: lo*hi, hi*lo, hi*hi.
@@ -991,6 +1130,23 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the surplus fetches behind the last step)
+        __syncthreads();       // the epilogue reuses the operand buffers
+    } else if constexpr (WPS) {
+        // weight gradient: both K-major operands by LDS-DMA, double-buffered, one barrier per k-tile (as below)
+        if (kbeg < kend) {
+            wka.issue(p.A, Apl, kbeg, kend, sm0);
+            wkb.issue(p.B, Bpl, kbeg, kend, sb0);
+        }
+        int cur = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if ((k0 + BK) < kend) {
+                wka.issue(p.A, Apl, k0 + BK, kend, sm0 + (cur ^ 1) * (A_ELEMS * 4));
+                wkb.issue(p.B, Bpl, k0 + BK, kend, sb0 + (cur ^ 1) * (B_ELEMS * 4));
+            }
+            mma((const unsigned*)(smem + cur * A_ELEMS), (const unsigned*)(Bs0 + cur * B_ELEMS));
+            cur ^= 1;
+        }
         __syncthreads();       // the epilogue reuses the operand buffers
     } else if constexpr (APS) {
         // both operands by LDS-DMA, double-buffered: one barrier per k-tile.  At the top of iteration t every wave waits for
@@ -1281,6 +1437,11 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 bool operand_vec_ok(const KoafOperand& o, int R, int K) {
+    if (o.kind == 3) {
+        // K-major activation plane images: 16-B chunks of 8 channels along the rows
+        return aligned16(o.planes) && aligned16(o.zeros) && o.zeros && !(o.plane_stride & 7) && !(o.bs0 & 7) && !(o.bs1 & 7) &&
+               !(R & 7) && (o.gather ? (o.C > 0 && !(o.C & 7) && !(o.CS & 7) && o.KW > 0) : !(o.ld & 7));
+    }
     if (o.kind == 2 && o.gather) {
         // activation plane images: 16-B chunks of 8 channels, k-tiles never straddle a tap
         return aligned16(o.planes) && aligned16(o.zeros) && o.zeros && !(o.plane_stride & 7) && !(o.bs0 & 7) && !(o.bs1 & 7) &&
@@ -1308,6 +1469,7 @@ bool operand_vec_ok(const KoafOperand& o, int R, int K) {
 }
 
 int operand_mode(const KoafOperand& o) {
+    if (o.kind == 3) return o.gather ? M_PKG : M_PK;
     if (o.kind == 2) return o.gather == 0 ? M_PS : (o.gather == 1 ? M_PA1 : M_PA2);
     if (o.kind == 0) return o.gather == 0 ? M_KC : (o.gather == 1 ? M_KC_G1 : M_KC_G2);
     return o.gather == 0 ? M_KM : (o.gather == 1 ? M_KM_G1 : M_KM_G3);
@@ -1336,6 +1498,8 @@ int launch_modes(const KoafGemm& g, dim3 grid, hipStream_t s) {
             }
             if (am == M_KC_G1 && bm == M_PS && ta != 2) { if (ta) { KOAF_LAUNCH(M_KC_G1, M_PS, 1, 0); } else { KOAF_LAUNCH(M_KC_G1, M_PS, 0, 0); } }
             if (am == M_KC_G2 && bm == M_PS && ta != 1) { if (ta) { KOAF_LAUNCH(M_KC_G2, M_PS, 2, 0); } else { KOAF_LAUNCH(M_KC_G2, M_PS, 0, 0); } }
+            if (am == M_PK && bm == M_PKG) { KOAF_LAUNCH(M_PK, M_PKG, 0, 0); }
+            if (am == M_PK && bm == M_PK) { KOAF_LAUNCH(M_PK, M_PK, 0, 0); }
             if (am == M_PA1 && bm == M_PS) { KOAF_LAUNCH(M_PA1, M_PS, 0, 0); }
             if (am == M_PA2 && bm == M_PS) { KOAF_LAUNCH(M_PA2, M_PS, 0, 0); }
             // weight gradient with the BatchNorm-backward apply formed in the A loader (dy = sc * dz + sh - sc2 * c)
@@ -1428,8 +1592,8 @@ extern "C" int koaf_gemm_part_rows(const KoafGemm* gp) {
 extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     KoafGemm g = *gp;
     KOAF_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0, "koaf_gemm: bad dims M=%d N=%d K=%d", g.M, g.N, g.K);
-    KOAF_REQUIRE((g.A.kind == 2 ? (const void*)g.A.planes : (const void*)g.A.ptr) &&
-                 (g.B.kind == 2 ? (const void*)g.B.planes : (const void*)g.B.ptr) && g.C, "koaf_gemm: null operand");
+    KOAF_REQUIRE((g.A.kind >= 2 ? (const void*)g.A.planes : (const void*)g.A.ptr) &&
+                 (g.B.kind >= 2 ? (const void*)g.B.planes : (const void*)g.B.ptr) && g.C, "koaf_gemm: null operand");
     fill_defaults(g);
     KOAF_REQUIRE(!g.cmap || (g.splitk == 1 && !g.stats), "koaf_gemm: row map excludes split-K / stats");
     KOAF_REQUIRE(!g.bnb_mode || (g.splitk == 1 && !g.stats && g.nb0 * g.nb1 == 1 && g.bnb_c && g.bnb_mean &&
@@ -1439,8 +1603,12 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     KOAF_REQUIRE(g.splitk == 1 || (!g.bias && !g.residual && !g.stats),
                  "koaf_gemm: split-K writes raw slabs (no epilogue)");
     KOAF_REQUIRE((int64_t)g.nb0 * g.nb1 <= 65535 && g.splitk <= 65535, "koaf_gemm: batch/splitk too large");
-    KOAF_REQUIRE(g.A.kind == 0 || (g.A.kind == 1 && g.A.gather == 0) || g.A.kind == 2,
-                 "koaf_gemm: A is K-contiguous fp32, K-major without gather, or gathered activation plane images");
+    KOAF_REQUIRE(g.A.kind == 0 || (g.A.kind == 1 && g.A.gather == 0) || g.A.kind == 2 || (g.A.kind == 3 && g.A.gather == 0),
+                 "koaf_gemm: A is K-contiguous fp32, K-major without gather, or activation plane images");
+    KOAF_REQUIRE((g.A.kind == 3) == (g.B.kind == 3), "koaf_gemm: K-major plane images (kind 3) come as a pair");
+    if (g.A.kind == 3)
+        KOAF_REQUIRE(g.fmt == 1 && !g.A.tf && !g.B.tf && g.A.zeros && g.B.zeros && (g.B.gather == 0 || g.B.gather == 1),
+                     "koaf_gemm: K-major plane images need fmt 1, no transform, the zero chunks; B.gather 0 | 1");
     if (g.A.kind == 2)
         KOAF_REQUIRE((g.A.gather == 1 || g.A.gather == 2) && g.B.kind == 2 && g.fmt == 1 && !g.A.tf && g.splitk == 1 && g.A.zeros,
                      "koaf_gemm: activation plane images (A.kind 2) need gather 1|2, a pre-split B, fmt 1, no transform, no split-K");
@@ -1459,7 +1627,7 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     const bool vec = tp.vec;
     KOAF_REQUIRE(((tp.bm == 64 || tp.bm == 128) && (tp.bn == 64 || tp.bn == 128)) || tp.halo, "koaf_gemm: tile must be 64|128");
     if (g.A.gather || g.B.gather) KOAF_REQUIRE(vec, "koaf_gemm: gathered operands need aligned, C%%32==0 tensors");
-    if (g.B.kind == 2 || g.A.kind == 2) KOAF_REQUIRE(vec, "koaf_gemm: pre-split operands need 16-B aligned images (and C %% 32 == 0 per tap)");
+    if (g.B.kind >= 2 || g.A.kind >= 2) KOAF_REQUIRE(vec, "koaf_gemm: pre-split operands need 16-B aligned images (and C %% 32 == 0 per tap)");
     if (g.B.kind == 1 && g.B.gather == 1)
         KOAF_REQUIRE(g.B.C % 4 == 0, "koaf_gemm: gathered K-major operand needs channels per tap (%d) %% 4 == 0", g.B.C);
     KOAF_REQUIRE(!g.cmap || vec, "koaf_gemm: row map needs the vector epilogue");

@@ -19,7 +19,8 @@ _i32 = ctypes.c_int32
 import os
 CONV_F16 = os.environ.get("KOAF_CONV_FMT", "f16") != "bf16"
 # activation plane images for the gathered (3x3) convolution kernels (koaf_act_planes); KOAF_APLANES=0: fp32 loaders
-APLANES = os.environ.get("KOAF_APLANES", "1") != "0"
+APLANES_MASK = int(os.environ.get("KOAF_APLANES", "7"))     # bit 0 forward, 1 data gradient, 2 weight gradient
+APLANES = APLANES_MASK != 0
 ACT_SCALE = 16.0        # koaf.h KOAF_ACT_SCALE
 
 # Optional live profiler (bench.py): when a list is installed here every MFMA-GEMM based call is bracketed
@@ -77,16 +78,18 @@ class BnApply(object):
     (coef [4][C] and the scale bound `amax` from koaf_bn_bwd_finalize).  conv2d_dgrad / conv2d_wgrad take it in place of the
     dy tensor and form dc in their loaders (koaf.h KoafOperand.tf 2), so dc never travels through HBM; materialize()
     writes it out for consumers that are not such GEMMs."""
-    __slots__ = ("dz", "c", "coef", "amax", "mean", "rows", "C")
+    __slots__ = ("dz", "c", "coef", "amax", "mean", "rows", "C", "_koaf_planes")
 
     def __init__(self, dz, c, coef, amax, mean, rows, C):
         self.dz, self.c, self.coef, self.amax, self.mean, self.rows, self.C = dz, c, coef, amax, mean, rows, C
+        self._koaf_planes = None        # activation plane images of dc, cut by the first convolution that wants them
 
     def struct(self):
         return ctypes.byref(KoafBnApply(dz=_ptr(self.dz), c=_ptr(self.c), coef=_ptr(self.coef), amax=_ptr(self.amax)))
 
     def tensors(self):
-        return (self.dz, self.c, self.coef, self.amax)
+        """everything a kernel launched with this recipe reads (to be kept alive / recorded for a second stream)"""
+        return (self.dz, self.c, self.coef, self.amax, self._koaf_planes)
 
     def materialize(self, out=None, want_amax=False):
         dc = out if out is not None else torch.empty_like(self.c)
@@ -152,7 +155,7 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
         part = _empty((nrows, 2, Cout), x)
     e0 = _prof_begin()
     if aplanes is None:
-        aplanes = use_aplanes(wimg, KH, KW, Cin) and wimg[0] is not None and stride == 1     # (stride 2: the pre-pass
+        aplanes = (APLANES_MASK & 1) and use_aplanes(wimg, KH, KW, Cin) and wimg[0] is not None and stride == 1     # (stride 2: the pre-pass
         #                                           would cut four times the pixels the kernel reads)
     xpl = None
     if torch.is_tensor(aplanes):
@@ -181,16 +184,12 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, 
     dyp, amp, app, like = _dy_args(dy, dy_amax)
     dx = _empty((N, H, W, Cin), like)
     if aplanes is None:
-        aplanes = (use_aplanes(wimg, KH, KW, Cout) and wimg[1] is not None and stride == 1 and
+        aplanes = ((APLANES_MASK & 2) and use_aplanes(wimg, KH, KW, Cout) and wimg[1] is not None and stride == 1 and
                    (app is not None or dy_amax is not None))
     e0 = _prof_begin()
     dypl = None
     if aplanes:
-        npo = N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad)
-        if app is not None:
-            dypl = act_planes(dy.dz, npo, Cout, 2, dy.coef[0], dy.coef[3], x2=dy.c, sc2=dy.coef[2], amax=dy.amax)
-        else:
-            dypl = act_planes(dy, npo, Cout, 0, amax=dy_amax)
+        dypl = _dy_planes(dy, dy_amax, N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad), Cout)
     dypp = dypl.data_ptr() if dypl is not None else None
     fl = 2.0 * N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad) * Cout * KH * KW * Cin
     tag = f"conv_dgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}"
@@ -223,15 +222,36 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, 
     return dx, part[:rows.value]
 
 
-def conv2d_wgrad(dy, x, dw, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, dy_amax=None):
-    """writes dw (packed [Cout,KH,KW,Cin] memory); dy_amax (device scalar max |dy|): fp16 scheme; dy may be a BnApply"""
+def _dy_planes(dy, dy_amax, npo, Cout):
+    """activation plane images of a gradient: a tensor at scale(*dy_amax), or a BnApply with its apply folded in -- cached on
+    the BnApply (an immutable recipe), so the data gradient and the weight gradient of one convolution cut them once"""
+    if isinstance(dy, BnApply):
+        if dy._koaf_planes is None:
+            dy._koaf_planes = act_planes(dy.dz, npo, Cout, 2, dy.coef[0], dy.coef[3], x2=dy.c, sc2=dy.coef[2], amax=dy.amax)
+        return dy._koaf_planes
+    return act_planes(dy, npo, Cout, 0, amax=dy_amax)
+
+
+def conv2d_wgrad(dy, x, dw, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, dy_amax=None, aplanes=None):
+    """writes dw (packed [Cout,KH,KW,Cin] memory); dy_amax (device scalar max |dy|): fp16 scheme; dy may be a BnApply.
+    aplanes (None = gathered stride-1 kernels on the fp16 scheme): both operands from activation plane images (dy's are
+    shared with conv2d_dgrad), moved K-major by LDS-DMA."""
     L = lib()
     dyp, amp, app, like = _dy_args(dy, dy_amax)
     ws = L.koaf_conv2d_wgrad_ws(N, H, W, Cin, Cout, KH, KW, stride, pad)
     slabs = _empty((ws,), like) if ws > 0 else None
+    if aplanes is None:
+        aplanes = ((APLANES_MASK & 4) and KH * KW > 1 and stride == 1 and Cin % 8 == 0 and Cout % 8 == 0 and
+                   (app is not None or dy_amax is not None))
     e0 = _prof_begin()
+    dypl = xpl = None
+    if aplanes:
+        npo = N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad)
+        dypl = _dy_planes(dy, dy_amax, npo, Cout)
+        xpl = act_planes(x, N * H * W, Cin, 1 if in_sc is not None else 0, in_sc, in_sh, fscale=ACT_SCALE)
     check(L.koaf_conv2d_wgrad(dyp, _ptr(x), _ptr(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
-                              _ptr(in_sh), _ptr(slabs), amp, app, _stream()), "conv2d_wgrad")
+                              _ptr(in_sh), _ptr(slabs), amp, app, dypl.data_ptr() if dypl is not None else None,
+                              xpl.data_ptr() if xpl is not None else None, _stream()), "conv2d_wgrad")
     npx = N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad)
     _prof_end(e0, "gemm", 2.0 * npx * Cout * KH * KW * Cin,
               f"conv_wgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}" + (" apply" if app is not None else ""),

@@ -653,10 +653,21 @@ def test_bn_backward_apply_formed_in_the_gemm_loaders(dev, N, H, W, Cin, Cout, k
         assert rel_err(r1[0], r0[0].double()) < 1e-6 and rel_err(r1[1].sum(0), r0[1].sum(0).double()) < 1e-4
         assert abs(float(r1[2]) / float(r0[2]) - 1) < 1e-5
     dw_f, dw_m = torch.empty(Cout, k, k, Cin, device=dev), torch.empty(Cout, k, k, Cin, device=dev)
-    ops.conv2d_wgrad(ap, xdv, dw_f, N, H, W, Cin, Cout, k, k, s, p)
-    ops.conv2d_wgrad(dc, xdv, dw_m, N, H, W, Cin, Cout, k, k, s, p, dy_amax=dc._koaf_amax)
+    ops.conv2d_wgrad(ap, xdv, dw_f, N, H, W, Cin, Cout, k, k, s, p, aplanes=False)
+    ops.conv2d_wgrad(dc, xdv, dw_m, N, H, W, Cin, Cout, k, k, s, p, dy_amax=dc._koaf_amax, aplanes=False)
     assert rel_err(dw_f, dw_m.double()) < 2e-6
     assert rel_err(dw_f.cpu().permute(0, 3, 1, 2), wd64.grad) < 1e-5
+    # weight gradient with BOTH operands from activation plane images, K-major by LDS-DMA (with and without the BatchNorm
+    # prologue of x; 1x1 kernels as the one-tap gather; stride 2): the loaders' bits, so the same sums in the same order
+    scx, shx = (rnd(Cin) * 0.2 + 1).to(dev), (rnd(Cin) * 0.1).to(dev)
+    for tf in (False, True):
+        a0, a1 = torch.empty(Cout, k, k, Cin, device=dev), torch.empty(Cout, k, k, Cin, device=dev)
+        ops.conv2d_wgrad(ap, xdv, a0, N, H, W, Cin, Cout, k, k, s, p, scx if tf else None, shx if tf else None, aplanes=False)
+        ops.conv2d_wgrad(ap, xdv, a1, N, H, W, Cin, Cout, k, k, s, p, scx if tf else None, shx if tf else None, aplanes=True)
+        assert torch.equal(a0, a1)
+    ops.conv2d_wgrad(dc, xdv, a1, N, H, W, Cin, Cout, k, k, s, p, scx, shx, dy_amax=dc._koaf_amax, aplanes=True)
+    ops.conv2d_wgrad(dc, xdv, a0, N, H, W, Cin, Cout, k, k, s, p, scx, shx, dy_amax=dc._koaf_amax, aplanes=False)
+    assert torch.equal(a0, a1)
 
 
 
