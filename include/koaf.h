@@ -179,9 +179,11 @@ int koaf_wplanes_build(const float* base, uint16_t* planes, float* amax, const K
 /* Gathered 3x3 / stride 1 / pad 1 convolutions over activation plane images (image rows up to 96 pixels) run the HALO
  * kernel: 256-pixel tiles in raster order whose source pixels for all nine taps are one contiguous range kept in LDS, so
  * the input tile is fetched 1.8 times instead of nine (k runs (channel chunk, tap, channel): the sums are reassociated
- * against the per-tap gather kernel, same accuracy).  koaf_set_conv3x3_halo(0) sends them through the gather kernel
- * instead (tests / A-B measurements); returns the previous setting.  Process-wide; not meant to be flipped while other
- * threads launch. */
+ * against the per-tap gather kernel, same accuracy).  Two shapes: 256 rows / 8 waves / one block per CU (halo double-
+ * buffered across channel chunks) and 128 rows / 4 waves / two blocks per CU (one halo buffer; the 64-channel layers).
+ * koaf_set_conv3x3_halo(mode): 0 sends them through the gather kernel instead, 1 (default) picks the shape per layer,
+ * 2 / 3 force the 256- / 128-row shape where it fits (tests / A-B measurements); returns the previous mode.  Process-wide;
+ * not meant to be flipped while other threads launch. */
 int koaf_set_conv3x3_halo(int on);
 int64_t koaf_act_planes_elems(int64_t npix, int32_t C);
 int koaf_act_planes(const float* x, const float* x2, int64_t npix, int32_t C, int32_t tf, const float* sc, const float* sh,

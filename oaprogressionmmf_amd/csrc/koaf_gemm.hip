@@ -119,8 +119,11 @@ __host__ __device__ constexpr bool mode_is_kc(int m) { return m < 3; }
 __host__ __device__ constexpr bool mode_is_pa(int m) { return m == M_PA1 || m == M_PA2; }
 // halo kernel (M_PH): widest image row kept in LDS (BM + 2 W + 2 pixels of 32 channels, two buffers) and the number of
 // weight-tile stages, chosen per column-tile width so that everything fits 160 KiB
-__host__ __device__ constexpr int halo_max_w(int bn) { return bn == 64 ? 96 : 64; }
-__host__ __device__ constexpr int halo_b_stages(int bn) { return bn == 64 ? 4 : 3; }
+// Two shapes: 256 pixel rows / 8 waves / one block per CU with the halo double-buffered across channel chunks, and 128 rows /
+// 4 waves with ONE halo buffer in under 80 KiB, so that two blocks share a CU and one's prologue, chunk switch and epilogue
+// run under the other's MFMAs (the shallow-K layers: 64 channels = two chunks, where those phases outweigh the k-loop).
+__host__ __device__ constexpr int halo_max_w(int bn, int bm = 256) { return bm == 256 ? (bn == 64 ? 96 : 64) : (bn == 64 ? 96 : 48); }
+__host__ __device__ constexpr int halo_b_stages(int bn, int bm = 256) { return bm == 256 ? (bn == 64 ? 4 : 3) : 3; }
 
 // TF = transform on load (KoafOperand.tf): 0 none; 1 relu(sc[c] * x + sh[c]) -- the producer's BatchNorm + ReLU; 2 the
 // BatchNorm-BACKWARD apply dc = sc[c] * dz + sh[c] - sc2[c] * c_raw of TWO source tensors (x = dz at ptr, c_raw at ptr2, same
@@ -862,11 +865,14 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
     static_assert(WPS == (BMD == M_PKG || BMD == M_PK), "K-major plane images come in pairs");
     static_assert(!(APS || AH) || (BPS && TFA == 0), "a pre-split A pairs with a pre-split B and carries its transform in the image");
     static_assert(NT == 256 || AH, "only the halo kernel runs 512 threads (the fp32 loaders are laid out for 256)");
-    constexpr int HP_MAX = (BM + 2 * halo_max_w(BN) + 2 + 15) / 16;  // 16-pixel (1 KiB) pieces of a halo plane
+    static_assert(!AH || (BM == 256) == (NT == 512), "halo shapes: 256 rows x 512 threads, 128 rows x 256 threads");
+    constexpr int HP_MAX = (BM + 2 * halo_max_w(BN, BM) + 2 + 15) / 16;  // 16-pixel (1 KiB) pieces of a halo plane
+    constexpr bool HDB = (NT == 512);                // halo double-buffered across channel chunks (the 256-row shape)
     constexpr int A_PL = AH ? HP_MAX * 256 : ((APS || WPS) ? BM * 16 : plane_dwords(BM, AKC));
     constexpr int B_PL = (BPS || WPS) ? BN * 16 : plane_dwords(BN, BKC);
     constexpr int A_ELEMS = NPL * A_PL, B_ELEMS = NPL * B_PL;
-    constexpr int NBA = (APS || AH || WPS) ? 2 : 1, NBB = AH ? halo_b_stages(BN) : ((BPS || WPS) ? 2 : 1);   // LDS buffers per operand
+    constexpr int NBA = (APS || (AH && HDB) || WPS) ? 2 : 1;                                  // LDS buffers per operand
+    constexpr int NBB = AH ? halo_b_stages(BN, BM) : ((BPS || WPS) ? 2 : 1);
     constexpr int LDC_S = BN + 4;                                    // epilogue staging row (floats)
     constexpr int C_ELEMS = VEC ? BM * LDC_S : 0;
     constexpr int OPS = NBA * A_ELEMS + NBB * B_ELEMS;
@@ -1005,7 +1011,7 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
         // nine.  Taps that fall off the image (the raster neighbour is then another row or image) are zeroed in the
         // fragment registers by per-row validity bits.  k runs (chunk, tap, channel); the weight tile of every (chunk, tap)
         // step is double-buffered as in the loops above, the next chunk's halo arrives in ninths under the nine tap steps.
-        static_assert(2 * HP_MAX <= 9 * NW, "the next halo is spread over the nine tap steps, one piece per wave and step");
+        static_assert(!HDB || 2 * HP_MAX <= 9 * NW, "the next halo is spread over the nine tap steps, one piece per wave and step");
         constexpr int NPB = BN / 16;                        // 1-KiB pieces of a weight plane tile
         constexpr int BPW = (2 * NPB + NW - 1) / NW;        // weight pieces per wave and step
         const int Wd = p.A.W, Hd = p.A.H, CSa = p.A.CS, Ca = p.A.C;
@@ -1071,14 +1077,14 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
             // (LDS pointers typed as such: left generic, hipcc could not always prove the address space of these reads)
             typedef const __attribute__((address_space(3))) v4i* lds_v4i;
             typedef const __attribute__((address_space(3))) unsigned* lds_u;
-            const lds_u Ah = (lds_u)smem + (chunk & 1) * A_ELEMS;
-            const unsigned Anext = sm0 + ((chunk + 1) & 1) * (A_ELEMS * 4);
+            const lds_u Ah = (lds_u)smem + (HDB ? (chunk & 1) : 0) * A_ELEMS;
+            const unsigned Anext = sm0 + (HDB ? ((chunk + 1) & 1) : 0) * (A_ELEMS * 4);
             const bool more_chunks = chunk + 1 < nchunk;
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 // in flight behind this step's tile: D - 1 younger tiles (BPW loads each) and, inside a chunk, D halo pieces
                 if (tap == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (more_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * BPW + (D < 9 ? D : 9)) : "memory");
+                else if (HDB && more_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * BPW + (D < 9 ? D : 9)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * BPW) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 {
@@ -1088,7 +1094,7 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
                     issue_b(nch < nchunk ? ntap : 8, nch < nchunk ? nch : nchunk - 1, sb0 + sd * (B_ELEMS * 4));
                     if (++ntap == 9) { ntap = 0; ++nch; }
                 }
-                if (more_chunks) {
+                if (HDB && more_chunks) {
                     const int idx = tap * NW + w;
                     issue_halo(idx < np2 ? idx : np2 - 1, chunk + 1, Anext);    // (surplus slots repeat the last piece)
                 }
@@ -1127,6 +1133,12 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
                     }
                 }
                 if (++sb == NBB) sb = 0;
+            }
+            if (!HDB && more_chunks) {
+                // one halo buffer: every wave is done with this chunk, then the next one is fetched whole (the first tap of
+                // the next chunk waits for it; the CU's other block computes meanwhile)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                for (int idx = w; idx < np2; idx += NW) issue_halo(idx, chunk + 1, Anext);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the surplus fetches behind the last step)
@@ -1239,7 +1251,10 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
 
     if constexpr (VEC) {
         // stage the accumulator tile through LDS so global stores (and residual / bias loads) are
-        // 16 B per lane on full 512-B row segments instead of 4 B per lane
+        // 16 B per lane on full 512-B row segments instead of 4 B per lane.  (Measured alternatives: 4-B stores straight
+        // from the accumulator registers -- two 128-B segments per wave store -- are 25-30 % slower on the output-bound 1x1
+        // convolutions; staging in two 64-row halves to fit a third block per CU needs <= 168 VGPRs, which spills ~130
+        // dwords per lane here and halves the speed.)
         float* Cs = smem;   // all waves passed the k-loop's last barrier: operand tiles are dead
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1249,7 +1264,7 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
                 for (int e = 0; e < 16; ++e) {
                     const float v = alpha * acc[i][jn][e];
                     s1[jn] += v - kshift[jn];
-                    s2[jn] += (v - kshift[jn]) * (v - kshift[jn]);
+                    s2[jn] = fmaf(v - kshift[jn], v - kshift[jn], s2[jn]);     // (explicit: every instantiation rounds alike)
                     Cs[(wm * WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC_S + wn * WN + 32 * jn + r] = v;
                 }
         __syncthreads();
@@ -1354,7 +1369,7 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
                 const int row = m0 + wm * WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
                 float v = alpha * acc[i][jn][e];
                 s1[jn] += v - kshift[jn];
-                s2[jn] += (v - kshift[jn]) * (v - kshift[jn]);
+                s2[jn] = fmaf(v - kshift[jn], v - kshift[jn], s2[jn]);     // (explicit: every instantiation rounds alike)
                 if (cok && row < p.M) {
                     v += bv;
                     if (Rp) v += Rp[(int64_t)row * p.ldr + col];
@@ -1539,13 +1554,13 @@ extern "C" int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn) 
 namespace {
 struct TilePlan { int bm, bn; bool vec; int part_rows; bool halo; };
 
-bool g_halo_on = true;      // koaf_set_conv3x3_halo
+int g_halo_mode = 1;        // koaf_set_conv3x3_halo: 0 off, 1 pick the shape per layer, 2 always 256 rows, 3 always 128 rows
 
 // 3x3 / stride 1 / pad 1 over activation plane images with the whole pixel range as rows: the halo kernel (M_PH)
 bool halo_ok(const KoafGemm& g) {
     const KoafOperand& a = g.A;
-    return g_halo_on && a.kind == 2 && (a.gather == 1 || a.gather == 2) && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 &&
-           a.pad_w == 1 && a.PH == a.H && a.PW == a.W && a.W <= halo_max_w(g.N >= 128 ? 128 : 64) && a.H * a.W > 0 && (g.M % (a.H * a.W)) == 0 &&
+    return g_halo_mode != 0 && a.kind == 2 && (a.gather == 1 || a.gather == 2) && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 &&
+           a.pad_w == 1 && a.PH == a.H && a.PW == a.W && a.W <= halo_max_w(g.N >= 128 ? 128 : 64, 256) && a.H * a.W > 0 && (g.M % (a.H * a.W)) == 0 &&
            g.nb0 * g.nb1 == 1 && g.m_base == 0 && g.K == 9 * a.C && g.B.kind == 2 && g.fmt == 1 && !g.cmap && g.splitk == 1;
 }
 
@@ -1566,7 +1581,12 @@ TilePlan plan_tiles(const KoafGemm& g) {
     t.vec = gemm_vec_ok(g);
     if (!t.vec) { t.bm = 64; t.bn = 64; }
     t.halo = t.vec && halo_ok(g);
-    if (t.halo) { t.bm = 256; t.bn = g.N >= 128 ? 128 : 64; }
+    if (t.halo) {
+        t.bn = g.N >= 128 ? 128 : 64;
+        // 128 rows x two blocks per CU where the k-loop is short (few channel chunks) and the row fits its halo buffer
+        const bool fits128 = g.A.W <= halo_max_w(t.bn, 128);
+        t.bm = (g_halo_mode == 3 || (g_halo_mode == 1 && g.A.C <= 64)) && fits128 ? 128 : 256;
+    }
     t.part_rows = (int)cdiv64(g.M - g.m_base, t.bm);
     return t;
 }
@@ -1639,6 +1659,11 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     if (tiles <= 0) return KOAF_OK;
     if (tiles >= (1ll << 31)) { koaf_set_error("koaf_gemm: grid too large"); return KOAF_EINVAL; }
     dim3 grid((unsigned)tiles, (unsigned)g.splitk, (unsigned)(g.nb0 * g.nb1));
+    if (tp.halo && tp.bm == 128) {
+        if (tp.bn == 128) hipLaunchKernelGGL((koaf_gemm_kernel<128, 128, M_PH, M_PS, 0, 0, true, true, 256>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((koaf_gemm_kernel<128, 64, M_PH, M_PS, 0, 0, true, true, 256>), grid, dim3(256), 0, s, g);
+        return koaf_check_launch("koaf_gemm/halo128");
+    }
     if (tp.halo) {
         if (tp.bn == 128) hipLaunchKernelGGL((koaf_gemm_kernel<256, 128, M_PH, M_PS, 0, 0, true, true, 512>), grid, dim3(512), 0, s, g);
         else hipLaunchKernelGGL((koaf_gemm_kernel<256, 64, M_PH, M_PS, 0, 0, true, true, 512>), grid, dim3(512), 0, s, g);
@@ -1867,7 +1892,7 @@ extern "C" int koaf_act_planes(const float* x, const float* x2, int64_t npix, in
 }
 
 extern "C" int koaf_set_conv3x3_halo(int on) {
-    const int was = g_halo_on ? 1 : 0;
-    g_halo_on = on != 0;
+    const int was = g_halo_mode;
+    g_halo_mode = (on >= 0 && on <= 3) ? on : 1;
     return was;
 }

@@ -129,10 +129,11 @@ def act_planes(x, npix, C, tf=0, sc=None, sh=None, x2=None, sc2=None, amax=None,
     return out
 
 
-def set_conv3x3_halo(on):
-    """route 3x3 / stride-1 convolutions over plane images through the halo kernel (default) or the per-tap gather kernel;
-    returns the previous setting (koaf.h koaf_set_conv3x3_halo)"""
-    return bool(lib().koaf_set_conv3x3_halo(1 if on else 0))
+def set_conv3x3_halo(mode):
+    """how 3x3 / stride-1 convolutions over plane images run: 0 / False per-tap gather kernel, 1 / True halo kernel with the
+    shape picked per layer (default), 2 / 3 the 256- / 128-row halo shape; returns the previous mode (koaf.h
+    koaf_set_conv3x3_halo)"""
+    return lib().koaf_set_conv3x3_halo(int(mode))
 
 
 def use_aplanes(wimg, KH, KW, C):

@@ -20,8 +20,8 @@ for (N_, H, W, Cin, Cout) in [(320, 96, 96, 64, 64), (320, 48, 48, 128, 128), (3
     img = ops.build_weight_planes(w, Cout, 9, Cin)
     pl = ops.act_planes(x, N_ * H * W, Cin, 1, sc, sh, fscale=16.0)
     out = []
-    for halo in (False, True):
+    for halo, name in ((0, "gather"), (2, "halo256"), (3, "halo128")):
         ops.set_conv3x3_halo(halo)
         t = timeit(lambda: ops.conv2d_fwd(x, w, N_, H, W, Cin, Cout, k, k, s, p, sc, sh, stats=True, wimg=img, aplanes=pl))
-        out.append(f"{'halo' if halo else 'gather'} {t:7.3f} ms {fl/t/1e9:6.1f} TF/s")
+        out.append(f"{name} {t:7.3f} ms {fl/t/1e9:6.1f} TF/s")
     print(f"{Cin}->{Cout} @{H}: " + " | ".join(out), flush=True)
