@@ -22,6 +22,7 @@ CONV_F16 = os.environ.get("KOAF_CONV_FMT", "f16") != "bf16"
 APLANES_MASK = int(os.environ.get("KOAF_APLANES", "7"))     # bit 0 forward, 1 data gradient, 2 weight gradient
 APLANES = APLANES_MASK != 0
 ACT_SCALE = 16.0        # koaf.h KOAF_ACT_SCALE
+KEEP_XPLANES_ELEMS = 1 << 29      # 16-bit elements (1 GiB) up to which forward plane images are kept for the weight gradient
 
 # Optional live profiler (bench.py): when a list is installed here every MFMA-GEMM based call is bracketed
 # by two events recorded on the stream the kernel is launched on (torch's current stream) and logged as
@@ -89,7 +90,7 @@ class BnApply(object):
 
     def tensors(self):
         """everything a kernel launched with this recipe reads (to be kept alive / recorded for a second stream)"""
-        return (self.dz, self.c, self.coef, self.amax, self._koaf_planes)
+        return (self.dz, self.c, self.coef, self.amax, self._koaf_planes, getattr(self.c, "_koaf_xplanes", None))
 
     def materialize(self, out=None, want_amax=False):
         dc = out if out is not None else torch.empty_like(self.c)
@@ -166,6 +167,11 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     check(L.koaf_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
                             _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _ptr(shift) if stats else None,
                             _img(wimg), xpl.data_ptr() if xpl is not None else None, _stream()), "conv2d_fwd")
+    if xpl is not None and not torch.is_tensor(aplanes) and xpl.numel() <= KEEP_XPLANES_ELEMS:
+        # the input's plane images ride on the output and this conv's weight gradient reads them again instead of cutting
+        # them a second time -- for the small (deep-layer) tensors only: kept for layer 1 as well they cost 13 GB at the
+        # peak of the headline step (reserved 267 of 288 GB) for under 1 % of its time
+        y._koaf_xplanes = xpl
     _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin, f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}",
               N * H * W * Cin + Cout * KH * KW * Cin + N * OH * OW * Cout, mpp=3 if wimg is not None else 6)
     if stats:
@@ -249,7 +255,10 @@ def conv2d_wgrad(dy, x, dw, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None,
     if aplanes:
         npo = N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad)
         dypl = _dy_planes(dy, dy_amax, npo, Cout)
-        xpl = act_planes(x, N * H * W, Cin, 1 if in_sc is not None else 0, in_sc, in_sh, fscale=ACT_SCALE)
+        # x's images: the ones the forward convolution cut (they ride on its output = the BatchNorm input dy.c), else cut here
+        xpl = getattr(dy.c, "_koaf_xplanes", None) if app is not None else None
+        if xpl is None or xpl.numel() != L.koaf_act_planes_elems(N * H * W, Cin):
+            xpl = act_planes(x, N * H * W, Cin, 1 if in_sc is not None else 0, in_sc, in_sh, fscale=ACT_SCALE)
     check(L.koaf_conv2d_wgrad(dyp, _ptr(x), _ptr(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
                               _ptr(in_sh), _ptr(slabs), amp, app, dypl.data_ptr() if dypl is not None else None,
                               xpl.data_ptr() if xpl is not None else None, _stream()), "conv2d_wgrad")
