@@ -26,7 +26,7 @@ extern "C" {
 #define KOAF_EINVAL (-1)
 #define KOAF_ELAUNCH (-2)
 
-int koaf_version(void);          /* 100 * major + 10 * minor: 130 = this header */
+int koaf_version(void);          /* 100 * major + 10 * minor: 140 = this header */
 const char* koaf_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ void koaf_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* koaf_last_error(void) { return g_err; }
-extern "C" int koaf_version(void) { return 130; }   // 1.3: fp16 contraction scheme (KoafGemm.fmt, KoafOperand.amax), weight plane images (KoafWImg)
+extern "C" int koaf_version(void) { return 140; }   // 1.4: activation plane images (koaf_act_planes; x_planes / dy_planes of the conv entry points; KoafOperand.kind 2 | 3 on the A side)
 
 namespace {
 

@@ -22,7 +22,11 @@ CONV_F16 = os.environ.get("KOAF_CONV_FMT", "f16") != "bf16"
 APLANES_MASK = int(os.environ.get("KOAF_APLANES", "7"))     # bit 0 forward, 1 data gradient, 2 weight gradient
 APLANES = APLANES_MASK != 0
 ACT_SCALE = 16.0        # koaf.h KOAF_ACT_SCALE
-KEEP_XPLANES_ELEMS = 1 << 29      # 16-bit elements (1 GiB) up to which forward plane images are kept for the weight gradient
+# Forward plane images of up to this many 16-bit elements are kept on the convolution's output for its weight gradient
+# (saves re-cutting them).  Off by default: the mixed lifetimes fragment the caching allocator's pool -- the headline
+# step's reserved memory went from 240 to 265 GB (of 288) for 1 % of its time with everything kept, and still to 264 GB
+# with only the deep layers' small images.
+KEEP_XPLANES_ELEMS = int(os.environ.get("KOAF_KEEP_XPLANES_ELEMS", "0"))
 
 # Optional live profiler (bench.py): when a list is installed here every MFMA-GEMM based call is bracketed
 # by two events recorded on the stream the kernel is launched on (torch's current stream) and logged as
@@ -168,10 +172,7 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
                             _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _ptr(shift) if stats else None,
                             _img(wimg), xpl.data_ptr() if xpl is not None else None, _stream()), "conv2d_fwd")
     if xpl is not None and not torch.is_tensor(aplanes) and xpl.numel() <= KEEP_XPLANES_ELEMS:
-        # the input's plane images ride on the output and this conv's weight gradient reads them again instead of cutting
-        # them a second time -- for the small (deep-layer) tensors only: kept for layer 1 as well they cost 13 GB at the
-        # peak of the headline step (reserved 267 of 288 GB) for under 1 % of its time
-        y._koaf_xplanes = xpl
+        y._koaf_xplanes = xpl       # ride on the output: this conv's weight gradient reads them instead of cutting them again
     _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin, f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}",
               N * H * W * Cin + Cout * KH * KW * Cin + N * OH * OW * Cout, mpp=3 if wimg is not None else 6)
     if stats:

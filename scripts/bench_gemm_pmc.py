@@ -2,8 +2,10 @@
 REP launches each, after a warm-up, on random operands (zeros clock higher), of
   * dense forward 4096^3 on the bf16 x 3 scheme (linear layers; the round-1 reference point),
   * the 3x3 256->256 convolution of the synthetic-shape slices (160 slices of 24 x 24: 92 160 pixels) on the fp16 x 2 scheme --
-    forward (BatchNorm prologue + statistics epilogue, weight tiles DMA'd from the plane image), data gradient (weight image,
-    dy formed from (dz, c) in the loader), weight gradient (same dy) -- and the same forward on the bf16 x 3 scheme."""
+    with the fp32 loaders (forward: BatchNorm prologue + statistics epilogue, weight tiles DMA'd from the plane image; data
+    gradient: weight image, dy formed from (dz, c) in the loader; weight gradient: same dy), with the activation operands
+    from plane images (forward through the per-tap gather kernel and through the halo kernel, weight gradient through the
+    K-major pair) -- and the same forward on the bf16 x 3 scheme."""
 import os
 import sys
 from pathlib import Path
@@ -26,8 +28,16 @@ rm, rv, nbt = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev), torch
 saved = ops.bn_finalize(ops.colstats(c, rows, Cout), Cout, rows, gam, bet, rm, rv, nbt, 0.1, 1e-5, True)
 dg, db = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
 ap = ops.bn_bwd(g, c, saved, rows, Cout, rows, dg, db, 2, fused=True)
-for _ in range(REP): ops.conv2d_fwd(xx, ww, N_, H, W, Cin, Cout, k, k, s, p, sc, sh, stats=True, wimg=img)
-for _ in range(REP): ops.conv2d_dgrad(ap, ww, N_, H, W, Cin, Cout, k, k, s, p, wimg=img)
-for _ in range(REP): ops.conv2d_wgrad(ap, xx, dw, N_, H, W, Cin, Cout, k, k, s, p, sc, sh)
+# fp32 loaders (round-2 first half): activation operand converted in the k-loop
+for _ in range(REP): ops.conv2d_fwd(xx, ww, N_, H, W, Cin, Cout, k, k, s, p, sc, sh, stats=True, wimg=img, aplanes=False)
+for _ in range(REP): ops.conv2d_dgrad(ap, ww, N_, H, W, Cin, Cout, k, k, s, p, wimg=img, aplanes=False)
+for _ in range(REP): ops.conv2d_wgrad(ap, xx, dw, N_, H, W, Cin, Cout, k, k, s, p, sc, sh, aplanes=False)
+# activation plane images: per-tap gather kernel, halo kernel (forward), K-major pair (weight gradient)
+ops.set_conv3x3_halo(0)
+for _ in range(REP): ops.conv2d_fwd(xx, ww, N_, H, W, Cin, Cout, k, k, s, p, sc, sh, stats=True, wimg=img, aplanes=True)
+ops.set_conv3x3_halo(1)
+for _ in range(REP): ops.conv2d_fwd(xx, ww, N_, H, W, Cin, Cout, k, k, s, p, sc, sh, stats=True, wimg=img, aplanes=True)
+for _ in range(REP): ops.conv2d_wgrad(ap, xx, dw, N_, H, W, Cin, Cout, k, k, s, p, sc, sh, aplanes=True)
+# the same forward on the bf16 x 3 scheme
 for _ in range(REP): ops.conv2d_fwd(xx, ww, N_, H, W, Cin, Cout, k, k, s, p, sc, sh, stats=True)
 torch.cuda.synchronize()

@@ -12,11 +12,14 @@ from pathlib import Path
 O = Path(sys.argv[1])
 ROOT = Path(__file__).resolve().parent.parent
 LABEL = {
-    "128, 128, 0, 0, 0, 0, true, false": "dense forward 4096^3, bf16 x 3 (6 MFMAs per product)",
-    "128, 128, 1, 6, 1, 0, true, true": "conv 3x3 256->256 forward, fp16 x 2 (3 MFMAs): BN prologue, weight tiles by LDS-DMA",
-    "128, 128, 2, 6, 2, 0, true, true": "conv 3x3 256->256 data gradient, fp16 x 2: dy formed from (dz, c) on load, weight tiles by LDS-DMA",
-    "128, 128, 3, 4, 2, 1, true, true": "conv 3x3 256->256 weight gradient, fp16 x 2: dy formed on load, x through its BN prologue",
-    "128, 128, 1, 0, 1, 0, true, false": "conv 3x3 256->256 forward, bf16 x 3 (the round-1 scheme)",
+    "128, 128, 0, 0, 0, 0, true, false, 256": "dense forward 4096^3, bf16 x 3 (6 MFMAs per product)",
+    "128, 128, 1, 6, 1, 0, true, true, 256": "conv 3x3 256->256 forward, fp16 x 2 (3 MFMAs), fp32 activation loader: BN prologue + split in the k-loop, weight tiles by LDS-DMA",
+    "128, 128, 7, 6, 0, 0, true, true, 256": "conv 3x3 256->256 forward, activation plane images gathered per tap by LDS-DMA (both operands DMA)",
+    "256, 128, 9, 6, 0, 0, true, true, 512": "conv 3x3 256->256 forward, HALO kernel: 256-pixel raster tile + halo resident in LDS for all nine taps, 8 waves",
+    "128, 128, 2, 6, 2, 0, true, true, 256": "conv 3x3 256->256 data gradient, fp32 loader: dy formed from (dz, c) on load, weight tiles by LDS-DMA",
+    "128, 128, 3, 4, 2, 1, true, true, 256": "conv 3x3 256->256 weight gradient, fp32 loaders: dy formed on load, x through its BN prologue",
+    "128, 128, 10, 11, 0, 0, true, true, 256": "conv 3x3 256->256 weight gradient, both operands from plane images (K-major LDS-DMA)",
+    "128, 128, 1, 0, 1, 0, true, false, 256": "conv 3x3 256->256 forward, bf16 x 3 (the round-1 scheme)",
 }
 
 
