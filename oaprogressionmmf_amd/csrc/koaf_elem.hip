@@ -229,16 +229,16 @@ __global__ void __launch_bounds__(256) bn_add_relu_kernel(const float* __restric
                                                           int64_t nvec, int C4) {
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * EB) {
         const int cv = (int)(i % C4) * 4;
-        v4f v = *(const v4f*)&c[i * 4];
+        v4f v = __builtin_nontemporal_load((const v4f*)&c[i * 4]);       // (streams: read / written once, kept out of L2's way)
         v = v * *(const v4f*)&sc[cv] + *(const v4f*)&sh[cv];
         if (idt) {
-            v4f d = *(const v4f*)&idt[i * 4];
+            v4f d = __builtin_nontemporal_load((const v4f*)&idt[i * 4]);
             if (idsc) d = d * *(const v4f*)&idsc[cv] + *(const v4f*)&idsh[cv];
             v += d;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-        *(v4f*)&y[i * 4] = v;
+        __builtin_nontemporal_store(v, (v4f*)&y[i * 4]);
     }
 }
 

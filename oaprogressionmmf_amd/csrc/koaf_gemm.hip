@@ -821,10 +821,11 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t orow = m0 + row + u * RPP;
-            if constexpr (HAS_R) rv[u] = *(const v4f*)(Rp + orow * p.ldr + col);
-            if constexpr (MODE != 0) cv[u] = *(const v4f*)(p.bnb_c + orow * ldc + col);
-            if constexpr (MODE == 1) yv[u] = *(const v4f*)(p.bnb_y + orow * ldc + col);
-            if constexpr (HAS_C2) c2v[u] = *(const v4f*)(p.bnb2_c + orow * ldc + col);
+            // (streamed once: non-temporal, like the stores below -- the tile's operands, not these, should stay in L2)
+            if constexpr (HAS_R) rv[u] = __builtin_nontemporal_load((const v4f*)(Rp + orow * p.ldr + col));
+            if constexpr (MODE != 0) cv[u] = __builtin_nontemporal_load((const v4f*)(p.bnb_c + orow * ldc + col));
+            if constexpr (MODE == 1) yv[u] = __builtin_nontemporal_load((const v4f*)(p.bnb_y + orow * ldc + col));
+            if constexpr (HAS_C2) c2v[u] = __builtin_nontemporal_load((const v4f*)(p.bnb2_c + orow * ldc + col));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -845,7 +846,7 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
 #pragma unroll
                 for (int j = 0; j < 4; ++j) qm[j] = fmaxf(qm[j], fabsf(v[j]));
             }
-            *(v4f*)(Cp + orow * ldc + col) = v;
+            __builtin_nontemporal_store(v, (v4f*)(Cp + orow * ldc + col));
         }
     }
 }
@@ -1335,7 +1336,7 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
                             q3 += v * ((c2 - mu2) * is2);
                         }
                     }
-                    *(v4f*)(Cp + orow * ldc + col) = v;
+                    __builtin_nontemporal_store(v, (v4f*)(Cp + orow * ldc + col));
                 }
             }
         }
