@@ -123,7 +123,7 @@ __host__ __device__ constexpr bool mode_is_pa(int m) { return m == M_PA1 || m ==
 // 4 waves with ONE halo buffer in under 80 KiB, so that two blocks share a CU and one's prologue, chunk switch and epilogue
 // run under the other's MFMAs (the shallow-K layers: 64 channels = two chunks, where those phases outweigh the k-loop).
 __host__ __device__ constexpr int halo_max_w(int bn, int bm = 256) { return bm == 256 ? (bn == 64 ? 96 : 64) : (bn == 64 ? 96 : 48); }
-__host__ __device__ constexpr int halo_b_stages(int bn, int bm = 256) { return bm == 256 ? (bn == 64 ? 4 : 3) : 3; }
+__host__ __device__ constexpr int halo_b_stages(int bn, int bm = 256) { return bn == 64 ? 4 : 3; }
 
 // TF = transform on load (KoafOperand.tf): 0 none; 1 relu(sc[c] * x + sh[c]) -- the producer's BatchNorm + ReLU; 2 the
 // BatchNorm-BACKWARD apply dc = sc[c] * dz + sh[c] - sc2[c] * c_raw of TWO source tensors (x = dz at ptr, c_raw at ptr2, same

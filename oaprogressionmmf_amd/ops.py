@@ -186,13 +186,14 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, 
     BatchNorm(+ReLU)-backward reduction of the layer that produced x into the epilogue; then returns
     (dz, part [rows][nsum][Cin]) instead of dx (+ the device scalar max |dz| as a third element when bnb has "dz_amax": True).
     wimg + dy_amax (device scalar max |dy|): fp16 scheme.  dy may be a BnApply (needs wimg with its D image).
-    aplanes (None = where it pays: gathered stride-1 kernels with a D image): dy is cut ONCE into activation plane images
-    (the BatchNorm-backward apply included) and the kernel's input tiles are DMA'd from them."""
+    aplanes (None = where it pays: gathered kernels with a D image; stride 2 too -- dy is the SMALL tensor there and its four
+    parity-class GEMMs gather from the same images): dy is cut ONCE into activation plane images (the BatchNorm-backward
+    apply included) and the kernel's input tiles are DMA'd from them."""
     L = lib()
     dyp, amp, app, like = _dy_args(dy, dy_amax)
     dx = _empty((N, H, W, Cin), like)
     if aplanes is None:
-        aplanes = ((APLANES_MASK & 2) and use_aplanes(wimg, KH, KW, Cout) and wimg[1] is not None and stride == 1 and
+        aplanes = ((APLANES_MASK & 2) and use_aplanes(wimg, KH, KW, Cout) and wimg[1] is not None and stride in (1, 2) and
                    (app is not None or dy_amax is not None))
     e0 = _prof_begin()
     dypl = None
