@@ -854,8 +854,15 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
 
 // F16 = KoafGemm.fmt == 1 (two fp16 planes per operand, three products); else three bf16 planes, six products
 // NT = threads per block: 256 (waves 2 x 2) or 512 (waves 4 x 2: the 256-row tiles of the halo kernel)
+// PERSIST variants (see the kernel): the one-source A loaders only -- measured on the headline step, the forward 1x1
+// convolutions gain 4-11 %, while the two-source (BatchNorm-backward apply) data-gradient kernels, whose second slot and
+// fused-reduction epilogue already fill the register file, spill 40-250 B per lane and lose 8-20 %.
+__host__ __device__ constexpr bool persist_mode(int am, int bmd, bool f16, int tfa) {
+    return f16 && bmd == M_PS && am <= M_KC_G2 && tfa != 2;
+}
+// (the persistent variants carry the next tile's A slot through the epilogue: held to two waves per SIMD = 256 registers)
 template <int BM, int BN, int AM, int BMD, int TFA, int TFB, bool VEC, bool F16, int NT = 256>
-__global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
+__global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) koaf_gemm_kernel(const KoafGemm p) {
     static_assert((TFA != 2 && TFB != 2) || VEC, "the two-source prologue needs the vector path");
     constexpr int NPL = F16 ? 2 : 3;
     static_assert(BMD != M_PS || F16, "plane images are fp16");
@@ -884,6 +891,19 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MiB L2): without a remap the ntn blocks that
     // share an A row tile land on ntn different L2s and the tile is fetched from beyond L2 ntn times.  Bijective remap:
     // XCD x works through one contiguous chunk of the tile order, so a row tile's blocks follow each other on one L2.
+    // PERSIST (fp32 A loader + weight tiles by DMA: the 1x1 and stride-2 convolutions, whose k-loops are 2-32 steps): the
+    // block walks the tiles vt = blockIdx.x, + gridDim.x, ... (the host launches 2 blocks per CU) and issues the NEXT tile's
+    // first A loads before the epilogue of the current one, so their HBM latency runs under the staging / stores instead
+    // of in front of the next k-loop.  All other variants run their single tile through the same loop.
+    constexpr bool PERSIST = persist_mode(AM, BMD, F16, TFA);
+    const unsigned ntx = (unsigned)((p.M - p.m_base + BM - 1) / BM) * (unsigned)ntn;     // tiles of one (split, batch) slice
+    auto decode = [&](unsigned v, int& tm_, int& tn_) {
+        const unsigned q = ntx >> 3, rem = ntx & 7, x = v & 7, j = v >> 3;
+        const unsigned b = x * q + (x < rem ? x : rem) + j;
+        tn_ = (int)(b % (unsigned)ntn);
+        tm_ = (int)(b / (unsigned)ntn);
+    };
+    unsigned vt = blockIdx.x;
     unsigned bid = blockIdx.x;
     int split = blockIdx.y;
     if (gridDim.y > 1 && (gridDim.y & 7) == 0) {
@@ -894,13 +914,10 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
         const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, x = lin & 7, slot = lin >> 3;
         bid = slot % gridDim.x;
         split = (int)((slot / gridDim.x) * 8 + x);
-    } else {
-        const unsigned nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, x = bid & 7, j = bid >> 3;
-        bid = x * q + (x < rem ? x : rem) + j;
     }
-    const int tn = bid % ntn;
-    const int tm = bid / ntn;
-    const int m0 = p.m_base + tm * BM, n0 = tn * BN;
+    int tn = bid % ntn, tm = bid / ntn;
+    if (!(gridDim.y > 1 && (gridDim.y & 7) == 0)) decode(vt, tm, tn);
+    int m0 = p.m_base + tm * BM, n0 = tn * BN;
     const int z0 = blockIdx.z / p.nb1, z1 = blockIdx.z - z0 * p.nb1;
     const int kchunk = (((p.K + p.splitk - 1) / p.splitk + BK - 1) / BK) * BK;
     const int kbeg = split * kchunk;
@@ -945,6 +962,14 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
         lb.seek(p.B, kbeg);
     }
 
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int r = lane & 31, h = lane >> 5;
+    if constexpr (PERSIST) {
+        if (kbeg < kend) la.issue(la.sa, p.A, Ap, kbeg, kend, z1);      // the first tile's A loads
+    }
+    for (;;) {      // the tiles of this block (one, unless PERSIST)
     v16f acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -952,11 +977,6 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int t = threadIdx.x;
-    const int lane = t & 63, w = t >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    const int r = lane & 31, h = lane >> 5;
 
     float* const Bs0 = smem + NBA * A_ELEMS;
     const unsigned sm0 = KOAF_LDS_ADDR(smem), sb0 = sm0 + NBA * A_ELEMS * 4;     // LDS byte addresses of the A / B buffers
@@ -1183,7 +1203,7 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
     } else {
     if (kbeg < kend) {
         if constexpr (BPS) lp.template issue<NPL>(p.B, Bpl, sb0);
-        la.issue(la.sa, p.A, Ap, kbeg, kend, z1);
+        if constexpr (!PERSIST) la.issue(la.sa, p.A, Ap, kbeg, kend, z1);       // (PERSIST: in flight since the last tile's epilogue)
         if constexpr (!BPS) lb.issue(lb.sa, p.B, Bp, kbeg, kend, z1);
         la.finish(la.sa);
         la.template store<NPL>(la.sa, smem);
@@ -1224,6 +1244,21 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
             __syncthreads();
         }
     }
+    }
+
+    // the next tile of this block: ids, A loader state and its first loads -- before the epilogue, whose staging, loads
+    // and stores they run under (the A slot registers are free here; the LDS is not: the staging tile covers the operand
+    // buffers, so the weight tile's DMA has to wait for the end of the epilogue)
+    bool has_next = false;
+    int tm2 = 0, tn2 = 0;
+    if constexpr (PERSIST) {
+        has_next = (vt + gridDim.x) < ntx;
+        if (has_next) {
+            decode(vt + gridDim.x, tm2, tn2);
+            la.init(p.A, p.m_base + tm2 * BM, p.M, z1, sca);
+            la.seek(p.A, kbeg);
+            if (kbeg < kend) la.issue(la.sa, p.A, Ap, kbeg, kend, z1);
+        }
     }
 
     // ---- epilogue ----
@@ -1409,6 +1444,17 @@ __global__ void __launch_bounds__(NT) koaf_gemm_kernel(const KoafGemm p) {
             st[p.stats_ld + n0 + t] = a2;
         }
     }
+    if (!has_next) break;
+    // on to this block's next tile (PERSIST only): its A loads are in flight; the LDS is free once every wave is here
+    __syncthreads();
+    vt += gridDim.x;
+    tm = tm2; tn = tn2;
+    m0 = p.m_base + tm * BM; n0 = tn * BN;
+    if constexpr (PERSIST) {
+        lp.init(p.B, n0, p.N);
+        lp.seek(p.B, kbeg);
+    }
+    }
 }
 
 // out[i] = sum_s slabs[s][i]: block = 64 float4-columns x 4 slab groups (LDS tree), so small outputs (a 64x64
@@ -1449,6 +1495,8 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
         else *(v4f*)(out + (int64_t)blockIdx.y * n + i) = a;   // second-level slabs
     }
 }
+
+constexpr unsigned PERSIST_BLOCKS = 512;      // 2 per CU x 256 CUs; a multiple of 8 (virtual tile ids keep their XCD)
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -1494,6 +1542,10 @@ int operand_mode(const KoafOperand& o) {
 #define KOAF_LAUNCH(AMODE, BMODE, TA, TB)                                                                        \
     hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16>), grid, dim3(256), 0, s, g);      \
     return koaf_check_launch("koaf_gemm")
+// the persistent variants (fp32 A loader + weight tiles by DMA): at most two blocks per CU, each walking its tiles
+#define KOAF_LAUNCH_P(AMODE, BMODE, TA, TB)                                                                      \
+    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16>), pgrid, dim3(256), 0, s, g);     \
+    return koaf_check_launch("koaf_gemm")
 
 // the operand-mode pairs the library uses: conv fwd (KC|KC_G1 x KC|PS), dgrad (KC|KC_G2 x PS, or KC x KM | KC_G2 x KM_G3
 // on fp32 weights), wgrad (KM x KM|KM_G1), linear / attention (dense pairs).  tf only where a BatchNorm prologue exists.
@@ -1501,6 +1553,8 @@ template <int BM, int BN, bool VEC, bool F16>
 int launch_modes(const KoafGemm& g, dim3 grid, hipStream_t s) {
     const int am = operand_mode(g.A), bm = operand_mode(g.B);
     const int ta = g.A.tf, tb = g.B.tf;
+    dim3 pgrid = grid;
+    if (grid.y == 1 && grid.x > PERSIST_BLOCKS) pgrid.x = PERSIST_BLOCKS;
     if (am == M_KC && bm == M_KC && !tb) { if (ta == 1) { KOAF_LAUNCH(M_KC, M_KC, 1, 0); } else if (!ta) { KOAF_LAUNCH(M_KC, M_KC, 0, 0); } }
     if (am == M_KC && bm == M_KM && !ta && !tb) { KOAF_LAUNCH(M_KC, M_KM, 0, 0); }
     if (am == M_KM && bm == M_KM && !ta) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM, 0, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM, 0, 0); } }
@@ -1510,10 +1564,10 @@ int launch_modes(const KoafGemm& g, dim3 grid, hipStream_t s) {
         if (am == M_KM && bm == M_KM_G1 && !ta) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM_G1, 0, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM_G1, 0, 0); } }
         if constexpr (F16) {
             if (am == M_KC && bm == M_PS) {
-                if (ta == 1) { KOAF_LAUNCH(M_KC, M_PS, 1, 0); } else if (ta == 2) { KOAF_LAUNCH(M_KC, M_PS, 2, 0); } else { KOAF_LAUNCH(M_KC, M_PS, 0, 0); }
+                if (ta == 1) { KOAF_LAUNCH_P(M_KC, M_PS, 1, 0); } else if (ta == 2) { KOAF_LAUNCH(M_KC, M_PS, 2, 0); } else { KOAF_LAUNCH_P(M_KC, M_PS, 0, 0); }
             }
-            if (am == M_KC_G1 && bm == M_PS && ta != 2) { if (ta) { KOAF_LAUNCH(M_KC_G1, M_PS, 1, 0); } else { KOAF_LAUNCH(M_KC_G1, M_PS, 0, 0); } }
-            if (am == M_KC_G2 && bm == M_PS && ta != 1) { if (ta) { KOAF_LAUNCH(M_KC_G2, M_PS, 2, 0); } else { KOAF_LAUNCH(M_KC_G2, M_PS, 0, 0); } }
+            if (am == M_KC_G1 && bm == M_PS && ta != 2) { if (ta) { KOAF_LAUNCH_P(M_KC_G1, M_PS, 1, 0); } else { KOAF_LAUNCH_P(M_KC_G1, M_PS, 0, 0); } }
+            if (am == M_KC_G2 && bm == M_PS && ta != 1) { if (ta) { KOAF_LAUNCH(M_KC_G2, M_PS, 2, 0); } else { KOAF_LAUNCH_P(M_KC_G2, M_PS, 0, 0); } }
             if (am == M_PK && bm == M_PKG) { KOAF_LAUNCH(M_PK, M_PKG, 0, 0); }
             if (am == M_PK && bm == M_PK) { KOAF_LAUNCH(M_PK, M_PK, 0, 0); }
             if (am == M_PA1 && bm == M_PS) { KOAF_LAUNCH(M_PA1, M_PS, 0, 0); }
