@@ -2,8 +2,8 @@
 compiles csrc/koaf_gemm.hip with -S, finds for each requested instantiation the basic block holding the MFMAs and the
 blocks of the same loop before it, and prints MFMA / vector / scalar / LDS / memory instruction counts per k-step and the
 most frequent vector opcodes (every block between the loop header and the MFMA block is summed, so code that runs only
-when the filter tap changes -- the dgrad gather -- is counted as if it ran every k-step).  Usage: python scripts/isa_mix.py [BM,BN,AM,BMD,TFA,TFB,VEC,NPL ...]
-(default: dense gradient, conv dgrad, conv wgrad, conv forward at 128x128)."""
+when the filter tap changes -- the dgrad gather -- is counted as if it ran every k-step).  Usage: python scripts/isa_mix.py [BM,BN,AM,BMD,TFA,TFB,VEC,F16,NT ...]
+(default: 1x1 and 3x3 forward with the fp32 loader, gather / halo / K-major plane-image kernels, fp32-loader weight gradient, dense bf16)."""
 import collections
 import re
 import subprocess
@@ -13,12 +13,14 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 SRC = ROOT / "oaprogressionmmf_amd" / "csrc" / "koaf_gemm.hip"
-DEFAULT = ["128,128,0,3,0,0,1,2", "128,128,2,5,0,0,1,2", "128,128,3,4,0,1,1,2", "128,128,1,0,1,0,1,3"]
+# BM,BN,AM,BMD,TFA,TFB,VEC,F16,NT (the template arguments of koaf_gemm_kernel; modes as in the source's enum)
+DEFAULT = ["128,128,0,6,1,0,1,1,256", "128,128,1,6,1,0,1,1,256", "128,128,7,6,0,0,1,1,256", "256,128,9,6,0,0,1,1,512",
+           "128,128,10,11,0,0,1,1,256", "128,128,3,4,2,1,1,1,256", "128,128,0,0,0,0,1,0,256"]
 
 
 def mangled(sig):
-    bm, bn, am, bmd, tfa, tfb, vec, npl = sig.split(",")
-    return f"koaf_gemm_kernelILi{bm}ELi{bn}ELi{am}ELi{bmd}ELb{tfa}ELb{tfb}ELb{vec}ELi{npl}E"
+    bm, bn, am, bmd, tfa, tfb, vec, f16, nt = sig.split(",")
+    return f"koaf_gemm_kernelILi{bm}ELi{bn}ELi{am}ELi{bmd}ELi{tfa}ELi{tfb}ELb{vec}ELb{f16}ELi{nt}E"
 
 
 def classify(ops):
