@@ -97,22 +97,51 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_workers(n, argv, program=None):
-    """N fresh child processes of this script, one rank each; rank 0's stdout is relayed.  Returns the exit code."""
+def launch_workers(n, argv, program=None, timeout_s=None):
+    """N fresh child processes of this script, one rank each; rank 0's stdout is relayed.  Returns the exit code.
+    All children are polled: on the first non-zero exit (a rank that died after the rendezvous leaves the others inside
+    a collective for ever) or after `timeout_s` (KOAF_BENCH_TIMEOUT_S, default 3000) the rest are terminated, then killed,
+    and the code is 1.  The parent only ever spawns fresh children -- it never touches a GPU and never re-execs."""
+    import tempfile
+    import time
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("KOAF_BENCH_TIMEOUT_S", "3000"))
     port = free_port()
     cmd = [sys.executable, program or str(Path(__file__).resolve())] + list(argv)
     procs = []
-    for r in range(n):
-        procs.append(subprocess.Popen(cmd, env=worker_env(r, n, port), stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
-                                      text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    if out0:
-        sys.stdout.write(out0)
+    with tempfile.TemporaryFile(mode="w+") as out0:          # rank 0's stdout goes to a file: no pipe to fill up and block on
+        for r in range(n):
+            procs.append(subprocess.Popen(cmd, env=worker_env(r, n, port), stdout=out0 if r == 0 else subprocess.DEVNULL))
+        t0, bad, timed_out = time.time(), [], False
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad or all(rc is not None for rc in rcs):
+                break
+            if time.time() - t0 > timeout_s:
+                timed_out = True
+                break
+            time.sleep(0.2)
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            p.terminate()
+        t1 = time.time()
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, 10.0 - (time.time() - t1)))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        out0.seek(0)
+        txt = out0.read()
+    if txt:
+        sys.stdout.write(txt)
         sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if timed_out:
+        print(f"bench.py: workers still running after {timeout_s:.0f} s: terminated", file=sys.stderr)
+        return 1
     if bad:
-        print(f"bench.py: worker(s) failed: {bad}", file=sys.stderr)
+        print(f"bench.py: worker(s) failed: {bad}; the remaining ranks were terminated", file=sys.stderr)
         return 1
     return 0
 

@@ -109,4 +109,18 @@ class GraphedTrainStep(object):
             with torch.cuda.graph(self.graph):
                 self.out = self._body()
         self.graph.replay()
+        self._invalidate_planes()
         return self.out
+
+    def _invalidate_planes(self):
+        """A replayed optimizer step rewrites the arena weights on the device without the host noticing (`arena.epoch` is only
+        bumped while the step is being captured): move the epoch on after every replay, so that the next EAGER forward
+        (validation between replayed train steps) finds its plane-image stamp stale and rebuilds the images from the
+        weights this replay left, instead of multiplying with the ones cut at the start of the replay."""
+        seen = set()
+        for group in self.opt.param_groups:
+            for p in group["params"]:
+                a = getattr(p, "_koaf_arena", None)
+                if a is not None and id(a) not in seen:
+                    seen.add(id(a))
+                    a.epoch += 1

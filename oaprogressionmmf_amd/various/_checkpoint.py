@@ -58,13 +58,26 @@ class CheckpointHandler(object):
         self.fname_pattern = fname_pattern
         self.num_saved = int(num_saved)
         self._suffix = Path(fname_pattern).suffix
+        self._saved = []          # files written by this handler, in save order
         found = self._listing()
         logger.info("Checkpoints found: %d", len(found))
         self._trim()
 
     def _listing(self):
-        """checkpoint files of the directory, oldest first (the zero-padded epoch makes name order = age order)"""
-        return sorted(p for p in self.path_root.iterdir() if p.is_file() and p.suffix == self._suffix)
+        """checkpoint files of the directory, oldest first.  Age = the order this handler saved them in (the reference
+        appends to its list, so the file just written is always the newest: `epoch_1000` sorts before `epoch_999` by
+        name, and a directory may hold several models / folds), files it did not write itself ordered before those by
+        (modification time, name)."""
+        files = [p for p in self.path_root.iterdir() if p.is_file() and p.suffix == self._suffix]
+        mine = {p: i for i, p in enumerate(self._saved)}
+        def age(p):
+            if p in mine:
+                return (1, mine[p], p.name)
+            try:
+                return (0, p.stat().st_mtime_ns, p.name)
+            except OSError:
+                return (0, 0, p.name)
+        return sorted(files, key=age)
 
     def _trim(self):
         files = self._listing()
@@ -86,5 +99,9 @@ class CheckpointHandler(object):
     def save_new_ckpt(self, model, model_name, fold_idx, epoch_idx):
         target = self.path_root / self.fname_pattern.format(model_name=model_name, fold_idx=fold_idx, epoch_idx=epoch_idx)
         torch.save(portable_state_dict(model), target)
+        if target in self._saved:
+            self._saved.remove(target)
+        self._saved.append(target)
         self._trim()
+        self._saved = [p for p in self._saved if p.exists()]
         return target

@@ -53,6 +53,10 @@ class Adam(optim.Optimizer):
                         p.grad = gv
                     by_arena.setdefault(id(a), (a, []))[1].append(p)
                 else:
+                    if self.capturable:
+                        # (its step count would live on the host: a captured step would replay with a frozen count)
+                        raise RuntimeError("koaf Adam(capturable=True) updates arena parameters only: this parameter lives "
+                                           "outside the model's arena (run one forward of the model before the first step)")
                     self._step_loose(p, lr, b1, b2, eps, wd)
             for a, plist in by_arena.values():
                 stt = self._arena_state(a)
@@ -223,8 +227,9 @@ class Adam(optim.Optimizer):
 class AdamW(Adam):
     _ADAMW = True
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False):
-        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, capturable=False):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad,
+                         capturable=capturable)
 
 
 def warmup_static_decay_factor(epoch, epochs_warmup, epochs_static, warmup_factor=0.1, decay_factor=0.9):

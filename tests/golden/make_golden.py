@@ -218,6 +218,85 @@ def case_f1_attention_feat(km, **_):
     print("  wrote f1_attention_feat.npz")
 
 
+F2_CASES = (                      # tag, inplanes, planes, stride, groups, base_width, (N, H, W)
+    ("s1", 256, 64, 1, 1, 64, (2, 12, 12)),
+    ("s2ds", 256, 128, 2, 1, 64, (2, 12, 12)),
+    ("g32", 256, 64, 1, 32, 4, (2, 12, 12)),
+    ("g32s2ds", 256, 128, 2, 32, 4, (2, 12, 12)),
+)
+
+
+def case_f2_bottleneck(tv, **_):
+    """F2: ONE `Bottleneck` (_torchvision.py:83-138) in train mode, forward + backward, FULL tensors -- output, BatchNorm
+    buffers after the step, dx and every parameter gradient -- plus the eval-mode output.  Three BatchNorms deep there is no
+    chaotic branch noise, so this is where a tight element-wise bar on gradients is possible; the only discrete effect left
+    is a ReLU input that close to zero that a 1e-6 rounding difference takes the other branch, so the input seed is chosen
+    (first of 0, 1, 2, ...) such that no ReLU input of the float64 run lies within 2e-5 of zero (the margin is recorded)."""
+    out = {"torch_version": np.array(torch.__version__)}
+    for tag, inpl, planes, stride, groups, bw, (N, H, W) in F2_CASES:
+        def build(dt=torch.float32):
+            torch.manual_seed(0)
+            ds = None
+            if stride != 1 or inpl != planes * 4:
+                ds = torch.nn.Sequential(tv.conv1x1(inpl, planes * 4, stride), torch.nn.BatchNorm2d(planes * 4))
+            blk = tv.Bottleneck(inpl, planes, stride=stride, downsample=ds, groups=groups, base_width=bw)
+            P.fill_state_dict(blk.state_dict())
+            return blk.to(dt)
+
+        def preacts(blk, x):
+            """the three ReLU inputs of Bottleneck.forward, restated on the block's own children (float64 margin check only)"""
+            a1 = blk.bn1(blk.conv1(x))
+            a2 = blk.bn2(blk.conv2(torch.relu(a1)))
+            a3 = blk.bn3(blk.conv3(torch.relu(a2))) + (blk.downsample(x) if blk.downsample is not None else x)
+            return a1, a2, a3
+        seed = None
+        for cand in range(200):
+            x64 = torch.relu(t(P.make_input("f2x_" + tag, (N, inpl, H, W), seed=cand))).double()
+            b64 = build(torch.float64).train()
+            with torch.no_grad():
+                margin = min(float(a.abs().min()) for a in preacts(b64, x64))
+            if margin > 2e-5:
+                seed = cand
+                break
+        assert seed is not None, tag
+        x = torch.relu(t(P.make_input("f2x_" + tag, (N, inpl, H, W), seed=seed)))
+        blk = build()
+        blk.eval()
+        with torch.no_grad():
+            out[tag + ":eval"] = blk(x.clone()).numpy()
+        res = {}
+        for dt in (torch.float32, torch.float64):
+            b = build(dt).train()
+            xi = x.to(dt).clone().requires_grad_(True)
+            y = b(xi + 0)                              # (+0: the block's `out += identity` must not write into the leaf)
+            g = t(P.make_input("f2g_" + tag, tuple(y.shape), seed=seed)).to(dt)
+            (y * g).sum().backward()
+            res[dt] = (y.detach(), xi.grad.detach(), {k: p.grad.detach() for k, p in b.named_parameters()},
+                       {k: v.detach().clone() for k, v in b.named_buffers()})
+        y32, dx32, g32, buf32 = res[torch.float32]
+        y64, dx64, g64, _ = res[torch.float64]
+        out[tag + ":seed"] = np.int64(seed)
+        out[tag + ":relu_margin64"] = np.float64(margin)
+        out[tag + ":train"] = y32.numpy()
+        out[tag + ":dx"] = dx32.numpy()
+        for k, v in g32.items():
+            out[tag + ":grad:" + k] = v.numpy()
+        for k, v in buf32.items():
+            out[tag + ":buf:" + k] = v.numpy()
+        keys = sorted(g32)
+        e32 = [float((g32[k].double() - g64[k]).abs().max() / g64[k].abs().max()) for k in keys]
+        # how far the reference's own float32 results are from its float64 run (max-norm, relative to the tensor's largest
+        # magnitude): the noise floor under the 1e-5 bar of the tests
+        out[tag + ":e32_keys"] = np.array(keys)
+        out[tag + ":e32_vals"] = np.array(e32)
+        out[tag + ":e32_out_dx"] = np.array([float((y32.double() - y64).abs().max() / y64.abs().max()),
+                                             float((dx32.double() - dx64).abs().max() / dx64.abs().max())])
+        print(f"  {tag}: seed {seed}, ReLU margin {margin:.2e}, reference fp32 vs fp64: out {_rel(y32, y64):.1e} dx "
+              f"{float((dx32.double() - dx64).abs().max() / dx64.abs().max()):.1e} worst grad (max-norm) {max(e32):.1e}")
+    np.savez_compressed(HERE / "f2_bottleneck.npz", **out)
+    print(f"  wrote f2_bottleneck.npz ({(HERE / 'f2_bottleneck.npz').stat().st_size / 1024:.0f} KiB)")
+
+
 def case_f3_trunk(tv, **_):
     out = {}
     for arch, shape in (("resnet50", (4, 1, 160, 160)), ("resnet50", (2, 1, 96, 112)), ("resnext50_32x4d", (2, 1, 130, 130)),
@@ -465,7 +544,7 @@ def case_f14_fullsize(km, tv, losses, **_):
 
 
 CASES = {
-    "f1": case_f1_attention_feat, "f3": case_f3_trunk, "f4": case_f4_xr1cnn,
+    "f1": case_f1_attention_feat, "f2": case_f2_bottleneck, "f3": case_f3_trunk, "f4": case_f4_xr1cnn,
     "f5": case_f5_mr, "f5g": case_f5_nogap, "f6": case_f6_full, "f7": case_f7_focal, "f8": case_f8_interp, "f9": case_f9_sched,
     "f11": case_f11_bookkeeping, "f12": case_f12_augment, "f13": case_f13_modal_abl, "f14": case_f14_fullsize,
 }

@@ -32,6 +32,31 @@ def test_launcher_starts_ranks_and_relays_rank0(tmp_path, capfd):
     capfd.readouterr()
 
 
+HANG = """
+import os, sys, time
+r = int(os.environ["RANK"])
+if r == 1:
+    time.sleep(0.5)
+    sys.exit(7)          # dies after the "rendezvous"
+time.sleep(600)          # the survivors would sit in a collective for ever
+"""
+
+
+def test_launcher_tears_down_survivors_of_a_dead_rank(tmp_path, capfd):
+    import time
+    import bench
+    stub = tmp_path / "hang.py"
+    stub.write_text(HANG)
+    t0 = time.time()
+    rc = bench.launch_workers(3, [], program=str(stub))
+    assert rc == 1 and time.time() - t0 < 30
+    assert "worker(s) failed" in capfd.readouterr().err
+    t0 = time.time()
+    rc = bench.launch_workers(1, [], program=str(stub), timeout_s=1.0)       # rank 0 alone only sleeps: the overall limit ends it
+    assert rc == 1 and time.time() - t0 < 30
+    assert "terminated" in capfd.readouterr().err
+
+
 def test_worker_env_and_defaults():
     import bench
     env = bench.worker_env(3, 8, 12345, base={"X": "1"})

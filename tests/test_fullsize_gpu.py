@@ -185,3 +185,66 @@ def test_baseline_synthetic_shapes_recompute_matches_stored_activations(dev):
     assert mem1 < 0.6 * mem0, (mem0, mem1)               # the point of recompute at these sizes
     worst = max(rel(g1[k].cpu().numpy(), g0[k].cpu().numpy()) for k in g0)
     assert worst < 1e-4, worst
+
+
+def test_headline_syn3_batch8_train_step_and_eval(dev):
+    """The configuration bench.py reports (BASELINE config 4 on BASELINE's synthetic tensors: XR 1x310x310 + 3 x MRI
+    1x160x384x384 slice-major + 9 clinical, per-GPU batch 8 = 3840 slices of 384^2, recompute policy from bench.workload_cfg)
+    under pytest: one train step with the headline policy "012,012,01" against the same step with "012,012,012" (both fit) --
+    the loss bit-equal, every gradient finite and within 1e-4 relative (recomputed activations are the same bits; what
+    differs is the summation order of a few BatchNorm reductions), peak memory under 250 GB reserved -- and eval-mode sample
+    independence at batch 8.  A tile-count, 32-bit-offset or lane-ordering error that only shows at 3840 x 384^2 fails here,
+    not in a plausible `last_loss`."""
+    import bench
+    from oaprogressionmmf_amd.models import KoafTrunk
+    from oaprogressionmmf_amd.various import dict_losses
+    cfg, B, policy = bench.workload_cfg("syn3")
+    assert B == 8 and policy == "012,012,01"
+    shapes = cfg.pop("_tensor_shapes")
+    assert shapes[1] == [160, 384, 384] and cfg["fe"]["mr"]["volume_layout"] == "ncdhw"
+    for sec in ("xr", "mr", "clin"):
+        cfg["fe"][sec]["dropout"] = 0.0                  # (masks are drawn per call: off for the comparison)
+    cfg["agg"]["emb_dropout"] = cfg["agg"]["mlp_dropout"] = 0.0
+    m = _model("syn3_ncdhw", cfg, dev)
+    xs = _inputs(cfg, B, dev, 1234, shapes)
+    assert tuple(xs[1].shape) == (8, 1, 160, 384, 384) and tuple(xs[0].shape) == (8, 1, 310, 310)
+    y = torch.from_numpy(P.make_target("target", B, 1234)).to(dev)
+    loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
+    buf0 = {k: b.detach().clone() for k, b in m.named_buffers()}
+    trunks = [t for t in m.modules() if isinstance(t, KoafTrunk)]
+
+    def run(pol):
+        for t in trunks:
+            t.recompute = False
+        assert bench.apply_recompute(m, pol) == pol
+        with torch.no_grad():
+            for k, b in m.named_buffers():
+                b.copy_(buf0[k])
+        m.train()
+        m.zero_grad()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        loss = loss_fn(input=m(*xs)["main"].squeeze(1), target=y.long().squeeze(1))
+        loss.backward()
+        torch.cuda.synchronize()
+        return (float(loss.detach()), torch.cuda.max_memory_reserved() / 1e9,
+                {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    try:
+        l0, mem0, g0 = run("012,012,01")
+        l1, mem1, g1 = run("012,012,012")
+    finally:
+        for t in trunks:
+            t.recompute = False
+    assert l0 == l1 and np.isfinite(l0), (l0, l1)
+    assert mem0 < 250.0 and mem1 < 250.0, (mem0, mem1)
+    assert len(g0) > 800 and sorted(g0) == sorted(g1)
+    assert all(bool(torch.isfinite(g).all()) for g in g0.values())
+    worst = max((float((g0[k] - g1[k]).norm() / (g1[k].norm() + 1e-30)), k) for k in g0)
+    assert worst[0] < 1e-4, worst
+    assert sum(float(g.abs().sum()) for g in g0.values()) > 0
+    del g0, g1
+    m.zero_grad()
+    _independence(m, xs, 2e-5)
+    _CACHE.clear()
+    torch.cuda.empty_cache()

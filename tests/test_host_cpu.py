@@ -182,6 +182,34 @@ def test_checkpoint_roundtrip(tmp_path):
     assert all(v.is_contiguous() for v in sd.values())           # plain tensors: loadable by the reference
 
 
+def test_checkpoint_newest_save_is_never_the_victim(tmp_path):
+    """age is save order, not name order: epoch 1000 sorts before epoch 999 by name, and a run directory may hold another
+    model's files (reference: the handler appends to its list, koafusion/various/_checkpoint.py:51-62)"""
+    from oaprogressionmmf_amd.various import CheckpointHandler
+    m = torch.nn.Linear(2, 2)
+    (tmp_path / "ZZ_other__fold_0__epoch_001.pth").write_bytes(b"x")
+    h = CheckpointHandler(tmp_path, num_saved=1)
+    a = h.save_new_ckpt(model=m, model_name="M", fold_idx=0, epoch_idx=999)
+    assert h.get_last_ckpt() == a and not (tmp_path / "ZZ_other__fold_0__epoch_001.pth").exists()
+    b = h.save_new_ckpt(model=m, model_name="M", fold_idx=0, epoch_idx=1000)
+    assert b.exists() and not a.exists() and h.get_last_ckpt() == b
+    c = h.save_new_ckpt(model=m, model_name="A", fold_idx=1, epoch_idx=5)        # sorts first by name, is the newest
+    assert c.exists() and not b.exists() and h.get_last_ckpt() == c
+    h2 = CheckpointHandler(tmp_path, num_saved=2)
+    d = h2.save_new_ckpt(model=m, model_name="M", fold_idx=0, epoch_idx=2)
+    assert sorted(p.name for p in tmp_path.glob("*.pth")) == sorted([c.name, d.name]) and h2.get_last_ckpt() == d
+
+
+def test_adamw_takes_capturable():
+    from oaprogressionmmf_amd.various import dict_optimizers
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = dict_optimizers["AdamW"]([p], lr=1e-3, capturable=True)
+    assert opt.capturable and opt._ADAMW
+    p.grad = torch.ones(3)
+    with pytest.raises(RuntimeError, match="arena parameters only"):
+        opt.step()                   # a parameter outside an arena cannot take a device-resident step count
+
+
 def test_fused_adam_state_dict_is_torch_layout():
     """resume bookkeeping without a device: a torch.optim.Adam state_dict loads into the fused Adam and comes back
     unchanged (same keys, steps, moment tensors, hyper-parameters); nothing is computed on the CPU"""

@@ -122,6 +122,56 @@ def test_oracle_attention_feat():
         assert rel(a[0].numpy(), g[tag + ":attn0"]) < 1e-5
 
 
+F2_CASES = (("s1", 256, 64, 1, 1, 64), ("s2ds", 256, 128, 2, 1, 64), ("g32", 256, 64, 1, 32, 4), ("g32s2ds", 256, 128, 2, 32, 4))
+
+
+def f2_state(tag, inpl, planes, stride, groups, bw):
+    """state dict of one reference Bottleneck (_torchvision.py:101-115), filled by key name like the fixture's"""
+    width = int(planes * (bw / 64.0)) * groups
+    shapes = {"conv1.weight": (width, inpl, 1, 1), "conv2.weight": (width, width // groups, 3, 3),
+              "conv3.weight": (planes * 4, width, 1, 1)}
+    bns = {"bn1": width, "bn2": width, "bn3": planes * 4}
+    if stride != 1 or inpl != planes * 4:
+        shapes["downsample.0.weight"] = (planes * 4, inpl, 1, 1)
+        bns["downsample.1"] = planes * 4
+    sd = {"b." + k: t(P.fill_value(k, s)) for k, s in shapes.items()}
+    for bn, c in bns.items():
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            sd[f"b.{bn}.{leaf}"] = t(P.fill_value(f"{bn}.{leaf}", (c,)))
+        sd[f"b.{bn}.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    return sd
+
+
+def test_oracle_bottleneck_f2():
+    """F2: one Bottleneck, full tensors, element-wise (max-norm relative to the tensor's largest magnitude) at 1e-5"""
+    g = load("f2_bottleneck.npz")
+
+    def mx(a, b):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        return float(np.abs(a - b).max() / np.abs(b).max())
+    for tag, inpl, planes, stride, groups, bw in F2_CASES:
+        seed = int(g[tag + ":seed"])
+        x = torch.relu(t(P.make_input("f2x_" + tag, (2, inpl, 12, 12), seed=seed)))
+        sd = f2_state(tag, inpl, planes, stride, groups, bw)
+        with torch.no_grad():
+            ye = O._bottleneck(x, {k: v.clone() for k, v in sd.items()}, "b", False, stride, groups)
+        assert mx(ye.numpy(), g[tag + ":eval"]) < 1e-5
+        for k in sd:
+            if O.is_param(k):
+                sd[k].requires_grad_(True)
+        xi = x.clone().requires_grad_(True)
+        y = O._bottleneck(xi, sd, "b", True, stride, groups)
+        (y * t(P.make_input("f2g_" + tag, tuple(y.shape), seed=seed))).sum().backward()
+        assert mx(y.detach().numpy(), g[tag + ":train"]) < 1e-5, tag
+        assert mx(xi.grad.numpy(), g[tag + ":dx"]) < 1e-5, tag
+        for k, v in sd.items():
+            if O.is_param(k):
+                assert mx(v.grad.numpy(), g[f"{tag}:grad:{k[2:]}"]) < 1e-5, (tag, k)
+            else:
+                assert mx(v.detach().numpy(), g[f"{tag}:buf:{k[2:]}"]) < 1e-5 or k.endswith("num_batches_tracked"), (tag, k)
+        assert int(sd["b.bn1.num_batches_tracked"]) == int(g[tag + ":buf:bn1.num_batches_tracked"]) == 1
+
+
 def test_oracle_trunks():
     g = load("f3_trunk.npz")
     for arch, shape in (("resnet50", (4, 1, 160, 160)), ("resnet50", (2, 1, 96, 112)),
