@@ -97,6 +97,9 @@ def free_port():
         return s.getsockname()[1]
 
 
+LAST_WORKER_CODES = []
+
+
 def launch_workers(n, argv, program=None, timeout_s=None):
     """N fresh child processes of this script, one rank each; rank 0's stdout is relayed.  Returns the exit code.
     All children are polled: on the first non-zero exit (a rank that died after the rendezvous leaves the others inside
@@ -137,6 +140,8 @@ def launch_workers(n, argv, program=None, timeout_s=None):
     if txt:
         sys.stdout.write(txt)
         sys.stdout.flush()
+    del LAST_WORKER_CODES[:]
+    LAST_WORKER_CODES.extend(p.returncode for p in procs)
     if timed_out:
         print(f"bench.py: workers still running after {timeout_s:.0f} s: terminated", file=sys.stderr)
         return 1
@@ -265,29 +270,43 @@ def cpu_baseline(workload):
     n = min(len(os.sched_getaffinity(0)), 64)
     torch.set_num_threads(n)
     if workload == "syn3":
-        # One knee of the headline workload is XR + 3 x 160 slices of 384^2 (~200 s on a host CPU).  The slice-wise
-        # encoders are linear in the slice count, so the sample times the SAME model and tensor sizes with 8 and with 4 of the
-        # 160 slices per MRI (batch 1, one full train step each, after a 2-slice warm-up step) and extrapolates the
-        # per-slice cost to 160: t(160) = t(4) + (160 - 4) * (t(8) - t(4)) / 4.
+        # One knee of the headline workload is XR + 3 x 160 slices of 384^2 (minutes on a host CPU).  The slice-wise encoders
+        # are linear in the slice count, so the sample times the SAME model and tensor sizes with 32 and with 16 of the 160
+        # slices per MRI (batch 1, one full train step each, after a 2-slice warm-up step: 96 / 48 images per convolution call
+        # keep all cores busy -- with the 4 / 8 slices of the earlier rounds oneDNN could not fill 64 threads and the slope
+        # was pessimistic for the CPU) and extrapolates the per-slice cost: t(160) = t(16) + (160 - 16) * (t(32) - t(16)) / 16.
+        # Footnote, as BASELINE.md 3 promises: the reference ships OMP_NUM_THREADS=1 (train_prog_fus.py:7-9); the same
+        # extrapolation from 2 and 1 slices per MRI on ONE thread.
         def job(S):
             return _oracle_job(lambda: P.cfg_xr1mr3c1(xr=(320, 320), mr1=(320, 320, S), mr2=(320, 320, S), mr3=(320, 320, S),
                                                       dropout=0.1), 1, [[310, 310], [384, 384, S], [384, 384, S], [384, 384, S], [16]])
-        om, xs, y = job(2)
-        om.train_step(xs, y)
-        ts = {}
-        for S in (8, 4):
+
+        def one(S):
             om, xs, y = job(S)
             t0 = time.time()
             om.train_step(xs, y)
-            ts[S] = time.time() - t0
-        per_slice = max((ts[8] - ts[4]) / 4.0, 1e-9)
-        t160 = ts[4] + 156 * per_slice
+            return time.time() - t0
+        one(2)                                           # warm-up (thread pool, primitive caches)
+        hi, lo = (32, 16) if n >= 16 else (8, 4)         # (a small host would need minutes for 96 images: keep the sample bounded)
+        ts = {S: one(S) for S in (hi, lo)}
+        per_slice = max((ts[hi] - ts[lo]) / float(hi - lo), 1e-9)
+        t160 = ts[lo] + (160 - lo) * per_slice
+        torch.set_num_threads(1)
+        t1 = {S: one(S) for S in (2, 1)}
+        torch.set_num_threads(n)
+        t160_1 = t1[1] + 159 * max(t1[2] - t1[1], 1e-9)
         return {"value": round(1.0 / t160, 5), "unit": "knees/s", "cores": n, "kind": "port",
                 "sample": f"oracle (CPU port of the same model and step: fwd + focal loss + bwd + Adam) at batch 1 on {n} torch "
-                          f"threads with 8 and with 4 of the 160 slices per MRI at the full 384x384 / 310x310 sizes (one train step "
-                          f"each, after a 2-slice warm-up step): {ts[8]:.1f} s and {ts[4]:.1f} s; the slice-wise encoders are linear "
-                          f"in the slice count, so one knee at 160 slices = t(4) + 156 x (t(8) - t(4)) / 4 = {t160:.0f} s",
-                "measured_s": {"slices_8": round(ts[8], 2), "slices_4": round(ts[4], 2)}, "extrapolated_s_per_knee": round(t160, 1)}
+                          f"threads with {hi} and with {lo} of the 160 slices per MRI at the full 384x384 / 310x310 sizes (one train "
+                          f"step each, after a 2-slice warm-up step): {ts[hi]:.1f} s and {ts[lo]:.1f} s; the slice-wise encoders are "
+                          f"linear in the slice count, so one knee at 160 slices = t({lo}) + {160 - lo} x (t({hi}) - t({lo})) / {hi - lo} "
+                          f"= {t160:.0f} s",
+                "measured_s": {f"slices_{hi}": round(ts[hi], 2), f"slices_{lo}": round(ts[lo], 2)},
+                "extrapolated_s_per_knee": round(t160, 1),
+                "one_thread_footnote": {"value": round(1.0 / t160_1, 6), "unit": "knees/s", "cores": 1,
+                                        "why": "the reference ships OMP_NUM_THREADS=1 (train_prog_fus.py:7-9)",
+                                        "measured_s": {"slices_2": round(t1[2], 2), "slices_1": round(t1[1], 2)},
+                                        "extrapolated_s_per_knee": round(t160_1, 1)}}
     cfg, _, _ = workload_cfg(workload)
     om, xs, y = _oracle_job(lambda: cfg, 1)
     om.train_step(xs, y)                     # warm-up
@@ -348,6 +367,7 @@ def main(args):
         torch.cuda.synchronize()
 
     comm_ms = []
+    jobs_ddp = []
 
     def make_job(name, batch, recompute="auto"):
         """model + optimizer + resident synthetic batch of one workload -> (cfg, B, policy, step)"""
@@ -357,6 +377,8 @@ def main(args):
         model = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None).to(dev)
         policy = apply_recompute(model, rdef if (recompute == "auto" and B >= bdef) else ("none" if recompute == "auto" else recompute))
         ddp = DataParallelRCCL(model, exchange_always=dist_on)
+        ddp.time_exposed = dist_on
+        jobs_ddp.append(ddp)
         loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
         opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=bool(args.graph))
         xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(dict(cfg, input_size=shapes) if shapes else cfg, B, seed=1234 + rank)]
@@ -387,11 +409,7 @@ def main(args):
             loss = loss_fn(input=logits.squeeze(1), target=y.long().squeeze(1))
             ddp.scale_loss(loss).backward()
             if dist_on:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                ddp.reduce_gradients()
-                e1.record()
-                comm_ms.append((e0, e1))
+                ddp.reduce_gradients()      # (time_exposed: events around the compute stream's waits on the collectives)
             opt.step()
             return loss.item()          # (see the module docstring: `host_sync`)
         return cfg, B, policy, step
@@ -401,7 +419,8 @@ def main(args):
         for _ in range(warmup):
             step()
         barrier()
-        del comm_ms[:]
+        for d in jobs_ddp:
+            d.exposed_ms()              # (drop the warm-up steps' brackets)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
         evs[0].record()
@@ -434,8 +453,10 @@ def main(args):
     dt, lv, per = timed(step, args.warmup, args.steps)
     hbm_gb = (round(torch.cuda.max_memory_allocated() / 2**30, 1), round(torch.cuda.max_memory_reserved() / 2**30, 1))
     comm_exposed = None
-    if dist_on and comm_ms:
-        comm_exposed = round(statistics.mean(a.elapsed_time(b) for a, b in comm_ms), 3)
+    if dist_on:
+        comm_ms = jobs_ddp[0].exposed_ms()
+        if comm_ms:
+            comm_exposed = round(statistics.mean(comm_ms), 3)
 
     if args.graph:
         if rank == 0:
@@ -541,7 +562,9 @@ def main(args):
                                    + ("inference pass (forward + softmax), " if args.workload == "eval3"
                                       else "train step (fwd+FocalLoss+bwd+Adam), ") +
                                    f"per-GPU batch {B}, global batch {world * B}, " + WORKLOAD_TEXT.get(args.workload, "random-init weights"),
-                       "parallelism": f"dp{world}", "last_loss": round(lv, 6), "activation_recompute": policy,
+                       "parallelism": f"dp{world}", "last_loss": round(lv, 6),
+                       "activation_recompute": policy + (" (fallback: the default policy 012,012,01 ran out of memory on this box; "
+                                                         "retried once in a fresh process)" if os.environ.get("KOAF_BENCH_OOM_RETRY") else ""),
                        "hbm_peak_gib": {"allocated": hbm_gb[0], "reserved": hbm_gb[1]}},
             "rccl_ranks": rccl_ranks, "comm_exposed_ms": comm_exposed,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak_mix, 1),
@@ -580,8 +603,56 @@ def main(args):
         torch.distributed.destroy_process_group()
 
 
+OOM_EXIT = 42
+FALLBACK_POLICY = "012,012,012"     # rebuild layer1-3 of every MRI encoder: ~25 GB less at the peak for ~2 % of the step
+
+
+def is_oom(e):
+    import torch
+    return isinstance(e, torch.cuda.OutOfMemoryError) or "out of memory" in str(e).lower()
+
+
+def fallback_allowed(args):
+    """the headline run with its default policy, not already a retry"""
+    return args.workload == "syn3" and args.recompute == "auto" and not args.batch and not os.environ.get("KOAF_BENCH_OOM_RETRY")
+
+
+def fallback_argv(argv):
+    return list(argv) + ["--recompute", FALLBACK_POLICY]
+
+
+def launch_with_fallback(args, argv, program=None):
+    """start the ranks; if one of them ran out of memory on the headline's default policy, ONE more launch with the leaner one"""
+    rc = launch_workers(args.gpus, argv, program=program)
+    if rc != 0 and OOM_EXIT in LAST_WORKER_CODES and fallback_allowed(args):
+        print(f"bench.py: a rank ran out of memory with the default recompute policy: one retry with {FALLBACK_POLICY}", file=sys.stderr)
+        os.environ["KOAF_BENCH_OOM_RETRY"] = "1"
+        try:
+            rc = launch_workers(args.gpus, fallback_argv(argv), program=program)
+        finally:
+            del os.environ["KOAF_BENCH_OOM_RETRY"]
+    return rc
+
+
 if __name__ == "__main__":
     _args = parse_args()
     if _args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_workers(_args.gpus, sys.argv[1:]))
-    main(_args)
+        sys.exit(launch_with_fallback(_args, sys.argv[1:]))
+    try:
+        main(_args)
+        sys.exit(0)
+    except Exception as _e:  # noqa: BLE001
+        if not is_oom(_e):
+            raise
+        print(f"bench.py: out of memory: {str(_e)[:300]}", file=sys.stderr)
+        if "WORLD_SIZE" in os.environ or not fallback_allowed(_args):
+            sys.exit(OOM_EXIT)          # (a rank of a launcher: the parent decides; its peers are torn down)
+    # 1 GPU, default policy: ONE retry with the leaner policy in a FRESH child process (this process only frees what it holds
+    # and waits; it is never re-executed), named in config.activation_recompute of the child's line
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
+    print(f"bench.py: retrying once with --recompute {FALLBACK_POLICY} in a fresh process", file=sys.stderr)
+    _env = dict(os.environ, KOAF_BENCH_OOM_RETRY="1")
+    sys.exit(subprocess.call([sys.executable, str(Path(__file__).resolve())] + fallback_argv(sys.argv[1:]), env=_env))

@@ -40,6 +40,8 @@ class DataParallelRCCL(nn.Module):
         self._seen = []
         self._streams = None       # per bucket: the HIP streams its gradients were delivered on this step
         self._comm = None          # staging stream the early all-reduces are ordered on
+        self.time_exposed = False  # bench: bracket the compute stream's waits on the collectives with events
+        self._exposed = []
 
     # -- setup -------------------------------------------------------------------------------------
     def arena(self):
@@ -143,9 +145,29 @@ class DataParallelRCCL(nn.Module):
             for bi, pend in enumerate(self._pending):
                 if pend:
                     self._launch(bi)
+        # exposed communication = how long the caller's (compute) stream sits in these waits: an event when it arrives at
+        # the first wait (everything it had to compute is done by then) and one after the last (read by exposed_ms())
+        timed = self.time_exposed and a.G.is_cuda and self._handles
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in self._handles:
             h.wait()             # the caller's stream waits for the collectives (which ran behind the staging stream)
+        if timed:
+            e1.record()
+            self._exposed.append((e0, e1))
         self._handles = []
+
+    def exposed_ms(self, reset=True):
+        """per-step milliseconds the compute stream waited for gradient collectives since the last call (needs
+        `time_exposed = True`; synchronises on the recorded events)"""
+        out = []
+        for e0, e1 in self._exposed:
+            e1.synchronize()
+            out.append(e0.elapsed_time(e1))
+        if reset:
+            self._exposed = []
+        return out
 
     # module protocol pass-throughs used by the train driver / checkpoint handler
     def state_dict(self, *a, **k):
@@ -153,3 +175,41 @@ class DataParallelRCCL(nn.Module):
 
     def load_state_dict(self, *a, **k):
         return self.module.load_state_dict(*a, **k)
+
+
+def shard_sampler(weights, rank, world, seed, num_samples=None, batch_size=None, drop_last=True):
+    """This rank's share of ONE global `WeightedRandomSampler` stream (SURVEY 8e "one-time": per-rank data shards from one
+    global sampler; reference: koafusion/datasets/_data_provider.py:463-483 builds
+    `WeightedRandomSampler(weights, num_samples=len(weights), replacement=True)` for the single-process DataParallel run).
+
+    Every rank draws the SAME index sequence (torch.multinomial on a generator seeded with `seed`: call again with
+    seed + epoch for the next epoch) and keeps its slice, so that the union over ranks is exactly the sequence a
+    single-process run would have consumed:
+      * batch_size given (the PER-RANK batch): global batch g = indices [g*B*world, (g+1)*B*world), of which this rank takes the
+        contiguous block [rank*B, (rank+1)*B) -- DataParallel's scatter of the global batch along dim 0; with drop_last (the
+        reference's train loaders, :483) the ragged tail that cannot fill a global batch is dropped, so all ranks run the
+        same number of steps;
+      * batch_size None: the strided slice stream[rank::world] (truncated to equal lengths under drop_last).
+    Returns a list of python ints to hand to `DataLoader(sampler=...)` / `Subset`."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    w = torch.as_tensor(weights, dtype=torch.double)
+    n = int(num_samples) if num_samples is not None else int(w.numel())
+    g = torch.Generator()
+    g.manual_seed(int(seed))
+    stream = torch.multinomial(w, n, replacement=True, generator=g).tolist()     # what WeightedRandomSampler.__iter__ draws
+    if batch_size is None:
+        if drop_last:
+            stream = stream[:n - n % world]
+        return stream[rank::world]
+    gb = int(batch_size) * world
+    full = n // gb
+    out = []
+    for b in range(full):
+        lo = b * gb + rank * batch_size
+        out.extend(stream[lo:lo + batch_size])
+    if not drop_last and n % gb:
+        tail = stream[full * gb:]
+        per = -(-len(tail) // world)
+        out.extend(tail[rank * per:(rank + 1) * per])
+    return out

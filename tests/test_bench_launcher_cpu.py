@@ -57,6 +57,32 @@ def test_launcher_tears_down_survivors_of_a_dead_rank(tmp_path, capfd):
     assert "terminated" in capfd.readouterr().err
 
 
+OOM = """
+import json, os, sys
+r = int(os.environ["RANK"])
+if "--recompute" not in sys.argv:
+    sys.exit(42 if r == 1 else 0)                  # rank 1 runs out of memory on the default policy
+assert os.environ.get("KOAF_BENCH_OOM_RETRY") == "1"
+if r == 0:
+    print(json.dumps({"argv": sys.argv[1:]}))
+"""
+
+
+def test_launcher_retries_once_with_the_lean_policy_after_an_oom(tmp_path, capfd):
+    import bench
+    stub = tmp_path / "oom.py"
+    stub.write_text(OOM)
+    args = bench.parse_args(["--gpus", "2"])
+    rc = bench.launch_with_fallback(args, ["--gpus", "2"], program=str(stub))
+    cap = capfd.readouterr()
+    assert rc == 0 and "one retry with 012,012,012" in cap.err
+    assert json.loads(cap.out.strip().splitlines()[-1])["argv"] == ["--gpus", "2", "--recompute", "012,012,012"]
+    assert "KOAF_BENCH_OOM_RETRY" not in __import__("os").environ
+    args = bench.parse_args(["--gpus", "2", "--recompute", "none"])            # an explicit policy is never overridden
+    assert bench.launch_with_fallback(args, ["--gpus", "2"], program=str(stub)) == 1
+    capfd.readouterr()
+
+
 def test_worker_env_and_defaults():
     import bench
     env = bench.worker_env(3, 8, 12345, base={"X": "1"})

@@ -123,3 +123,29 @@ def test_arena_views_and_adam_ranges():
     assert len(runs) == 1                                                 # contiguous: ONE fused Adam launch
     runs = a.active_ranges([m.conv.weight, m.fc.weight])
     assert len(runs) == 2
+
+
+def test_shard_sampler_slices_one_global_stream():
+    """per-rank data shards from ONE global WeightedRandomSampler stream (_data_provider.py:463-483): the union of
+    the ranks' shards, batch by batch, is the sequence the reference's single-process sampler draws"""
+    from torch.utils.data import WeightedRandomSampler
+    from oaprogressionmmf_amd.parallel import shard_sampler
+    w = torch.tensor([0.1, 0.9, 0.5, 0.5, 2.0, 0.01, 1.0] * 9)           # 63 samples
+    g = torch.Generator().manual_seed(77)
+    glob = list(WeightedRandomSampler(w, num_samples=len(w), replacement=True, generator=g))
+    world, B = 4, 3
+    shards = [shard_sampler(w, r, world, seed=77, batch_size=B) for r in range(world)]
+    steps = len(glob) // (B * world)
+    assert steps == 5 and all(len(s) == steps * B for s in shards)            # drop_last: equal step counts on every rank
+    for b in range(steps):
+        gathered = sum((shards[r][b * B:(b + 1) * B] for r in range(world)), [])    # DataParallel's scatter order
+        assert gathered == glob[b * B * world:(b + 1) * B * world]
+    # without drop_last nothing of the stream is lost
+    all_ = [shard_sampler(w, r, world, seed=77, batch_size=B, drop_last=False) for r in range(world)]
+    assert sorted(sum(all_, [])) == sorted(glob)
+    # strided variant; another epoch = another seed = another stream; bad rank raises
+    st = [shard_sampler(w, r, 2, seed=77) for r in range(2)]
+    assert st[0] == glob[0:62:2] and st[1] == glob[1:62:2]
+    assert shard_sampler(w, 0, world, seed=78, batch_size=B) != shards[0]
+    with pytest.raises(ValueError):
+        shard_sampler(w, 4, 4, seed=0)

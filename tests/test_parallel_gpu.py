@@ -27,15 +27,21 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     import sys
     from pathlib import Path
     here = Path(__file__).resolve().parent
     sys.path.insert(0, str(here))
     sys.path.insert(0, str(here.parent))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # gloo: both ranks share device 0 (the 1-GPU box); nccl (= RCCL): one rank per device, as the driver's multi-GPU runs
+    di = rank if backend == "nccl" else 0
+    torch.cuda.set_device(di)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", di))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import numpy as np
         import procedural as P
@@ -43,7 +49,7 @@ def _worker(rank, world, port, q):
         from oaprogressionmmf_amd.models import dict_models
         from oaprogressionmmf_amd.parallel import DataParallelRCCL
         from oaprogressionmmf_amd.various import dict_losses
-        dev = torch.device("cuda:0")
+        dev = torch.device("cuda", di)
         cfg = P.cfg_xr1mr2(xr=(96, 96), mr1=(64, 64, 3), mr2=(64, 64, 2), depth=1)
         B = 2
         loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
@@ -66,6 +72,7 @@ def _worker(rank, world, port, q):
         want = {k: parts[0][k] + parts[1][k] for k in parts[0]}
         # data-parallel: a small bucket size makes many buckets straddle encoders / streams
         ddp = DataParallelRCCL(make(), bucket_elems=4 * 1024 * 1024)
+        ddp.time_exposed = True
         xs, y = batch(rank)
         bad = {}
         buf0 = {k: b.detach().clone() for k, b in ddp.module.named_buffers()}
@@ -82,6 +89,8 @@ def _worker(rank, world, port, q):
             assert sorted(got) == sorted(want)
             bad[step] = [k for k in want if not torch.equal(got[k], want[k])]
         nb = len(ddp._plan)
+        ex = ddp.exposed_ms()
+        assert len(ex) == 3 and all(v >= 0.0 for v in ex), ex      # one bracket per step around the compute stream's waits
         q.put((rank, None, bad, nb))
     except Exception as e:  # noqa: BLE001
         import traceback
@@ -105,6 +114,27 @@ def test_two_ranks_overlapped_allreduce_is_exact(dev):
         assert err is None, f"rank {rank}:\n{err}"
         assert nb >= 8, f"only {nb} buckets: the plan does not straddle encoders"
         assert all(len(v) == 0 for v in bad.values()), f"rank {rank}: gradients differ from the exchange-free sum: {bad}"
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_ranks_rccl_is_exact():
+    """the same assertion over the real backend: backend "nccl" (= RCCL over xGMI), one rank per device -- the first
+    multi-GPU box proves the collective path (broadcast of the arena, bucketed async all-reduce on the staging stream,
+    waits on the compute stream) bit for bit against the exchange-free sum.  Skipped on 1-GPU boxes."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "nccl")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, err, bad, nb in res:
+        assert err is None, f"rank {rank}:\n{err}"
+        assert nb >= 8
+        assert all(len(v) == 0 for v in bad.values()), f"rank {rank}: RCCL-reduced gradients differ from the exchange-free sum: {bad}"
 
 
 def _rccl_worker(port, q):

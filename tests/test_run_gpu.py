@@ -256,6 +256,35 @@ def test_graphed_train_step_replay_is_bit_identical_to_eager(dev):
         assert torch.equal(p0[k], p1[k]), k
 
 
+def test_eager_eval_between_replayed_steps_sees_the_current_weights(dev):
+    """replay, eval, replay, eval == the same sequence run eagerly: a replayed optimizer step rewrites the arena weights on
+    the device, so the eager forward after it must rebuild the convolution weight plane images (the host-side stamp is
+    invalidated after every replay) instead of multiplying with the images cut at the start of the last replay"""
+    from oaprogressionmmf_amd.run import GraphedTrainStep, predict_batch
+    from oaprogressionmmf_amd.various import dict_losses, dict_optimizers
+    cfg = P.cfg_full(xr=(96, 96), mr1=(64, 64, 6), mr2=(64, 64, 5), depth=1, dropout=0.0)
+    B = 2
+    xs = [t(a).to(dev) for a in P.model_inputs(cfg, B, 13)]
+    ys = t(P.make_target("target", B, 13)).to(dev)
+    loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
+    runs = []
+    for warmup in (100, 1):                              # all eager / captured at the second train call
+        m = build(cfg, dev).train()
+        opt = dict_optimizers["Adam"](m.parameters(), lr=5e-3, weight_decay=1e-4, capturable=True)   # (large steps: stale weights show)
+        step = GraphedTrainStep(m, loss_fn, opt, xs, ys, warmup=warmup, seed=7)
+        evals = []
+        for it in range(4):
+            m.train()
+            step(xs, ys)
+            m.eval()
+            evals.append(predict_batch(m, xs)[0].clone())
+        assert (step.graph is not None) == (warmup == 1)
+        runs.append(evals)
+    for it, (a, b) in enumerate(zip(*runs)):
+        assert torch.equal(a, b), (it, a, b)
+    assert not torch.equal(runs[0][2], runs[0][3])        # the weights (and with them the eval logits) do move per step
+
+
 def test_graphed_train_step_dropout_masks_follow_the_device_counter(dev):
     """the same call site draws a different mask after every begin_step() and the same mask within a step (forward and
     backward regenerate it from (salt, epoch)); without a step state the host-drawn seed path is unchanged"""
