@@ -39,6 +39,23 @@
 //       Double-buffered: the DMA of k-tile t+1 lands while tile t is multiplied.
 #include "koaf_common.h"
 
+// In-kernel phase stamps (diagnostic builds only: make STAMPS=1 -> libkoaf_stamps.so, scripts/stamps_*.py): thread 0 of every
+// block adds the 100 MHz real-time counter differences between its phase boundaries to a device table.
+#ifdef KOAF_STAMPS
+// (64 replicas of the table, indexed by block id: the adds of ~10^5 tiles per launch must not queue on eight addresses; the
+// stamps themselves are wave-uniform s_memrealtime reads kept in scalar registers, consumed only at the end of the tile)
+__device__ unsigned long long koaf_stamp_tab[64][8];
+#define KOAF_STAMP_DECL unsigned long long kst_[6] = {0, 0, 0, 0, 0, 0}
+#define KOAF_STAMP(i) do { kst_[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define KOAF_STAMP_ADD(slot, a, b) do { if (threadIdx.x == 0 && kst_[b] >= kst_[a]) atomicAdd(&koaf_stamp_tab[blockIdx.x & 63][slot], kst_[b] - kst_[a]); } while (0)
+#define KOAF_STAMP_ACC(slot, v) do { if (threadIdx.x == 0) atomicAdd(&koaf_stamp_tab[blockIdx.x & 63][slot], (unsigned long long)(v)); } while (0)
+#else
+#define KOAF_STAMP_DECL
+#define KOAF_STAMP(i)
+#define KOAF_STAMP_ADD(slot, a, b)
+#define KOAF_STAMP_ACC(slot, v)
+#endif
+
 namespace {
 
 constexpr int BK = 32;
@@ -123,7 +140,7 @@ __host__ __device__ constexpr bool mode_is_pa(int m) { return m == M_PA1 || m ==
 // 4 waves with ONE halo buffer in under 80 KiB, so that two blocks share a CU and one's prologue, chunk switch and epilogue
 // run under the other's MFMAs (the shallow-K layers: 64 channels = two chunks, where those phases outweigh the k-loop).
 __host__ __device__ constexpr int halo_max_w(int bn, int bm = 256) { return bm == 256 ? (bn == 64 ? 96 : 64) : (bn == 64 ? 96 : 48); }
-__host__ __device__ constexpr int halo_b_stages(int bn, int bm = 256) { return bn == 64 ? 4 : 3; }
+__host__ __device__ constexpr int halo_b_stages(int bn, int bm = 256) { return bm == 256 ? 3 : (bn == 64 ? 4 : 3); }
 
 // TF = transform on load (KoafOperand.tf): 0 none; 1 relu(sc[c] * x + sh[c]) -- the producer's BatchNorm + ReLU; 2 the
 // BatchNorm-BACKWARD apply dc = sc[c] * dz + sh[c] - sc2[c] * c_raw of TWO source tensors (x = dz at ptr, c_raw at ptr2, same
@@ -887,6 +904,8 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
     constexpr int SMEM = (OPS > C_ELEMS) ? OPS : C_ELEMS;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
+    KOAF_STAMP_DECL;
+    KOAF_STAMP(0);
     const int ntn = (p.N + BN - 1) / BN;
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MiB L2): without a remap the ntn blocks that
     // share an A row tile land on ntn different L2s and the tile is fetched from beyond L2 ntn times.  Bijective remap:
@@ -970,6 +989,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
         if (kbeg < kend) la.issue(la.sa, p.A, Ap, kbeg, kend, z1);      // the first tile's A loads
     }
     for (;;) {      // the tiles of this block (one, unless PERSIST)
+    KOAF_STAMP(0);
     v16f acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1032,7 +1052,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
         // nine.  Taps that fall off the image (the raster neighbour is then another row or image) are zeroed in the
         // fragment registers by per-row validity bits.  k runs (chunk, tap, channel); the weight tile of every (chunk, tap)
         // step is double-buffered as in the loops above, the next chunk's halo arrives in ninths under the nine tap steps.
-        static_assert(!HDB || 2 * HP_MAX <= 9 * NW, "the next halo is spread over the nine tap steps, one piece per wave and step");
+        static_assert(!HDB || 2 * HP_MAX <= 14 * NW, "the next halo is spread over seven tap steps, at most two pieces per wave and step");
         constexpr int NPB = BN / 16;                        // 1-KiB pieces of a weight plane tile
         constexpr int BPW = (2 * NPB + NW - 1) / NW;        // weight pieces per wave and step
         const int Wd = p.A.W, Hd = p.A.H, CSa = p.A.CS, Ca = p.A.C;
@@ -1082,6 +1102,110 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
                     lds_dma16(Bpl + bsrc[j] + koff, buf + (idx / NPB) * (B_PL * 4) + (idx % NPB) * 1024);
             }
         };
+        if constexpr (HDB) {
+        // 256-row shape.  Software pipeline over the steps s = (chunk, tap):
+        //   * weight tiles: three LDS stages; tile s + 3 is issued at step s into the stage tile s leaves;
+        //   * fragments: the registers of step s + 1 are read from LDS DURING the MFMAs of step s (two register sets,
+        //     ping-pong), so the matrix pipe never waits for an LDS read burst -- with one barrier per step all eight waves
+        //     used to read, then multiply, in lockstep, and the k-loop ran at half the matrix rate;
+        //   * the next chunk's halo arrives under taps 0..6 of the current chunk (its first fragments are read at tap 8);
+        //   * waits are counted (loads retire in order): barrier(s) needs tile s + 1, issued two steps earlier, and lets
+        //     everything issued since stay in flight -- no drain at chunk boundaries.
+        static_assert(NBB == 3, "three weight-tile stages");
+        typedef const __attribute__((address_space(3))) v4i* lds_v4i;
+        typedef const __attribute__((address_space(3))) unsigned* lds_u;
+        constexpr int NST = 7;                              // taps that carry pieces of the next halo
+        const int nh = (np2 + NW - 1) / NW;                 // halo pieces per wave and chunk
+        const int hq = nh / NST, hr = nh - hq * NST;        // pieces at tap t < NST: hq + (t < hr)   (<= 2: np2 <= 14 NW)
+        const int nstep = 9 * nchunk;
+        struct Frags { v4i a[2][TM][2]; v4i b[2][TN][2]; };
+        auto load_frags = [&](Frags& f, int tap, int hbuf, int stage) {
+            const lds_u Ah = (lds_u)smem + hbuf * A_ELEMS;
+            const lds_u Bu = (lds_u)smem + NBA * A_ELEMS + stage * B_ELEMS;
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const int shift = flip ? (1 - kh) * Wd + (1 - kw) : (kh - 1) * Wd + (kw - 1);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int hp = i0[i] + shift;
+                    const int off = hp * 16 + 4 * ((2 * g + h) ^ ((hp >> 2) & 3));
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) f.a[g][i][q] = *(lds_v4i)&Ah[q * A_PL + off];
+                }
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    const int brow = wn * WN + 32 * jn + (lane & 31);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        f.b[g][jn][q] = *(lds_v4i)&Bu[q * B_PL + brow * 16 + 4 * ((2 * g + h) ^ ((brow >> 2) & 3))];   // = frag_load_ps
+                }
+            }
+        };
+        auto compute = [&](Frags& f, int tap) {
+            constexpr int PAH[3] = {1, 0, 0}, PBH[3] = {0, 1, 0};
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                v4i ap[TM][2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int okm = -(int)((vb[i] >> tap) & 1u);       // all ones / zero: the tap's validity as an AND mask
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) ap[i][q] = and_mask(f.a[g][i][q], okm);
+                }
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                    for (int term = 0; term < 3; ++term)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ap[i][PAH[term]]),
+                                                                                __builtin_bit_cast(h16x8, f.b[g][jn][PBH[term]]),
+                                                                                acc[i][jn], 0, 0, 0);
+            }
+        };
+        for (int idx = w; idx < np2; idx += NW) issue_halo(idx, 0, sm0);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) issue_b(d, 0, sb0 + d * (B_ELEMS * 4));       // (nstep >= 9)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * BPW) : "memory");             // halo 0 and tile 0 have landed
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        KOAF_STAMP(1);
+        Frags F0, F1;
+        load_frags(F0, 0, 0, 0);
+        int tap = 0, chunk = 0, sb = 0;     // this step; sb = stage of its weight tile
+        int itap = 3, ich = 0;              // (tap, chunk) of tile s + 3
+        int hk = 0, hprev = 0;              // halo pieces of the next chunk issued so far / loads per wave at the previous step
+        auto body = [&](Frags& cur, Frags& nxt, bool has_next) {
+            // tile s + 1 (issued at step s - 2, the last loads of that step) has landed; what step s - 1 issued stays in flight
+            if (hprev == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW) : "memory");
+            else if (hprev == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW + 2) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (and every wave holds the fragments of step s)
+            const bool more_chunks = chunk + 1 < nchunk;
+            const int hc = (more_chunks && tap < NST) ? hq + (tap < hr ? 1 : 0) : 0;
+            const unsigned Anext = sm0 + ((chunk + 1) & 1) * (A_ELEMS * 4);
+            if (hc > 0) { const int idx = hk * NW + w; issue_halo(idx < np2 ? idx : np2 - 1, chunk + 1, Anext); ++hk; }
+            if (hc > 1) { const int idx = hk * NW + w; issue_halo(idx < np2 ? idx : np2 - 1, chunk + 1, Anext); ++hk; }
+            hprev = hc;
+            // tile s + 3 into the stage tile s leaves (past the end: re-fetch the last tile there -- nobody reads it, the counts stay uniform)
+            issue_b(ich < nchunk ? itap : 8, ich < nchunk ? ich : nchunk - 1, sb0 + sb * (B_ELEMS * 4));
+            if (++itap == 9) { itap = 0; ++ich; }
+            int ntap = tap + 1, nch2 = chunk;
+            if (ntap == 9) { ntap = 0; ++nch2; hk = 0; }
+            if (++sb == 3) sb = 0;
+            if (has_next) load_frags(nxt, ntap, nch2 & 1, sb);
+            compute(cur, tap);
+            tap = ntap; chunk = nch2;
+        };
+#pragma unroll 1
+        for (int s2 = 0; s2 + 1 < nstep; s2 += 2) {
+            body(F0, F1, true);
+            body(F1, F0, s2 + 2 < nstep);
+        }
+        if (nstep & 1) body(F0, F1, false);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the surplus fetches behind the last step)
+        __syncthreads();       // the epilogue reuses the operand buffers
+        } else {
         // Pipeline: the weight tile of step s + D (D = NBB - 1 steps ahead) and one halo piece of the NEXT chunk are issued
         // at step s; loads retire in order, so "the tile of step s has landed" is a counted wait that leaves the younger
         // loads in flight.  Only the first tap of a chunk drains everything (its halo was completed by the previous step).
@@ -1104,10 +1228,18 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 // in flight behind this step's tile: D - 1 younger tiles (BPW loads each) and, inside a chunk, D halo pieces
-                if (tap == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (tap == 0) {
+                    KOAF_STAMP(4);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 else if (HDB && more_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * BPW + (D < 9 ? D : 9)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * BPW) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (tap == 0) {
+                    KOAF_STAMP(5);
+                    KOAF_STAMP_ADD(5, 4, 5);          // exposed wait for a chunk's halo (+ barrier skew)
+                    if (chunk == 0) KOAF_STAMP(1);
+                }
                 {
                     int sd = sb + D;
                     if (sd >= NBB) sd -= NBB;
@@ -1164,6 +1296,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the surplus fetches behind the last step)
         __syncthreads();       // the epilogue reuses the operand buffers
+        }
     } else if constexpr (WPS) {
         // weight gradient: both K-major operands by LDS-DMA, double-buffered, one barrier per k-tile (as below)
         if (kbeg < kend) {
@@ -1171,6 +1304,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
             wkb.issue(p.B, Bpl, kbeg, kend, sb0);
         }
         int cur = 0;
+        KOAF_STAMP(1);
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if ((k0 + BK) < kend) {
@@ -1190,6 +1324,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
             lp.template issue<NPL>(p.B, Bpl, sb0);
         }
         int cur = 0;
+        KOAF_STAMP(1);
         for (int k0 = kbeg; k0 < kend; k0 += BK) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if ((k0 + BK) < kend) {
@@ -1216,6 +1351,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
     }
     __syncthreads();
     int cur = 0;
+    KOAF_STAMP(1);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = (k0 + BK) < kend;
         // the next tile's global loads go out first: in flight under this tile's MFMAs (the DMA into the other B buffer,
@@ -1262,6 +1398,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
     }
 
     // ---- epilogue ----
+    KOAF_STAMP(2);
     float* Cp;
     int64_t ldc;
     const bool slab = p.splitk > 1;
@@ -1304,6 +1441,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
                     Cs[(wm * WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC_S + wn * WN + 32 * jn + r] = v;
                 }
         __syncthreads();
+        KOAF_STAMP(3);
         constexpr int C4 = BN / 4;
         constexpr int RPP = NT / C4;           // rows per pass
         const int c4 = t % C4, rr = t / C4;
@@ -1444,6 +1582,13 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
             st[p.stats_ld + n0 + t] = a2;
         }
     }
+    KOAF_STAMP(4);
+    KOAF_STAMP_ADD(0, 0, 1);      // prologue (entry -> first k-step ready); only the halo loop sets stamp 1
+    KOAF_STAMP_ADD(1, 1, 2);      // k-loop
+    KOAF_STAMP_ADD(2, 2, 3);      // accumulators -> LDS staging
+    KOAF_STAMP_ADD(3, 3, 4);      // stores / fused reductions / statistics
+    KOAF_STAMP_ADD(4, 0, 4);      // whole tile
+    KOAF_STAMP_ACC(7, 1);         // tiles
     if (!has_next) break;
     // on to this block's next tile (PERSIST only): its A loads are in flight; the LDS is free once every wave is here
     __syncthreads();
@@ -1945,6 +2090,23 @@ extern "C" int koaf_act_planes(const float* x, const float* x2, int64_t npix, in
     else hipLaunchKernelGGL(act_planes_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, x, x2, n8, C, sc, sh, sc2, amax, fscale, planes, ps);
     return koaf_check_launch("koaf_act_planes");
 }
+
+#ifdef KOAF_STAMPS
+// out[8] = {prologue, k-loop, staging, stores, tile, chunk waits, -, tiles} summed over blocks, in 10 ns ticks; reset: zero the table
+extern "C" int koaf_debug_stamps(unsigned long long* out, int reset) {
+    static unsigned long long h[64][8];
+    if (hipDeviceSynchronize() != hipSuccess) return KOAF_ELAUNCH;
+    if (out) {
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(koaf_stamp_tab), sizeof(h)) != hipSuccess) return KOAF_ELAUNCH;
+        for (int k = 0; k < 8; ++k) { out[k] = 0; for (int r = 0; r < 64; ++r) out[k] += h[r][k]; }
+    }
+    if (reset) {
+        for (int r = 0; r < 64; ++r) for (int k = 0; k < 8; ++k) h[r][k] = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(koaf_stamp_tab), h, sizeof(h)) != hipSuccess) return KOAF_ELAUNCH;
+    }
+    return KOAF_OK;
+}
+#endif
 
 extern "C" int koaf_set_conv3x3_halo(int on) {
     const int was = g_halo_mode;
