@@ -594,6 +594,7 @@ def main(args):
                          "step_gflop_per_sample_survey": algorithmic_train_gflop_per_sample(args.workload),
                          "step_tflops_algorithmic": round(algorithmic_train_gflop_per_sample(args.workload) * value / 1e3 / world, 1)},
         }
+        out["numerics"] = ops.numerics_status()       # clamped activations / non-finite operand scales over the whole run: must be 0 / 0
         if secondary:
             out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:

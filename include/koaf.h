@@ -26,14 +26,28 @@ extern "C" {
 #define KOAF_EINVAL (-1)
 #define KOAF_ELAUNCH (-2)
 
-int koaf_version(void);          /* 100 * major + 10 * minor: 140 = this header */
+int koaf_version(void);          /* 100 * major + 10 * minor: 150 = this header */
 const char* koaf_last_error(void);
+/* Numerics status words: a device uint32[4] (zeroed by the caller; NULL = off, the default) that kernels bump with atomics when
+ *   [0] an activation operand left the fp16 range of the fixed activation scale and was CLAMPED (KOAF_ACT_SCALE: |x| > 4094), or
+ *       was not finite: counted per element by koaf_act_planes / koaf_bn_add_relu / koaf_bn_relu / koaf_maxpool_fwd (the
+ *       producers of every tensor the convolutions read at that scale), and per GEMM tile by the fp32 loader that applies
+ *       relu(sc*x+sh) on load (KoafOperand.tf 1; there a NaN becomes 0 and is not counted -- the BatchNorm coefficients are, [1]);
+ *   [1] a NaN / Inf reached an operand's amax scalar (weights, gradients: the GEMM then returns NaN everywhere, see KoafGemm)
+ *       or a BatchNorm's sc / sh came out non-finite (koaf_bn_finalize).
+ * Process-wide (one process per GPU); read it back with a device-to-host copy whenever convenient (e.g. once per epoch). */
+int koaf_set_status_buffer(uint32_t* dev4);
 
 /* ---------------------------------------------------------------------------------------------
  * Generic MFMA GEMM  C[M,N] = alpha * sum_k A(m,k) B(n,k)  (+bias[n]) (+residual[m,n])
  * fp32 in / fp32 out / fp32 accumulate.  Products are formed on the bf16 matrix pipe from exact bf16 pieces of the
  * fp32 operands (KoafGemm.fmt: three bf16 pieces / six products, or two scaled fp16 pieces / three products): error at
- * fp32 rounding level either way.  An Inf operand yields NaN; NaN stays NaN.
+ * fp32 rounding level either way.  Non-finite operands: fmt 0 -- an Inf operand yields NaN, NaN stays NaN.  fmt 1 -- the
+ * scaled pieces are clamped to +-65504 (a NaN piece becomes the lower clamp bound), so a non-finite ELEMENT does not
+ * propagate by itself; instead (a) operands scaled by a device amax (weights, gradients) carry their NaN / Inf into that
+ * scalar (all amax reductions propagate non-finite values) and a GEMM that finds a non-finite amax returns NaN in EVERY
+ * output element, and (b) activation operands at the fixed scale are watched by the numerics status words
+ * (koaf_set_status_buffer): clamped / non-finite elements are counted, non-finite BatchNorm coefficients too.
  * Each operand is either K-contiguous ("KC": element (r,k) at ptr + r*ld + k) or K-major
  * ("KM": element (r,k) at ptr + k*ld + r).  Operands can be gathered on the fly from an NHWC
  * tensor (implicit-GEMM convolution) and transformed on load with relu(sc[c]*x+sh[c]) -- the
@@ -140,6 +154,7 @@ typedef struct KoafGemm {
        sum (v - k)^2 (NULL: k = 0).  With k near the column mean -- the BatchNorm's running mean -- the variance
        E[(v-k)^2] - E[v-k]^2 keeps its digits when |mean| >> std. */
     const float* stats_shift;
+    uint32_t* status;      /* numerics status words (koaf_set_status_buffer); NULL = the registered buffer */
 } KoafGemm;
 
 int koaf_gemm(const KoafGemm* g, void* stream);

@@ -101,6 +101,7 @@ class KoafGemm(ctypes.Structure):
         ("m_base", ctypes.c_int32),
         ("part_row0", ctypes.c_int32),
         ("stats_shift", ctypes.c_void_p),
+        ("status", ctypes.c_void_p),
     ]
 
 
@@ -149,6 +150,7 @@ _SCALARS = {
     "int32_t": ctypes.c_int32,
     "int64_t": ctypes.c_int64,
     "uint64_t": ctypes.c_uint64,
+    "uint32_t": ctypes.c_uint32,
     "float": ctypes.c_float,
 }
 

@@ -42,21 +42,42 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// Raise the device scalar *slot (a non-negative float, zeroed beforehand) to the block's maximum of v: one atomic per BLOCK,
-// and none at all once the slot already holds a value >= the block's (the slot only grows, so a stale read can cost a
-// redundant atomic but never lose a maximum).  Float bits of non-negative values order like unsigned integers; a NaN
-// compares above every finite value and poisons the slot on purpose.  All threads of the block must call it.
-__device__ __forceinline__ void block_amax_raise(float v, float* slot) {
-    __shared__ float koaf_amax_red[16];
-    v = wave_max(v);
+// |x| as an unsigned integer: orders like the magnitude for finite values, +Inf above every finite value and every NaN above
+// +Inf -- an integer maximum over these bits PROPAGATES non-finite values, which fmaxf (IEEE maxNum: a NaN operand is dropped)
+// does not.  All "largest magnitude of a tensor" reductions run on these bits, so a NaN / Inf anywhere in an operand reaches
+// its amax scalar, and the GEMM that scales by that amax turns its whole output into NaN (koaf_gemm.hip) instead of clamping
+// the value away.
+__device__ __forceinline__ unsigned koaf_absbits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+__device__ __forceinline__ bool koaf_bits_finite(unsigned absbits) { return absbits < 0x7f800000u; }
+__device__ __forceinline__ unsigned wave_max_u(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = v > w ? v : w; }
+    return v;
+}
+
+// Raise the device scalar *slot (a non-negative float, zeroed beforehand) to the block's maximum of the magnitudes `bits`
+// (koaf_absbits): one atomic per BLOCK, and none at all once the slot already holds a value >= the block's (the slot only
+// grows, so a stale read can cost a redundant atomic but never lose a maximum).  A NaN / Inf compares above every finite value
+// and poisons the slot on purpose.  All threads of the block must call it.
+__device__ __forceinline__ void block_amax_raise_bits(unsigned bits, float* slot) {
+    __shared__ unsigned koaf_amax_red[16];
+    bits = wave_max_u(bits);
     const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    if ((threadIdx.x & 63) == 0) koaf_amax_red[w] = v;
+    if ((threadIdx.x & 63) == 0) koaf_amax_red[w] = bits;
     __syncthreads();
     if (threadIdx.x == 0) {
-        float m = koaf_amax_red[0];
-        for (int i = 1; i < nw; ++i) m = fmaxf(m, koaf_amax_red[i]);
-        const unsigned bits = __float_as_uint(m);
-        if (bits > __hip_atomic_load(reinterpret_cast<unsigned*>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(reinterpret_cast<unsigned*>(slot), bits);
+        unsigned m = koaf_amax_red[0];
+        for (int i = 1; i < nw; ++i) m = m > koaf_amax_red[i] ? m : koaf_amax_red[i];
+        if (m > __hip_atomic_load(reinterpret_cast<unsigned*>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(reinterpret_cast<unsigned*>(slot), m);
     }
+}
+__device__ __forceinline__ void block_amax_raise(float v, float* slot) { block_amax_raise_bits(koaf_absbits(v), slot); }
+
+// ---- numerics status words (koaf.h koaf_set_status_buffer): device uint32[4] registered by the host, or NULL -------------
+//   [0] activation-operand elements / tiles that left the fp16 range of the fixed activation scale (clamped) or were not finite
+//   [1] non-finite operand scales (a NaN / Inf in a weight or gradient tensor) and non-finite BatchNorm coefficients
+uint32_t* koaf_status_ptr();
+__device__ __forceinline__ void koaf_status_add(uint32_t* st, int slot, unsigned n) {
+    if (st != nullptr && n != 0u) atomicAdd(&st[slot], n);
 }

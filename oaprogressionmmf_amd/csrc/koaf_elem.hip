@@ -16,7 +16,10 @@ void koaf_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* koaf_last_error(void) { return g_err; }
-extern "C" int koaf_version(void) { return 140; }   // 1.4: activation plane images (koaf_act_planes; x_planes / dy_planes of the conv entry points; KoafOperand.kind 2 | 3 on the A side)
+static uint32_t* g_status = nullptr;
+uint32_t* koaf_status_ptr() { return g_status; }
+extern "C" int koaf_set_status_buffer(uint32_t* dev4) { g_status = dev4; return KOAF_OK; }
+extern "C" int koaf_version(void) { return 150; }   // 1.4: activation plane images (koaf_act_planes; x_planes / dy_planes of the conv entry points; KoafOperand.kind 2 | 3 on the A side)
 
 namespace {
 
@@ -179,7 +182,8 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const T* __restrict__
                                                            const float* __restrict__ beta, float* running_mean,
                                                            float* running_var, int64_t* nbt, float momentum,
                                                            float eps, int train, float* mean, float* invstd,
-                                                           float* sc, float* sh, const float* __restrict__ shift) {
+                                                           float* sc, float* sh, const float* __restrict__ shift,
+                                                           uint32_t* status) {
     __shared__ double red[2][16][64];
     const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
@@ -217,6 +221,9 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const T* __restrict__
         invstd[c] = is;
         sc[c] = g * is;
         sh[c] = b - m * g * is;
+        // a NaN / Inf in the conv output reaches the statistics, and from there every element of the channel: say so (the
+        // consumers' fp16 clamp would turn relu(NaN * x + NaN) into 0)
+        if (!koaf_bits_finite(koaf_absbits(g * is)) || !koaf_bits_finite(koaf_absbits(b - m * g * is))) koaf_status_add(status, 1, 1u);
     }
     if (train && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
 }
@@ -226,7 +233,8 @@ __global__ void __launch_bounds__(256) bn_add_relu_kernel(const float* __restric
                                                           const float* __restrict__ sh, const float* __restrict__ idt,
                                                           const float* __restrict__ idsc,
                                                           const float* __restrict__ idsh, float* __restrict__ y,
-                                                          int64_t nvec, int C4) {
+                                                          int64_t nvec, int C4, uint32_t* status) {
+    unsigned nsat = 0;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * EB) {
         const int cv = (int)(i % C4) * 4;
         v4f v = __builtin_nontemporal_load((const v4f*)&c[i * 4]);       // (streams: read / written once, kept out of L2's way)
@@ -237,9 +245,15 @@ __global__ void __launch_bounds__(256) bn_add_relu_kernel(const float* __restric
             v += d;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        for (int j = 0; j < 4; ++j) {
+            // (this tensor feeds convolutions at the fixed activation scale: |y| * KOAF_ACT_SCALE beyond the fp16 range is
+            // clamped there -- counted here, where the check is free; a NaN counts too and stays a NaN in y)
+            nsat += !(v[j] * KOAF_ACT_SCALE <= 65504.f) ? 1u : 0u;
+            v[j] = v[j] != v[j] ? v[j] : fmaxf(v[j], 0.f);
+        }
         __builtin_nontemporal_store(v, (v4f*)&y[i * 4]);
     }
+    koaf_status_add(status, 0, nsat);
 }
 
 // BN backward pass 1: masked gradient + column partials of dz and dz*xhat
@@ -251,7 +265,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
                                                             float* __restrict__ dz_out, int64_t rows, int C,
                                                             ColGeom geo, float* __restrict__ part, float* dz_amax) {
     const int t = threadIdx.x, cvx = t % geo.CV, ry = t / geo.CV;
-    float am = 0.f;
+    unsigned am = 0u;       // largest |dz| as magnitude bits (a NaN / Inf wins: koaf_common.h)
     const int c0 = blockIdx.y * geo.CW + 4 * cvx;
     const int64_t rbeg = (int64_t)blockIdx.x * geo.rpb;
     const int64_t rend = min(rows, rbeg + (int64_t)geo.rpb);
@@ -274,10 +288,11 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
         if (dz_out) *(v4f*)&dz_out[o] = gv;
         s[0] += gv;
         s[1] += gv * ((cvv - mu) * is);
-        am = fmaxf(fmaxf(am, fmaxf(fabsf(gv[0]), fabsf(gv[1]))), fmaxf(fabsf(gv[2]), fabsf(gv[3])));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) am = max(am, koaf_absbits(gv[j]));
     }
     col_block_reduce<2>(s, part, blockIdx.x, C, blockIdx.y * geo.CW, geo.CV, geo.RP);
-    if (dz_amax) block_amax_raise(am, dz_amax);
+    if (dz_amax) block_amax_raise_bits(am, dz_amax);
 }
 
 template <typename T>
@@ -326,7 +341,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ coef, float* __restrict__ dc,
                                                            int64_t nvec, int C, float* __restrict__ amax) {
     const int C4 = C / 4;
-    float m = 0.f;
+    unsigned m = 0u;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * EB) {
         const int cv = (int)(i % C4) * 4;
         v4f z = *(const v4f*)&dz[i * 4];
@@ -335,10 +350,11 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
         v4f mu = *(const v4f*)&mean[cv];
         const v4f o = k0 * (z - k1) - k2 * (x - mu);
         *(v4f*)&dc[i * 4] = o;
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = max(m, koaf_absbits(o[j]));
     }
     // max |dc| of the tensor: the scale of dc as an operand of the fp16 contraction scheme
-    if (amax) block_amax_raise(m, amax);
+    if (amax) block_amax_raise_bits(m, amax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -449,8 +465,9 @@ __global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ 
 __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restrict__ c, const float* __restrict__ sc,
                                                           const float* __restrict__ sh, float* __restrict__ y,
                                                           uint8_t* __restrict__ am, int N, int H, int W, int C,
-                                                          int OH, int OW) {
+                                                          int OH, int OW, uint32_t* status) {
     const int C4 = C / 4;
+    unsigned nsat = 0;
     const int64_t total = (int64_t)N * OH * OW * C4;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
         const int cv = (int)(i % C4) * 4;
@@ -478,9 +495,12 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restric
                 }
             }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nsat += !(best[j] * KOAF_ACT_SCALE <= 65504.f) ? 1u : 0u;    // (as in bn_add_relu_kernel)
         *(v4f*)&y[i * 4] = best;
         *(uint32_t*)&am[i * 4] = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
     }
+    koaf_status_add(status, 0, nsat);
 }
 
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ am,
@@ -924,11 +944,11 @@ extern "C" int koaf_bn_finalize(const float* stats, int32_t rows, int32_t C, int
     if (S)
         hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, ws, S, C, inv, unbias,
                            gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, train, mean,
-                           invstd, sc, sh, train ? shift : nullptr);
+                           invstd, sc, sh, train ? shift : nullptr, koaf_status_ptr());
     else
         hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, stats, rows, C, inv,
                            unbias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, train,
-                           mean, invstd, sc, sh, train ? shift : nullptr);
+                           mean, invstd, sc, sh, train ? shift : nullptr, koaf_status_ptr());
     return koaf_check_launch("koaf_bn_finalize");
 }
 
@@ -939,7 +959,7 @@ extern "C" int koaf_bn_add_relu(const float* c, const float* sc, const float* sh
     KOAF_REQUIRE((idsc == nullptr) == (idsh == nullptr), "koaf_bn_add_relu: idsc/idsh come together");
     const int64_t nvec = rows * (C / 4);
     hipLaunchKernelGGL(bn_add_relu_kernel, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, c, sc, sh, idt, idsc, idsh, y,
-                       nvec, C / 4);
+                       nvec, C / 4, koaf_status_ptr());
     return koaf_check_launch("koaf_bn_add_relu");
 }
 extern "C" int koaf_bn_relu(const float* c, const float* sc, const float* sh, float* y, int64_t rows, int32_t C,
@@ -1014,7 +1034,7 @@ extern "C" int koaf_maxpool_fwd(const float* c, const float* sc, const float* sh
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const int64_t nvec = (int64_t)N * OH * OW * (C / 4);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, c, sc, sh, y, argmax, N, H, W, C,
-                       OH, OW);
+                       OH, OW, koaf_status_ptr());
     return koaf_check_launch("koaf_maxpool_fwd");
 }
 extern "C" int koaf_maxpool_bwd(const float* dy, const uint8_t* argmax, float* da, int32_t N, int32_t H, int32_t W,

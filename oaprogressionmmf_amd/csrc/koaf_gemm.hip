@@ -163,6 +163,7 @@ struct TileLoader {
     Slot sa, sb;
     v4f kts4, kth4, ktk4;    // transform coefficients of this thread's columns (KM operands: fixed)
     float fsc;               // F16: operand scale (a power of two)
+    unsigned satmax;         // F16, TF 1: packed maximum of the fp16 hi pieces stored so far (0x7bff = clamped at 65504)
     // KC state (ext-vector values, not arrays: arrays of per-unit state were left in scratch by hipcc and
     // every scratch reload drained the in-flight global loads through the in-order vmcnt)
     v4l base;          // element offset of each unit's row / image from the operand pointer
@@ -187,6 +188,7 @@ struct TileLoader {
     __device__ __forceinline__ void init(const KoafOperand& op, int r0, int R, int z1, float scale) {
         const int t = threadIdx.x;
         fsc = scale;
+        satmax = 0u;
         sa.vm = sb.vm = 0;
         sa.ts4 = sa.th4 = sb.ts4 = sb.th4 = kts4 = kth4 = sa.tk4 = sb.tk4 = ktk4 = (v4f){0.f, 0.f, 0.f, 0.f};
         rvm = cvm = 0;
@@ -481,7 +483,7 @@ struct TileLoader {
     }
 
     template <int NPL>
-    __device__ __forceinline__ void store(const Slot& s, float* Sf) const {
+    __device__ __forceinline__ void store(const Slot& s, float* Sf) {
         unsigned* S = (unsigned*)Sf;
         constexpr int P = plane_dwords(ROWS, KC);
 #pragma unroll
@@ -489,6 +491,16 @@ struct TileLoader {
             unsigned pl[NPL][2];
             if constexpr (F16) split2h(s.r[i], pl);
             else split3v(s.r[i], pl);
+            if constexpr (F16 && TF == 1 && KC) {
+                // saturation watch of the fixed activation scale: behind the ReLU the hi pieces are non-negative fp16, whose
+                // bits order like the values -- one packed 16-bit maximum per two elements; a tile that reached 65504 (0x7bff)
+                // clamped something (koaf.h koaf_set_status_buffer)
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+                    satmax = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, satmax),
+                                                                                     __builtin_bit_cast(u16x2, pl[0][d])));
+            }
             const int off = plane_off(i);
 #pragma unroll
             for (int q = 0; q < NPL; ++q) *(uint2*)&S[q * P + off] = make_uint2(pl[q][0], pl[q][1]);
@@ -861,7 +873,7 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
                 q2 += v * ((cv[u] - mu) * is);
                 if constexpr (HAS_C2) q3 += v * ((c2v[u] - mu2) * is2);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) qm[j] = fmaxf(qm[j], fabsf(v[j]));
+                for (int j = 0; j < 4; ++j) qm[j] = __uint_as_float(max(__float_as_uint(qm[j]), koaf_absbits(v[j])));
             }
             __builtin_nontemporal_store(v, (v4f*)(Cp + orow * ldc + col));
         }
@@ -945,7 +957,16 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
     // operand scales of the fp16 scheme (powers of two; 1 otherwise): applied on load, divided out in the epilogue
     const float sca = F16 ? operand_scale(p.A) : 1.f;
     const float scb = F16 ? operand_scale(p.B) : 1.f;
-    const float alpha = F16 ? p.alpha / (sca * scb) : p.alpha;
+    float alpha = F16 ? p.alpha / (sca * scb) : p.alpha;
+    if constexpr (F16) {
+        // a NaN / Inf anywhere in an operand reaches its amax scalar (the reductions propagate them, koaf_common.h); the pieces
+        // themselves are clamped to the fp16 range, so the whole OUTPUT is made NaN here: a diverged run shows as one
+        const bool bad = (p.A.amax && !koaf_bits_finite(koaf_absbits(*p.A.amax))) || (p.B.amax && !koaf_bits_finite(koaf_absbits(*p.B.amax)));
+        if (bad) {
+            alpha = __uint_as_float(0x7fc00000u);
+            if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) koaf_status_add(p.status, 1, 1u);
+        }
+    }
 
     const float* Ap = (APS || AH || WPS) ? nullptr : p.A.ptr + z0 * p.A.bs0 + z1 * p.A.bs1;
     const unsigned short* Apl = (APS || AH || WPS) ? p.A.planes + z0 * p.A.bs0 + z1 * p.A.bs1 : nullptr;
@@ -1397,6 +1418,10 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
         }
     }
 
+    if constexpr (F16 && TFA == 1 && AKC && !APS && !AH && !WPS) {
+        if (((la.satmax & 0xffffu) >= 0x7bffu) | ((la.satmax >> 16) >= 0x7bffu)) koaf_status_add(p.status, 0, 1u);
+        la.satmax = 0u;
+    }
     // ---- epilogue ----
     KOAF_STAMP(2);
     float* Cp;
@@ -1448,7 +1473,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
         const int col = n0 + 4 * c4;
         const bool bnb = (p.bnb_mode != 0) && !slab;
         v4f q1 = {0.f, 0.f, 0.f, 0.f}, q2 = q1, q3 = q1;   // fused BN-backward column sums of this thread's rows
-        v4f qm = q1;                                       // and the largest |dz| it stored (KoafGemm.bnb_amax)
+        v4f qm = q1;                                       // and the largest |dz| it stored (KoafGemm.bnb_amax), as magnitude bits
         if (col < p.N) {                         // N % 4 == 0 on this path
             v4f bv = {0.f, 0.f, 0.f, 0.f};
             if (bias) bv = *(const v4f*)(bias + col);
@@ -1503,7 +1528,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
                         q1 += v;
                         q2 += v * ((cv - mu) * is);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) qm[j] = fmaxf(qm[j], fabsf(v[j]));
+                        for (int j = 0; j < 4; ++j) qm[j] = __uint_as_float(max(__float_as_uint(qm[j]), koaf_absbits(v[j])));
                         if (p.bnb2_c) {
                             const v4f c2 = *(const v4f*)(p.bnb2_c + orow * ldc + col);
                             q3 += v * ((c2 - mu2) * is2);
@@ -1514,7 +1539,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
             }
         }
         if (bnb) {
-            if (p.bnb_amax) block_amax_raise(fmaxf(fmaxf(qm[0], qm[1]), fmaxf(qm[2], qm[3])), p.bnb_amax);
+            if (p.bnb_amax) block_amax_raise_bits(max(max(__float_as_uint(qm[0]), __float_as_uint(qm[1])), max(__float_as_uint(qm[2]), __float_as_uint(qm[3]))), p.bnb_amax);
             // column sums over the block's rows: RPP row-threads per column vector -> LDS -> one partial row
             __syncthreads();                     // Cs fully consumed
             v4f* red4 = reinterpret_cast<v4f*>(smem);   // [3][RPP][C4]
@@ -1815,6 +1840,7 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     KOAF_REQUIRE((g.A.kind >= 2 ? (const void*)g.A.planes : (const void*)g.A.ptr) &&
                  (g.B.kind >= 2 ? (const void*)g.B.planes : (const void*)g.B.ptr) && g.C, "koaf_gemm: null operand");
     fill_defaults(g);
+    if (!g.status) g.status = koaf_status_ptr();
     KOAF_REQUIRE(!g.cmap || (g.splitk == 1 && !g.stats), "koaf_gemm: row map excludes split-K / stats");
     KOAF_REQUIRE(!g.bnb_mode || (g.splitk == 1 && !g.stats && g.nb0 * g.nb1 == 1 && g.bnb_c && g.bnb_mean &&
                                  g.bnb_invstd && g.bnb_part && (g.bnb_mode == 1 ? g.bnb_y != nullptr
@@ -1958,8 +1984,7 @@ __global__ void __launch_bounds__(256) wplanes_amax_kernel(const float* __restri
     const WTile w = wtile_of_block(tab, ntab);
     const int t = threadIdx.x;
     const v4f x = wtile_load(base, w, w.rt * 32 + (t >> 3), w.ct * 32 + 4 * (t & 7));
-    float m = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
-    block_amax_raise(m, amax + w.idx);
+    block_amax_raise_bits(max(max(koaf_absbits(x[0]), koaf_absbits(x[1])), max(koaf_absbits(x[2]), koaf_absbits(x[3]))), amax + w.idx);
 }
 
 // pass 2: the images of w * scale_of_amax(amax[i]) (split2h: bit-identical to the in-kernel split of the same operand)
@@ -2038,8 +2063,10 @@ template <int TF>
 __global__ void __launch_bounds__(256) act_planes_kernel(const float* __restrict__ x, const float* __restrict__ x2, int64_t n8,
                                                          int C, const float* __restrict__ sc, const float* __restrict__ sh,
                                                          const float* __restrict__ sc2, const float* __restrict__ amax,
-                                                         float fscale, unsigned short* __restrict__ planes, int64_t ps) {
+                                                         float fscale, unsigned short* __restrict__ planes, int64_t ps,
+                                                         uint32_t* status) {
     constexpr float HMAX = 65504.f;
+    unsigned nsat = 0;      // elements beyond the fp16 range of the scale (clamped below) or not finite
     const float fsc = amax ? scale_of_amax(*amax) : (fscale != 0.f ? fscale : 1.f);
     if (blockIdx.x == 0 && threadIdx.x == 0) *(uint4*)(planes + 2 * ps) = make_uint4(0u, 0u, 0u, 0u);   // the zero chunk
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
@@ -2051,16 +2078,28 @@ __global__ void __launch_bounds__(256) act_planes_kernel(const float* __restrict
             if constexpr (TF == 1) {
                 const v4f a = *(const v4f*)(sc + c + 4 * hf) * fsc, b = *(const v4f*)(sh + c + 4 * hf) * fsc;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(fmaf(v[j], a[j], b[j]), 0.f, HMAX);
+                for (int j = 0; j < 4; ++j) {
+                    const float u = fmaf(v[j], a[j], b[j]);
+                    nsat += !(u <= HMAX) ? 1u : 0u;
+                    v[j] = __builtin_amdgcn_fmed3f(u, 0.f, HMAX);
+                }
             } else if constexpr (TF == 2) {
                 const v4f a = *(const v4f*)(sc + c + 4 * hf) * fsc, b = *(const v4f*)(sh + c + 4 * hf) * fsc;
                 const v4f k = *(const v4f*)(sc2 + c + 4 * hf) * fsc;
                 const v4f w = *(const v4f*)(x2 + i * 8 + 4 * hf);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(fmaf(a[j], v[j], fmaf(-k[j], w[j], b[j])), -HMAX, HMAX);
+                for (int j = 0; j < 4; ++j) {
+                    const float u = fmaf(a[j], v[j], fmaf(-k[j], w[j], b[j]));
+                    nsat += !(fabsf(u) <= HMAX) ? 1u : 0u;
+                    v[j] = __builtin_amdgcn_fmed3f(u, -HMAX, HMAX);
+                }
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j] * fsc, -HMAX, HMAX);
+                for (int j = 0; j < 4; ++j) {
+                    const float u = v[j] * fsc;
+                    nsat += !(fabsf(u) <= HMAX) ? 1u : 0u;
+                    v[j] = __builtin_amdgcn_fmed3f(u, -HMAX, HMAX);
+                }
             }
             split2h(v, pl[hf]);
         }
@@ -2068,6 +2107,7 @@ __global__ void __launch_bounds__(256) act_planes_kernel(const float* __restrict
         for (int q = 0; q < 2; ++q)
             *(uint4*)(planes + q * ps + i * 8) = make_uint4(pl[0][q][0], pl[0][q][1], pl[1][q][0], pl[1][q][1]);
     }
+    koaf_status_add(status, 0, nsat);
 }
 }  // namespace
 
@@ -2085,9 +2125,9 @@ extern "C" int koaf_act_planes(const float* x, const float* x2, int64_t npix, in
     int64_t blocks = cdiv64(n8, 256);
     if (blocks > 16384) blocks = 16384;
     hipStream_t s = (hipStream_t)stream;
-    if (tf == 0) hipLaunchKernelGGL(act_planes_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, x, x2, n8, C, sc, sh, sc2, amax, fscale, planes, ps);
-    else if (tf == 1) hipLaunchKernelGGL(act_planes_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, x, x2, n8, C, sc, sh, sc2, amax, fscale, planes, ps);
-    else hipLaunchKernelGGL(act_planes_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, x, x2, n8, C, sc, sh, sc2, amax, fscale, planes, ps);
+    if (tf == 0) hipLaunchKernelGGL(act_planes_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, x, x2, n8, C, sc, sh, sc2, amax, fscale, planes, ps, koaf_status_ptr());
+    else if (tf == 1) hipLaunchKernelGGL(act_planes_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, x, x2, n8, C, sc, sh, sc2, amax, fscale, planes, ps, koaf_status_ptr());
+    else hipLaunchKernelGGL(act_planes_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, x, x2, n8, C, sc, sh, sc2, amax, fscale, planes, ps, koaf_status_ptr());
     return koaf_check_launch("koaf_act_planes");
 }
 

@@ -62,8 +62,48 @@ def _ptr(t):
     return t.data_ptr()
 
 
+_STATUS = None       # device int32[4]: the library's numerics status words (koaf.h koaf_set_status_buffer)
+
+
 def _stream():
+    if _STATUS is None:
+        _status_buffer()
     return torch.cuda.current_stream().cuda_stream
+
+
+def _status_buffer():
+    """register (once per process = per GPU) the status words every kernel launch may bump"""
+    global _STATUS
+    if _STATUS is None:
+        _STATUS = torch.zeros(4, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        check(lib().koaf_set_status_buffer(_STATUS.data_ptr()), "set_status_buffer")
+    return _STATUS
+
+
+def numerics_status(reset=False):
+    """{"saturated": ..., "nonfinite": ...} since the last reset (one small device-to-host copy: call it per epoch, not per step).
+    saturated: activation elements (or GEMM tiles holding some) that left the fp16 range of the fixed activation scale
+    (|x| > 4094) and were clamped, or were not finite; nonfinite: NaN / Inf that reached an operand's scale scalar (the GEMM
+    then returned NaN everywhere) or a BatchNorm's coefficients."""
+    st = _status_buffer()
+    v = st.cpu().tolist()
+    if reset:
+        st.zero_()
+    return {"saturated": int(v[0]) & 0xffffffff, "nonfinite": int(v[1]) & 0xffffffff}
+
+
+def check_numerics(reset=True):
+    """numerics_status() + a RuntimeWarning when anything was flagged; returns the status dict"""
+    import warnings
+    st = numerics_status(reset=reset)
+    if st["saturated"]:
+        warnings.warn(f"koaf: {st['saturated']} activation elements / tiles exceeded the fixed activation scale's range (|x| > 4094 behind "
+                      f"a BatchNorm) and were clamped in the convolution operands: results are no longer at fp32 rounding level",
+                      RuntimeWarning, stacklevel=2)
+    if st["nonfinite"]:
+        warnings.warn(f"koaf: non-finite values reached {st['nonfinite']} operand scales / BatchNorm coefficients (a diverged run)",
+                      RuntimeWarning, stacklevel=2)
+    return st
 
 
 def _img(wimg):

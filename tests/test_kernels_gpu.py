@@ -677,3 +677,70 @@ def test_bn_backward_apply_formed_in_the_gemm_loaders(dev, N, H, W, Cin, Cout, k
 
 
 
+
+
+def test_numerics_status_words_saturation_and_nonfinite(dev):
+    """The fp16 contraction scheme clamps its scaled pieces to +-65504: behind the FIXED activation scale 16 an activation
+    beyond 4094 saturates, and a NaN piece becomes a clamp bound.  Neither may stay silent (koaf.h koaf_set_status_buffer):
+    (1) saturated activations are counted by every producer / loader of a fixed-scale operand;
+    (2) a NaN in a weight or gradient reaches that operand's amax scalar and the GEMM returns NaN everywhere;
+    (3) non-finite BatchNorm coefficients are counted.  Healthy inputs flag nothing."""
+    from oaprogressionmmf_amd import ops
+    N, H, W, Cin, Cout = 2, 12, 12, 64, 128
+    rows = N * H * W
+    x = rnd(N, H, W, Cin).to(dev)
+    w1 = rnd(Cout, 1, 1, Cin, scale=0.1).to(dev)
+    w3 = rnd(Cout, 3, 3, Cin, scale=0.05).to(dev)
+    img1, img3 = ops.build_weight_planes(w1, Cout, 1, Cin), ops.build_weight_planes(w3, Cout, 9, Cin)
+    sc, sh = torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)
+    ops.numerics_status(reset=True)
+    y_ok, _ = ops.conv2d_fwd(x, w1, N, H, W, Cin, Cout, 1, 1, 1, 0, sc, sh, wimg=img1)
+    ops.conv2d_fwd(x, w3, N, H, W, Cin, Cout, 3, 3, 1, 1, sc, sh, wimg=img3)
+    saved = torch.stack([torch.zeros(Cin), torch.ones(Cin), torch.ones(Cin), torch.zeros(Cin)]).to(dev)
+    ops.bn_add_relu(x, saved, rows, Cin, idt=x)
+    assert ops.numerics_status() == {"saturated": 0, "nonfinite": 0}
+    # (1) relu(5000 * x) passes 4094 for about 40 % of the elements
+    big = torch.full((Cin,), 5000.0, device=dev)
+    y_sat, _ = ops.conv2d_fwd(x, w1, N, H, W, Cin, Cout, 1, 1, 1, 0, big, sh, wimg=img1)       # fp32 loader: per tile
+    s1 = ops.numerics_status(reset=True)
+    assert s1["saturated"] > 0 and s1["nonfinite"] == 0 and torch.isfinite(y_sat).all()
+    ops.conv2d_fwd(x, w3, N, H, W, Cin, Cout, 3, 3, 1, 1, big, sh, wimg=img3)                  # plane images: per element
+    s2 = ops.numerics_status(reset=True)
+    n_over = int((torch.relu(x * 5000.0) > 4094.0).sum())
+    assert s2["saturated"] == n_over, (s2, n_over)
+    saved_big = saved.clone()
+    saved_big[2] = 5000.0
+    yb = ops.bn_add_relu(x, saved_big, rows, Cin)                                               # the bottleneck tail's output
+    s3 = ops.numerics_status(reset=True)
+    assert s3["saturated"] == int((yb > 4094.0).sum()) > 0
+    with pytest.warns(RuntimeWarning, match="clamped"):
+        ops.bn_add_relu(x, saved_big, rows, Cin)
+        ops.check_numerics()
+    assert ops.numerics_status() == {"saturated": 0, "nonfinite": 0}                           # check_numerics() resets
+    # (2) one NaN in a weight: its plane images carry a NaN amax, every output element of the convolution is NaN
+    wn = w1.clone()
+    wn[3, 0, 0, 5] = float("nan")
+    imgn = ops.build_weight_planes(wn, Cout, 1, Cin)
+    assert torch.isnan(imgn[2]).all()
+    yn, _ = ops.conv2d_fwd(x, wn, N, H, W, Cin, Cout, 1, 1, 1, 0, sc, sh, wimg=imgn)
+    assert torch.isnan(yn).all() and ops.numerics_status(reset=True)["nonfinite"] >= 1
+    # ... and one Inf in a gradient: max |dz| -> the bound of |dc| -> the data gradient
+    g = rnd(N, H, W, Cout, scale=1e-3).to(dev)
+    g[1, 2, 3, 4] = float("inf")
+    c = rnd(N, H, W, Cout).to(dev)
+    gam, bet = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+    rm, rv, nbt = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+    sv = ops.bn_finalize(ops.colstats(c, rows, Cout), Cout, rows, gam, bet, rm, rv, nbt, 0.1, 1e-5, True)
+    dg, db = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
+    ap = ops.bn_bwd(g, c, sv, rows, Cout, rows, dg, db, 0, fused=True)
+    assert not torch.isfinite(ap.amax).all()
+    dx = ops.conv2d_dgrad(ap, w1, N, H, W, Cin, Cout, 1, 1, 1, 0, wimg=img1)
+    assert torch.isnan(dx).all() and ops.numerics_status(reset=True)["nonfinite"] >= 1
+    # (3) a NaN in a conv output poisons its channel's statistics: the BatchNorm coefficients are counted
+    cn = c.clone()
+    cn[0, 0, 0, 7] = float("nan")
+    ops.bn_finalize(ops.colstats(cn, rows, Cout), Cout, rows, gam, bet, rm.clone(), rv.clone(), nbt, 0.1, 1e-5, True)
+    assert ops.numerics_status(reset=True)["nonfinite"] == 1
+    # healthy again
+    y2, _ = ops.conv2d_fwd(x, w1, N, H, W, Cin, Cout, 1, 1, 1, 0, sc, sh, wimg=img1)
+    assert torch.equal(y2, y_ok) and ops.numerics_status() == {"saturated": 0, "nonfinite": 0}
