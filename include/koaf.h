@@ -155,6 +155,13 @@ typedef struct KoafGemm {
        E[(v-k)^2] - E[v-k]^2 keeps its digits when |mean| >> std. */
     const float* stats_shift;
     uint32_t* status;      /* numerics status words (koaf_set_status_buffer); NULL = the registered buffer */
+    /* bf16 ACTIVATION STORAGE: which tensors of this call are forward activations kept in HBM as bf16 instead of fp32 (the
+       pointers stay typed float*; strides / offsets count elements).  0: none.  1 (forward convolution): A.ptr and C -- the
+       loader widens (exact), the epilogue rounds the output to nearest even; statistics come from the fp32 accumulators.
+       2 (data gradient): A.ptr2 (the conv output c of a tf-2 apply) and bnb_c / bnb_y / bnb2_c.  3 (weight gradient): A.ptr2
+       and B.ptr.  Gradients, weights, statistics and all arithmetic stay fp32; needs the vector path. */
+    int32_t act16;
+    int32_t _pad5;
 } KoafGemm;
 
 int koaf_gemm(const KoafGemm* g, void* stream);
@@ -202,7 +209,7 @@ int koaf_wplanes_build(const float* base, uint16_t* planes, float* amax, const K
 int koaf_set_conv3x3_halo(int on);
 int64_t koaf_act_planes_elems(int64_t npix, int32_t C);
 int koaf_act_planes(const float* x, const float* x2, int64_t npix, int32_t C, int32_t tf, const float* sc, const float* sh,
-                    const float* sc2, const float* amax, float fscale, uint16_t* planes, void* stream);
+                    const float* sc2, const float* amax, float fscale, uint16_t* planes, int32_t act16, void* stream);
 /* what the convolution entry points take for a weight whose images are current (all device pointers) */
 typedef struct KoafWImg {
     const uint16_t* f;      /* F image or NULL */
@@ -217,6 +224,19 @@ typedef struct KoafBnApply {
     const float* coef;
     const float* amax;
 } KoafBnApply;
+
+/* ---- bf16 ACTIVATION STORAGE (`act16` of the entry points below; BASELINE.json config 2 "bf16") -------------------
+ * A trunk may keep its FORWARD ACTIVATIONS -- stem / conv outputs, block outputs, max-pool output -- in HBM as bf16 instead of
+ * fp32: half the bytes on every HBM-bound call, half the memory saved for backward.  act16 != 0 says that the activation tensors
+ * among a call's arguments (named at each entry point) are bf16 behind their float* type; everything else stays fp32: weights,
+ * BatchNorm statistics and coefficients, every gradient, all accumulation and all arithmetic -- a kernel widens the bf16 values
+ * on load (exact), computes exactly as in the fp32 mode, and only a producer's store rounds (to nearest even).  It is a storage
+ * mode, selected per model (config key `activation_storage: bf16`, default fp32), reported by bench.py as a named secondary
+ * with its measured error against the fp32 mode; the parity gate (1e-3 of the reference) is the fp32 mode's.
+ * Activation arguments per entry point: koaf_conv2d_fwd / koaf_gconv3x3_fwd x, y; koaf_conv2d_dgrad(_bnb) dy_apply->c and
+ * bnb->c / y / c2; koaf_conv2d_wgrad / koaf_gconv3x3_wgrad x and dy_apply->c; koaf_stem_fwd y; koaf_colstats x; koaf_bn_add_relu /
+ * koaf_bn_relu c, idt, y; koaf_bn_bwd_reduce c, ymask; koaf_bn_bwd_apply c; koaf_maxpool_fwd c, y; koaf_gap_fwd y; koaf_act_planes
+ * x (tf 0 / 1) or x2 (tf 2). */
 
 /* ---- Convolution (nn.Conv2d, bias-free; _torchvision.py:23-31) as implicit GEMM on NHWC -------
  * x [N,H,W,Cin], w packed [Cout,KH,KW,Cin] (the memory of a channels_last (Cout,Cin,KH,KW)
@@ -234,7 +254,7 @@ typedef struct KoafBnApply {
 int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W,
                     int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                     const float* in_sc, const float* in_sh, float* stats, int32_t* stats_rows,
-                    const float* stats_shift, const KoafWImg* wimg, const uint16_t* x_planes, void* stream);
+                    const float* stats_shift, const KoafWImg* wimg, const uint16_t* x_planes, int32_t act16, void* stream);
 /* rows of the stats buffer koaf_conv2d_fwd writes for M output pixels */
 int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout);
 /* dx [N,H,W,Cin] = conv_transpose(dy [N,OH,OW,Cout], w) (+residual: the other branch's gradient);
@@ -246,7 +266,7 @@ int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout);
 int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
                       int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride,
                       int32_t pad, const float* residual, const KoafWImg* wimg, const float* dy_amax,
-                      const KoafBnApply* dy_apply, const uint16_t* dy_planes, void* stream);
+                      const KoafBnApply* dy_apply, const uint16_t* dy_planes, int32_t act16, void* stream);
 /* Same, with the BatchNorm(+ReLU) backward reduction of the layer that PRODUCED x fused into the epilogue (see
  * KoafGemm.bnb_*): dx receives the masked gradient dz; part [*part_rows][nsum][Cin] (nsum = 2, or 3 with c2) feeds
  * koaf_bn_bwd_finalize.  koaf_conv2d_dgrad_bnb_rows() bounds *part_rows for sizing. */
@@ -268,7 +288,7 @@ int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx, int32_t N,
                           int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                           const float* residual, const KoafBnb* bnb, float* part, int32_t* part_rows,
                           const KoafWImg* wimg, const float* dy_amax, const KoafBnApply* dy_apply,
-                          const uint16_t* dy_planes, void* stream);
+                          const uint16_t* dy_planes, int32_t act16, void* stream);
 /* dw packed [Cout,KH,KW,Cin] = sum_pixels dy^T x, x optionally transformed on load.  Deterministic
  * split-K: slabs = workspace of koaf_conv2d_wgrad_ws() floats (0 = none needed).  dy_amax (nullable): max |dy| on the
  * device -> fp16 scheme.  dy_planes + x_planes (nullable, together; need dy_amax or dy_apply, Cin % 8 == 0, Cout % 8 == 0):
@@ -280,7 +300,7 @@ int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int32_t N, int
                       int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride,
                       int32_t pad, const float* in_sc, const float* in_sh, float* slabs,
                       const float* dy_amax, const KoafBnApply* dy_apply, const uint16_t* dy_planes,
-                      const uint16_t* x_planes, void* stream);
+                      const uint16_t* x_planes, int32_t act16, void* stream);
 
 /* ---- Grouped 3x3 convolution (ResNeXt 32x4d; _torchvision.py:110,327-330) -------------------
  * Runs on the same MFMA GEMM as 64-channel block-diagonal slabs: packed weights [C][3][3][C/groups]
@@ -289,19 +309,19 @@ int koaf_gconv_expand_w(const float* w, float* wexp, int32_t C, int32_t groups, 
 int koaf_gconv_compress_dw(const float* dwexp, float* dw, int32_t C, int32_t groups, void* stream);
 int koaf_gconv3x3_fwd(const float* x, const float* wexp, float* y, int32_t N, int32_t H, int32_t W,
                       int32_t C, int32_t stride, const float* in_sc, const float* in_sh,
-                      float* stats, int32_t* stats_rows, const float* stats_shift, void* stream);
+                      float* stats, int32_t* stats_rows, const float* stats_shift, int32_t act16, void* stream);
 int koaf_gconv3x3_dgrad(const float* dy, const float* wexp, float* dx, int32_t N, int32_t H,
                         int32_t W, int32_t C, int32_t stride, void* stream);
 int64_t koaf_gconv3x3_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride);
 int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp, int32_t N, int32_t H,
                         int32_t W, int32_t C, int32_t stride, const float* in_sc,
-                        const float* in_sh, float* slabs, void* stream);
+                        const float* in_sh, float* slabs, int32_t act16, void* stream);
 
 /* ---- Stem: 7x7 s2 p3 conv on the 1->3 channel-repeated image (_torchvision.py:170; the
  * `repeat "b ch r c -> b (k ch) r c", k=3` of _xrNmrMcP.py:211-213 is folded: w1t = sum_c w[:,c]).
  * x [N,H,W] (single channel), w1t [49][64], y [N,OH,OW,64].  */
 int koaf_stem_fwd(const float* x, const float* w1t, float* y, int32_t N, int32_t H, int32_t W,
-                  void* stream);
+                  int32_t act16, void* stream);
 int64_t koaf_stem_wgrad_ws(int32_t N, int32_t H, int32_t W);
 int koaf_stem_wgrad(const float* dy, const float* x, float* dw1t, int32_t N, int32_t H, int32_t W,
                     float* slabs, void* stream);
@@ -314,7 +334,7 @@ int koaf_stem_unfold_dw(const float* dw1t, float* dw, void* stream);
  * (koaf_colpart_rows(rows, C) rows), summed about shift[C] (nullable = 0); for producers without a GEMM epilogue
  * (stem). */
 int koaf_colstats(const float* x, int64_t rows, int32_t C, float* part, int32_t* part_rows,
-                  const float* shift, void* stream);
+                  const float* shift, int32_t act16, void* stream);
 int32_t koaf_colpart_rows(int64_t rows, int32_t C);
 /* Bytes of the fp64 workspace `ws` the two finalisations below use to spread a long list of partial rows over
  * the chip (two-stage, fixed-order reduction); 0 = not needed for this row count.  ws may always be NULL
@@ -334,10 +354,10 @@ int koaf_bn_finalize(const float* stats, int32_t rows, int32_t C, int64_t count,
  * (downsample branch BN folded).  Bottleneck tail, _torchvision.py:132-136.  */
 int koaf_bn_add_relu(const float* c, const float* sc, const float* sh, const float* idt,
                      const float* idsc, const float* idsh, float* y, int64_t rows, int32_t C,
-                     void* stream);
+                     int32_t act16, void* stream);
 /* y = relu(sc*c+sh) materialised */
 int koaf_bn_relu(const float* c, const float* sc, const float* sh, float* y, int64_t rows,
-                 int32_t C, void* stream);
+                 int32_t C, int32_t act16, void* stream);
 /* backward reduce: dz = g * mask, partial sums of dz and dz*(c-mean)*invstd.
  * mask_mode 0: none; 1: y>0 from tensor `ymask`; 2: sc*c+sh>0 recomputed.  If dz_out != NULL
  * writes the masked gradient.  part [*part_rows][2][C] (koaf_colpart_rows rows).  dz_amax (nullable): device scalar set to
@@ -345,7 +365,7 @@ int koaf_bn_relu(const float* c, const float* sc, const float* sh, float* y, int
 int koaf_bn_bwd_reduce(const float* g, const float* c, const float* ymask, const float* sc,
                        const float* sh, const float* mean, const float* invstd, int32_t mask_mode,
                        float* dz_out, float* part, int32_t* part_rows, int64_t rows, int32_t C,
-                       float* dz_amax, void* stream);
+                       float* dz_amax, int32_t act16, void* stream);
 /* part [rows][nsum][C] -> dgamma (= sum index i1), dbeta (= sum index 0), and apply coefficients
  * coef [3][C] = {sc, dbeta/M, sc*invstd*dgamma/M}.  (nsum, i1) = (2, 1) for the plain layout.
  * With mean: coef is [4][C], the fourth row = coef2*mean - coef0*coef1, so that dc = coef0*dz + coef3 - coef2*c -- the form
@@ -360,7 +380,7 @@ int koaf_bn_bwd_finalize(const float* part, int32_t part_rows, int32_t C, int64_
 /* dc = coef0*(dz - coef1) - coef2*(c - mean), materialised (consumers that are not GEMMs: the stem's weight gradient; GEMMs
  * without scale information).  amax (nullable): device scalar raised to max |dc| (atomic max; zero it beforehand). */
 int koaf_bn_bwd_apply(const float* dz, const float* c, const float* mean, const float* coef,
-                      float* dc, int64_t rows, int32_t C, float* amax, void* stream);
+                      float* dc, int64_t rows, int32_t C, float* amax, int32_t act16, void* stream);
 
 /* ---- input pipeline on the device (koafusion/preproc/_pt.py; applied per sample by the reference's CPU loader
  * workers, koafusion/datasets/_data_provider.py:295-335) ------------------------------------------------------- */
@@ -382,11 +402,11 @@ int koaf_augment(const float* x, float* y, const float* mm, const float* params,
 
 /* ---- MaxPool2d 3x3 s2 p1 over relu(sc*c+sh) (_torchvision.py:173-174), GAP (:182) ------------ */
 int koaf_maxpool_fwd(const float* c, const float* sc, const float* sh, float* y, uint8_t* argmax,
-                     int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+                     int32_t N, int32_t H, int32_t W, int32_t C, int32_t act16, void* stream);
 /* da [N,H,W,C] (gradient wrt relu(bn(c))) gathered from dy via argmax (every element written) */
 int koaf_maxpool_bwd(const float* dy, const uint8_t* argmax, float* da, int32_t N, int32_t H,
                      int32_t W, int32_t C, void* stream);
-int koaf_gap_fwd(const float* y, float* out, int32_t N, int32_t HW, int32_t C, void* stream);
+int koaf_gap_fwd(const float* y, float* out, int32_t N, int32_t HW, int32_t C, int32_t act16, void* stream);
 int koaf_gap_bwd(const float* dout, float* dy, int32_t N, int32_t HW, int32_t C, void* stream);
 
 /* ---- Input plumbing -------------------------------------------------------------------------- */

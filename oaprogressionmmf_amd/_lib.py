@@ -102,6 +102,8 @@ class KoafGemm(ctypes.Structure):
         ("part_row0", ctypes.c_int32),
         ("stats_shift", ctypes.c_void_p),
         ("status", ctypes.c_void_p),
+        ("act16", ctypes.c_int32),
+        ("_pad5", ctypes.c_int32),
     ]
 
 

@@ -81,3 +81,50 @@ uint32_t* koaf_status_ptr();
 __device__ __forceinline__ void koaf_status_add(uint32_t* st, int slot, unsigned n) {
     if (st != nullptr && n != 0u) atomicAdd(&st[slot], n);
 }
+
+// ---- bf16 activation storage (koaf.h KoafGemm.act16 / the act16 argument of the element-wise entry points): forward
+// activations may live in HBM as bf16; every kernel widens them on load (exact) and computes in fp32; producers round to
+// nearest even on store.  The pointers stay typed float*; offsets count elements.
+typedef __bf16 koaf_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v4f widen_bf16x4(unsigned lo, unsigned hi) {
+    return (v4f){__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+}
+__device__ __forceinline__ uint2 round_bf16x4(v4f v) {
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    const unsigned a = __builtin_bit_cast(unsigned, __builtin_convertvector((v2f_){v[0], v[1]}, koaf_bf16x2));
+    const unsigned b = __builtin_bit_cast(unsigned, __builtin_convertvector((v2f_){v[2], v[3]}, koaf_bf16x2));
+    return make_uint2(a, b);
+}
+template <bool H>
+__device__ __forceinline__ v4f load4_nt(const float* p, int64_t off) {          // streamed once (epilogue operands), widened
+    if constexpr (!H) return __builtin_nontemporal_load((const v4f*)(p + off));
+    else {
+        const unsigned short* q = reinterpret_cast<const unsigned short*>(p) + off;
+        const unsigned lo = __builtin_nontemporal_load((const unsigned*)q), hi = __builtin_nontemporal_load((const unsigned*)q + 1);
+        return widen_bf16x4(lo, hi);
+    }
+}
+template <bool H>
+__device__ __forceinline__ void store4_nt(float* p, int64_t off, v4f v) {
+    if constexpr (!H) __builtin_nontemporal_store(v, (v4f*)(p + off));
+    else {
+        const uint2 u = round_bf16x4(v);
+        unsigned* q = (unsigned*)(reinterpret_cast<unsigned short*>(p) + off);
+        __builtin_nontemporal_store(u.x, q);
+        __builtin_nontemporal_store(u.y, q + 1);
+    }
+}
+
+template <bool H>
+__device__ __forceinline__ v4f load4(const float* p, int64_t off) {             // cached load, widened
+    if constexpr (!H) return *(const v4f*)(p + off);
+    else {
+        const uint2 u = *(const uint2*)(reinterpret_cast<const unsigned short*>(p) + off);
+        return widen_bf16x4(u.x, u.y);
+    }
+}
+template <bool H>
+__device__ __forceinline__ void store4(float* p, int64_t off, v4f v) {
+    if constexpr (!H) *(v4f*)(p + off) = v;
+    else *(uint2*)(reinterpret_cast<unsigned short*>(p) + off) = round_bf16x4(v);
+}

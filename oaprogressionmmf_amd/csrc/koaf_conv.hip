@@ -88,8 +88,14 @@ __device__ __forceinline__ void stem_load_patch(float (*patch)[ST_PW], const flo
     }
 }
 
+// Y16: the output is stored as bf16 (activation storage mode)
+template <bool Y16>
 __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1t,
                                                        float* __restrict__ y, int N, int H, int W, int OH, int OW) {
+    auto put = [&](int64_t idx, float v) {
+        if constexpr (Y16) reinterpret_cast<__bf16*>(y)[idx] = (__bf16)v;
+        else y[idx] = v;
+    };
     __shared__ __attribute__((aligned(16))) float patch[ST_PH][ST_PW];
     const int co = threadIdx.x & 63, pg = threadIdx.x >> 6;
     const int tx = (OW + ST_TW - 1) / ST_TW, ty = (OH + ST_TH - 1) / ST_TH;
@@ -121,8 +127,8 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
         }
         const int ox = ox0 + 2 * q;
         if (oy < OH) {
-            if (ox < OW) y[(((int64_t)n * OH + oy) * OW + ox) * 64 + co] = a0;
-            if (ox + 1 < OW) y[(((int64_t)n * OH + oy) * OW + ox + 1) * 64 + co] = a1;
+            if (ox < OW) put((((int64_t)n * OH + oy) * OW + ox) * 64 + co, a0);
+            if (ox + 1 < OW) put((((int64_t)n * OH + oy) * OW + ox + 1) * 64 + co, a1);
         }
     }
 }
@@ -240,7 +246,7 @@ __global__ void __launch_bounds__(256) gconv_compress_kernel(const float* __rest
 extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W, int32_t Cin,
                                int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, const float* in_sc,
                                const float* in_sh, float* stats, int32_t* stats_rows, const float* stats_shift,
-                               const KoafWImg* wimg, const uint16_t* x_planes, void* stream) {
+                               const KoafWImg* wimg, const uint16_t* x_planes, int32_t act16, void* stream) {
     KOAF_REQUIRE((x || x_planes) && w && y && N > 0 && Cin % 32 == 0 && Cout % 4 == 0, "koaf_conv2d_fwd: bad args (Cin=%d Cout=%d)",
                  Cin, Cout);
     KOAF_REQUIRE((in_sc == nullptr) == (in_sh == nullptr), "koaf_conv2d_fwd: in_sc/in_sh come together");
@@ -273,6 +279,7 @@ extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t
     g.C = y; g.ldc = Cout;
     g.stats = stats;
     g.stats_shift = stats ? stats_shift : nullptr;
+    g.act16 = act16 ? 1 : 0;            // (x and y are bf16 activations)
     if (stats_rows) *stats_rows = koaf_gemm_part_rows(&g);
     return koaf_gemm(&g, stream);
 }
@@ -312,7 +319,7 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
                                      int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                                      const float* residual, const KoafBnb* bnb, float* part, int32_t* part_rows,
                                      const KoafWImg* wimg, const float* dy_amax, const KoafBnApply* dy_apply,
-                                     const uint16_t* dy_planes, void* stream) {
+                                     const uint16_t* dy_planes, int32_t act16, void* stream) {
     KOAF_REQUIRE(!dy_planes || (wimg && wimg->amax && wimg->d && (dy_amax || dy_apply) && KH * KW > 1),
                  "koaf_conv2d_dgrad: dy_planes need the weight's D plane image, dy_amax and a gathered (KH*KW > 1) kernel");
     KOAF_REQUIRE((dy || dy_apply || dy_planes) && w && dx && N > 0 && Cout % 32 == 0 && Cin % 4 == 0, "koaf_conv2d_dgrad: bad args");
@@ -373,6 +380,7 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
                     set_bnb(&g, bnb, part + (int64_t)rows_done * nsum * Cin);
                     rows_done += koaf_gemm_part_rows(&g);
                 }
+                g.act16 = act16 ? 2 : 0;
                 int rc = koaf_gemm(&g, stream);
                 if (rc != KOAF_OK) return rc;
             }
@@ -416,15 +424,16 @@ extern "C" int koaf_conv2d_dgrad_bnb(const float* dy, const float* w, float* dx,
         set_bnb(&g, bnb, part);
         *part_rows = koaf_gemm_part_rows(&g);
     }
+    g.act16 = act16 ? 2 : 0;            // (dy_apply->c and the BatchNorm-backward operands c / y / c2 are bf16 activations)
     return koaf_gemm(&g, stream);
 }
 
 extern "C" int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W,
                                  int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                                  const float* residual, const KoafWImg* wimg, const float* dy_amax,
-                                 const KoafBnApply* dy_apply, const uint16_t* dy_planes, void* stream) {
+                                 const KoafBnApply* dy_apply, const uint16_t* dy_planes, int32_t act16, void* stream) {
     return koaf_conv2d_dgrad_bnb(dy, w, dx, N, H, W, Cin, Cout, KH, KW, stride, pad, residual, nullptr, nullptr,
-                                 nullptr, wimg, dy_amax, dy_apply, dy_planes, stream);
+                                 nullptr, wimg, dy_amax, dy_apply, dy_planes, act16, stream);
 }
 
 extern "C" int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH,
@@ -438,7 +447,7 @@ extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int
                                  int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                                  const float* in_sc, const float* in_sh, float* slabs, const float* dy_amax,
                                  const KoafBnApply* dy_apply, const uint16_t* dy_planes, const uint16_t* x_planes,
-                                 void* stream) {
+                                 int32_t act16, void* stream) {
     KOAF_REQUIRE((dy_planes == nullptr) == (x_planes == nullptr) && (!dy_planes || dy_amax || dy_apply),
                  "koaf_conv2d_wgrad: dy_planes and x_planes come together, with dy_amax (or dy_apply)");
     KOAF_REQUIRE((dy || dy_apply || dy_planes) && (x || x_planes) && dw && N > 0 && Cin % 64 == 0 && Cout % 4 == 0, "koaf_conv2d_wgrad: bad args");
@@ -482,6 +491,7 @@ extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int
     g.bm = p.bm; g.bn = p.bn; g.splitk = p.splitk;
     g.C = p.splitk > 1 ? slabs : dw;
     g.ldc = Ntot;
+    g.act16 = (act16 && !dy_planes) ? 3 : 0;      // (x and dy_apply->c are bf16 activations; plane images carry no storage type)
     int rc = koaf_gemm(&g, stream);
     if (rc != KOAF_OK || p.splitk == 1) return rc;
     return koaf_slab_reduce(slabs, p.splitk, (int64_t)Cout * Ntot, dw, stream);
@@ -505,7 +515,7 @@ extern "C" int koaf_gconv_compress_dw(const float* dwexp, float* dw, int32_t C, 
 
 extern "C" int koaf_gconv3x3_fwd(const float* x, const float* wexp, float* y, int32_t N, int32_t H, int32_t W,
                                  int32_t C, int32_t stride, const float* in_sc, const float* in_sh, float* stats,
-                                 int32_t* stats_rows, const float* stats_shift, void* stream) {
+                                 int32_t* stats_rows, const float* stats_shift, int32_t act16, void* stream) {
     KOAF_REQUIRE(x && wexp && y && N > 0 && C % 64 == 0, "koaf_gconv3x3_fwd: bad args");
     const int OH = conv_out(H, 3, stride, 1), OW = conv_out(W, 3, stride, 1);
     const int64_t M = (int64_t)N * OH * OW;
@@ -525,6 +535,7 @@ extern "C" int koaf_gconv3x3_fwd(const float* x, const float* wexp, float* y, in
     g.bn = 64; g.bm = 128;
     if (stats_rows) *stats_rows = (int)cdiv64(M, g.bm);
     g.A.tf_bs = 64;
+    g.act16 = act16 ? 1 : 0;
     return koaf_gemm(&g, stream);
 }
 
@@ -559,7 +570,7 @@ extern "C" int64_t koaf_gconv3x3_wgrad_ws(int32_t N, int32_t H, int32_t W, int32
 // dwexp [C/64][64][9][64]
 extern "C" int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp, int32_t N, int32_t H, int32_t W,
                                    int32_t C, int32_t stride, const float* in_sc, const float* in_sh, float* slabs,
-                                   void* stream) {
+                                   int32_t act16, void* stream) {
     KOAF_REQUIRE(dy && x && dwexp && slabs && N > 0 && C % 64 == 0, "koaf_gconv3x3_wgrad: bad args");
     const int OH = conv_out(H, 3, stride, 1), OW = conv_out(W, 3, stride, 1);
     const int64_t P = (int64_t)N * OH * OW;
@@ -581,6 +592,7 @@ extern "C" int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp
         g.bm = 64; g.bn = 64; g.splitk = p.splitk;
         g.C = slabs;
         g.ldc = 576; g.cbs1 = 64 * 576;      // (unsplit case; split-K slabs are addressed by the kernel)
+        g.act16 = act16 ? 3 : 0;
         int rc = koaf_gemm(&g, stream);
         if (rc != KOAF_OK) return rc;
     }
@@ -594,12 +606,13 @@ extern "C" int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp
 // stem
 // ================================================================================================
 extern "C" int koaf_stem_fwd(const float* x, const float* w1t, float* y, int32_t N, int32_t H, int32_t W,
-                             void* stream) {
+                             int32_t act16, void* stream) {
     KOAF_REQUIRE(x && w1t && y && N > 0 && H > 0 && W > 0, "koaf_stem_fwd: bad args");
     const int OH = conv_out(H, 7, 2, 3), OW = conv_out(W, 7, 2, 3);
     const int64_t blocks = (int64_t)N * cdiv64(OH, ST_TH) * cdiv64(OW, ST_TW);
     KOAF_REQUIRE(blocks < (1ll << 31), "koaf_stem_fwd: grid too large");
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM, x, w1t, y, N, H, W, OH, OW);
+    if (act16) hipLaunchKernelGGL(stem_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, STREAM, x, w1t, y, N, H, W, OH, OW);
+    else hipLaunchKernelGGL(stem_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, STREAM, x, w1t, y, N, H, W, OH, OW);
     return koaf_check_launch("koaf_stem_fwd");
 }
 static inline int stem_wgrad_blocks(int N, int H, int W) {

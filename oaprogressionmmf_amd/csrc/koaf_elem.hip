@@ -86,6 +86,7 @@ __device__ __forceinline__ void col_block_reduce(v4f (&s)[NS], float* part, int 
     }
 }
 
+template <bool H>
 __global__ void __launch_bounds__(256) colstats_kernel(const float* __restrict__ x, int64_t rows, int C,
                                                        ColGeom g, float* __restrict__ part, int sq,
                                                        const float* __restrict__ shift) {
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256) colstats_kernel(const float* __restrict__
     v4f k = {0, 0, 0, 0};
     if (shift) k = *(const v4f*)&shift[c0 + 4 * cvx];       // sums about the shift (see KoafGemm.stats_shift)
     for (int64_t r = rbeg + ry; r < rend; r += g.RP) {
-        v4f v = *(const v4f*)&x[r * C + c0 + 4 * cvx] - k;
+        v4f v = load4<H>(x, r * C + c0 + 4 * cvx) - k;
         s[0] += v;
         s[1] += v * v;
     }
@@ -228,7 +229,8 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const T* __restrict__
     if (train && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
 }
 
-// y = relu(sc*c+sh [+ identity])
+// y = relu(sc*c+sh [+ identity])   (H: c, idt and y are bf16 activations)
+template <bool H>
 __global__ void __launch_bounds__(256) bn_add_relu_kernel(const float* __restrict__ c, const float* __restrict__ sc,
                                                           const float* __restrict__ sh, const float* __restrict__ idt,
                                                           const float* __restrict__ idsc,
@@ -237,10 +239,10 @@ __global__ void __launch_bounds__(256) bn_add_relu_kernel(const float* __restric
     unsigned nsat = 0;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * EB) {
         const int cv = (int)(i % C4) * 4;
-        v4f v = __builtin_nontemporal_load((const v4f*)&c[i * 4]);       // (streams: read / written once, kept out of L2's way)
+        v4f v = load4_nt<H>(c, i * 4);       // (streams: read / written once, kept out of L2's way)
         v = v * *(const v4f*)&sc[cv] + *(const v4f*)&sh[cv];
         if (idt) {
-            v4f d = __builtin_nontemporal_load((const v4f*)&idt[i * 4]);
+            v4f d = load4_nt<H>(idt, i * 4);
             if (idsc) d = d * *(const v4f*)&idsc[cv] + *(const v4f*)&idsh[cv];
             v += d;
         }
@@ -251,12 +253,13 @@ __global__ void __launch_bounds__(256) bn_add_relu_kernel(const float* __restric
             nsat += !(v[j] * KOAF_ACT_SCALE <= 65504.f) ? 1u : 0u;
             v[j] = v[j] != v[j] ? v[j] : fmaxf(v[j], 0.f);
         }
-        __builtin_nontemporal_store(v, (v4f*)&y[i * 4]);
+        store4_nt<H>(y, i * 4, v);
     }
     koaf_status_add(status, 0, nsat);
 }
 
-// BN backward pass 1: masked gradient + column partials of dz and dz*xhat
+// BN backward pass 1: masked gradient + column partials of dz and dz*xhat   (H: c and ymask are bf16 activations)
+template <bool H>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ c,
                                                             const float* __restrict__ ymask,
                                                             const float* __restrict__ sc, const float* __restrict__ sh,
@@ -276,9 +279,9 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
     for (int64_t r = rbeg + ry; r < rend; r += geo.RP) {
         const int64_t o = r * C + c0;
         v4f gv = *(const v4f*)&g[o];
-        v4f cvv = *(const v4f*)&c[o];
+        v4f cvv = load4<H>(c, o);
         if (mask_mode == 1) {
-            v4f yv = *(const v4f*)&ymask[o];
+            v4f yv = load4<H>(ymask, o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
         } else if (mask_mode == 2) {
@@ -336,6 +339,7 @@ __global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const T* __restri
     if (amax && mean) block_amax_raise(bound, amax);
 }
 
+template <bool H>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ c,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ coef, float* __restrict__ dc,
@@ -345,7 +349,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * EB) {
         const int cv = (int)(i % C4) * 4;
         v4f z = *(const v4f*)&dz[i * 4];
-        v4f x = *(const v4f*)&c[i * 4];
+        v4f x = load4<H>(c, i * 4);
         v4f k0 = *(const v4f*)&coef[cv], k1 = *(const v4f*)&coef[C + cv], k2 = *(const v4f*)&coef[2 * C + cv];
         v4f mu = *(const v4f*)&mean[cv];
         const v4f o = k0 * (z - k1) - k2 * (x - mu);
@@ -462,6 +466,7 @@ __global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // max-pool 3x3 s2 p1 over relu(sc*c+sh); GAP
 // ------------------------------------------------------------------------------------------------
+template <bool B16>
 __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restrict__ c, const float* __restrict__ sc,
                                                           const float* __restrict__ sh, float* __restrict__ y,
                                                           uint8_t* __restrict__ am, int N, int H, int W, int C,
@@ -487,7 +492,7 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restric
             for (int kw = 0; kw < 3; ++kw) {
                 const int ix = ox * 2 - 1 + kw;
                 if ((unsigned)ix >= (unsigned)W) continue;
-                v4f v = *(const v4f*)&c[((int64_t)(n * H + iy) * W + ix) * C + cv];
+                v4f v = load4<B16>(c, ((int64_t)(n * H + iy) * W + ix) * C + cv);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float a = fmaxf(v[j] * s4[j] + h4[j], 0.f);
@@ -497,7 +502,7 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* __restric
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) nsat += !(best[j] * KOAF_ACT_SCALE <= 65504.f) ? 1u : 0u;    // (as in bn_add_relu_kernel)
-        *(v4f*)&y[i * 4] = best;
+        store4<B16>(y, i * 4, best);
         *(uint32_t*)&am[i * 4] = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
     }
     koaf_status_add(status, 0, nsat);
@@ -538,6 +543,7 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restric
     }
 }
 
+template <bool H>
 __global__ void __launch_bounds__(256) gap_fwd_kernel(const float* __restrict__ y, float* __restrict__ out, int N,
                                                       int HW, int C) {
     const int C4 = C / 4;
@@ -547,7 +553,7 @@ __global__ void __launch_bounds__(256) gap_fwd_kernel(const float* __restrict__ 
         const int cv = (int)(i % C4) * 4;
         const int64_t n = i / C4;
         v4f a = {0, 0, 0, 0};
-        for (int p = 0; p < HW; ++p) a += *(const v4f*)&y[(n * HW + p) * C + cv];
+        for (int p = 0; p < HW; ++p) a += load4<H>(y, (n * HW + p) * C + cv);
         *(v4f*)&out[n * C + cv] = a * inv;
     }
 }
@@ -953,26 +959,29 @@ extern "C" int koaf_bn_finalize(const float* stats, int32_t rows, int32_t C, int
 }
 
 extern "C" int koaf_bn_add_relu(const float* c, const float* sc, const float* sh, const float* idt, const float* idsc,
-                                const float* idsh, float* y, int64_t rows, int32_t C, void* stream) {
+                                const float* idsh, float* y, int64_t rows, int32_t C, int32_t act16, void* stream) {
     KOAF_REQUIRE(c && sc && sh && y && rows > 0 && C > 0 && C % 4 == 0, "koaf_bn_add_relu: bad args");
     KOAF_REQUIRE(al16(c) && al16(y) && al16(sc) && al16(sh) && (!idt || al16(idt)), "koaf_bn_add_relu: unaligned");
     KOAF_REQUIRE((idsc == nullptr) == (idsh == nullptr), "koaf_bn_add_relu: idsc/idsh come together");
     const int64_t nvec = rows * (C / 4);
-    hipLaunchKernelGGL(bn_add_relu_kernel, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, c, sc, sh, idt, idsc, idsh, y,
-                       nvec, C / 4, koaf_status_ptr());
+    if (act16) hipLaunchKernelGGL(bn_add_relu_kernel<true>, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, c, sc, sh, idt, idsc, idsh, y,
+                                  nvec, C / 4, koaf_status_ptr());
+    else hipLaunchKernelGGL(bn_add_relu_kernel<false>, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, c, sc, sh, idt, idsc, idsh, y,
+                            nvec, C / 4, koaf_status_ptr());
     return koaf_check_launch("koaf_bn_add_relu");
 }
 extern "C" int koaf_bn_relu(const float* c, const float* sc, const float* sh, float* y, int64_t rows, int32_t C,
-                            void* stream) {
-    return koaf_bn_add_relu(c, sc, sh, nullptr, nullptr, nullptr, y, rows, C, stream);
+                            int32_t act16, void* stream) {
+    return koaf_bn_add_relu(c, sc, sh, nullptr, nullptr, nullptr, y, rows, C, act16, stream);
 }
 
 extern "C" int koaf_colstats(const float* x, int64_t rows, int32_t C, float* part, int32_t* part_rows,
-                             const float* shift, void* stream) {
+                             const float* shift, int32_t act16, void* stream) {
     ColGeom g;
     KOAF_REQUIRE(x && part && part_rows && rows > 0, "koaf_colstats: bad args");
     KOAF_REQUIRE(col_geom(rows, C, 1024, &g), "koaf_colstats: unsupported C=%d", C);
-    hipLaunchKernelGGL(colstats_kernel, dim3(g.nblk, g.nchunk), dim3(256), 0, STREAM, x, rows, C, g, part, 1, shift);
+    if (act16) hipLaunchKernelGGL(colstats_kernel<true>, dim3(g.nblk, g.nchunk), dim3(256), 0, STREAM, x, rows, C, g, part, 1, shift);
+    else hipLaunchKernelGGL(colstats_kernel<false>, dim3(g.nblk, g.nchunk), dim3(256), 0, STREAM, x, rows, C, g, part, 1, shift);
     *part_rows = g.nblk;
     return koaf_check_launch("koaf_colstats");
 }
@@ -984,7 +993,7 @@ extern "C" int32_t koaf_colpart_rows(int64_t rows, int32_t C) {
 
 extern "C" int koaf_bn_bwd_reduce(const float* g, const float* c, const float* ymask, const float* sc, const float* sh,
                                   const float* mean, const float* invstd, int32_t mask_mode, float* dz_out, float* part,
-                                  int32_t* part_rows, int64_t rows, int32_t C, float* dz_amax, void* stream) {
+                                  int32_t* part_rows, int64_t rows, int32_t C, float* dz_amax, int32_t act16, void* stream) {
     ColGeom geo;
     KOAF_REQUIRE(g && c && mean && invstd && part && part_rows && rows > 0, "koaf_bn_bwd_reduce: bad args");
     KOAF_REQUIRE(mask_mode != 1 || ymask, "koaf_bn_bwd_reduce: mask_mode 1 needs ymask");
@@ -994,8 +1003,10 @@ extern "C" int koaf_bn_bwd_reduce(const float* g, const float* c, const float* y
         koaf_set_error("koaf_bn_bwd_reduce: memset failed");
         return KOAF_ELAUNCH;
     }
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(geo.nblk, geo.nchunk), dim3(256), 0, STREAM, g, c, ymask, sc, sh,
-                       mean, invstd, mask_mode, dz_out, rows, C, geo, part, dz_amax);
+    if (act16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(geo.nblk, geo.nchunk), dim3(256), 0, STREAM, g, c, ymask, sc, sh,
+                                  mean, invstd, mask_mode, dz_out, rows, C, geo, part, dz_amax);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(geo.nblk, geo.nchunk), dim3(256), 0, STREAM, g, c, ymask, sc, sh,
+                            mean, invstd, mask_mode, dz_out, rows, C, geo, part, dz_amax);
     *part_rows = geo.nblk;
     return koaf_check_launch("koaf_bn_bwd_reduce");
 }
@@ -1021,20 +1032,23 @@ extern "C" int koaf_bn_bwd_finalize(const float* part, int32_t part_rows, int32_
     return koaf_check_launch("koaf_bn_bwd_finalize");
 }
 extern "C" int koaf_bn_bwd_apply(const float* dz, const float* c, const float* mean, const float* coef, float* dc,
-                                 int64_t rows, int32_t C, float* amax, void* stream) {
+                                 int64_t rows, int32_t C, float* amax, int32_t act16, void* stream) {
     KOAF_REQUIRE(dz && c && mean && coef && dc && rows > 0 && C % 4 == 0, "koaf_bn_bwd_apply: bad args");
     const int64_t nvec = rows * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, dz, c, mean, coef, dc, nvec, C, amax);
+    if (act16) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, dz, c, mean, coef, dc, nvec, C, amax);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, dz, c, mean, coef, dc, nvec, C, amax);
     return koaf_check_launch("koaf_bn_bwd_apply");
 }
 
 extern "C" int koaf_maxpool_fwd(const float* c, const float* sc, const float* sh, float* y, uint8_t* argmax, int32_t N,
-                                int32_t H, int32_t W, int32_t C, void* stream) {
+                                int32_t H, int32_t W, int32_t C, int32_t act16, void* stream) {
     KOAF_REQUIRE(c && sc && sh && y && argmax && N > 0 && H > 0 && W > 0 && C % 4 == 0, "koaf_maxpool_fwd: bad args");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const int64_t nvec = (int64_t)N * OH * OW * (C / 4);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, c, sc, sh, y, argmax, N, H, W, C,
-                       OH, OW, koaf_status_ptr());
+    if (act16) hipLaunchKernelGGL(maxpool_fwd_kernel<true>, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, c, sc, sh, y, argmax, N, H, W, C,
+                                  OH, OW, koaf_status_ptr());
+    else hipLaunchKernelGGL(maxpool_fwd_kernel<false>, dim3(ew_grid(nvec)), dim3(EB), 0, STREAM, c, sc, sh, y, argmax, N, H, W, C,
+                            OH, OW, koaf_status_ptr());
     return koaf_check_launch("koaf_maxpool_fwd");
 }
 extern "C" int koaf_maxpool_bwd(const float* dy, const uint8_t* argmax, float* da, int32_t N, int32_t H, int32_t W,
@@ -1046,9 +1060,10 @@ extern "C" int koaf_maxpool_bwd(const float* dy, const uint8_t* argmax, float* d
                        OW);
     return koaf_check_launch("koaf_maxpool_bwd");
 }
-extern "C" int koaf_gap_fwd(const float* y, float* out, int32_t N, int32_t HW, int32_t C, void* stream) {
+extern "C" int koaf_gap_fwd(const float* y, float* out, int32_t N, int32_t HW, int32_t C, int32_t act16, void* stream) {
     KOAF_REQUIRE(y && out && N > 0 && HW > 0 && C % 4 == 0, "koaf_gap_fwd: bad args");
-    hipLaunchKernelGGL(gap_fwd_kernel, dim3(ew_grid((int64_t)N * C / 4)), dim3(EB), 0, STREAM, y, out, N, HW, C);
+    if (act16) hipLaunchKernelGGL(gap_fwd_kernel<true>, dim3(ew_grid((int64_t)N * C / 4)), dim3(EB), 0, STREAM, y, out, N, HW, C);
+    else hipLaunchKernelGGL(gap_fwd_kernel<false>, dim3(ew_grid((int64_t)N * C / 4)), dim3(EB), 0, STREAM, y, out, N, HW, C);
     return koaf_check_launch("koaf_gap_fwd");
 }
 extern "C" int koaf_gap_bwd(const float* dout, float* dy, int32_t N, int32_t HW, int32_t C, void* stream) {
@@ -1198,7 +1213,7 @@ extern "C" int koaf_colsum(const float* x, float* out, int32_t rows, int32_t C, 
     KOAF_REQUIRE(x && out && rows > 0 && C > 0, "koaf_colsum: bad args");
     ColGeom g;
     if (part && al16(x) && col_geom(rows, C, 256, &g)) {
-        hipLaunchKernelGGL(colstats_kernel, dim3(g.nblk, g.nchunk), dim3(256), 0, STREAM, x, (int64_t)rows, C, g, part,
+        hipLaunchKernelGGL(colstats_kernel<false>, dim3(g.nblk, g.nchunk), dim3(256), 0, STREAM, x, (int64_t)rows, C, g, part,
                            0, (const float*)nullptr);
         hipLaunchKernelGGL(colfinal_kernel<1>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, part, g.nblk, C, out,
                            (float*)nullptr);

@@ -117,6 +117,22 @@ __device__ __forceinline__ void split2h(const v4f x, unsigned out[2][2]) {
     }
 }
 
+// ---- bf16 ACTIVATION STORAGE (KoafGemm.act16) ------------------------------------------------------------------------------
+// The forward activations of a trunk (conv outputs, block outputs) may live in HBM as bf16 instead of fp32: half the bytes on
+// every HBM-bound call.  Arithmetic is unchanged: a loader widens the bf16 values to fp32 (exact), applies its transform and
+// cuts the fp32 result into the same two fp16 pieces; accumulation, statistics and all gradients stay fp32; only the store of a
+// forward output rounds (to nearest even).  Raw 16-bit loads are kept as bits in the loader slot and widened in finish(), so
+// that the loads stay in flight under the MFMAs exactly like the fp32 ones.
+// 4 consecutive elements at element offset `off` of a tensor stored as fp32 (H = false) or bf16 (H = true: the pointer is typed
+// float* all the same); the 16-bit form returns the raw bits in lanes 0 / 1 (widen_bf16x4 later)
+template <bool H>
+__device__ __forceinline__ v4f load4_raw(const float* p, int64_t off) {
+    if constexpr (!H) return *(const v4f*)(p + off);
+    else {
+        const uint2 u = *(const uint2*)(reinterpret_cast<const unsigned short*>(p) + off);
+        return (v4f){__uint_as_float(u.x), __uint_as_float(u.y), 0.f, 0.f};
+    }
+}
 // operand access modes (compile-time: the loaders are straight-line code, so hipcc can schedule their
 // address arithmetic into the shadows of the MFMAs)
 enum { M_KC = 0,     // K-contiguous rows, dense
@@ -148,8 +164,10 @@ __host__ __device__ constexpr int halo_b_stages(int bn, int bm = 256) { return b
 // written to HBM.  (TF 2 needs the vector path.)
 // F16: the operand feeds the fp16 scheme: finish() also multiplies by the operand's scale `fsc` (folded into the transform
 // coefficients where there is a transform) and clamps to the fp16 range (relu and clamp are one v_med3 for TF 1).
-template <int ROWS, int MODE, int TF, bool VEC, bool F16>
+// S16 / S2_16: the source tensor at ptr / ptr2 is stored as bf16 (activation storage mode; vector path only)
+template <int ROWS, int MODE, int TF, bool VEC, bool F16, bool S16 = false, bool S2_16 = false>
 struct TileLoader {
+    static_assert(!(S16 || S2_16) || VEC, "bf16 sources need the vector path");
     static constexpr int NU = ROWS / 32;
     static constexpr bool KC = mode_is_kc(MODE);
     static constexpr int NU2 = (TF == 2) ? NU : 1;
@@ -372,8 +390,8 @@ struct TileLoader {
                 if constexpr (MODE == M_KC) {
                     if (VEC) {
                         const bool ok = rok && kok;
-                        s.r[i] = *(const v4f*)(ptr + (ok ? base[i] + k0 : 0));
-                        if constexpr (TF == 2) s.r2[i] = *(const v4f*)(ptr2 + (ok ? base[i] + k0 : 0));
+                        s.r[i] = load4_raw<S16>(ptr, ok ? base[i] + k0 : 0);
+                        if constexpr (TF == 2) s.r2[i] = load4_raw<S2_16>(ptr2, ok ? base[i] + k0 : 0);
                         s.vm |= (ok ? 1u : 0u) << i;
                     } else {
 #pragma unroll
@@ -385,8 +403,8 @@ struct TileLoader {
                     }
                 } else {
                     const bool ok = kok && ((tvm >> i) & 1u);
-                    s.r[i] = *(const v4f*)(ptr + (ok ? base[i] + (toff[i] + coff) : 0));
-                    if constexpr (TF == 2) s.r2[i] = *(const v4f*)(ptr2 + (ok ? base[i] + (toff[i] + coff) : 0));
+                    s.r[i] = load4_raw<S16>(ptr, ok ? base[i] + (toff[i] + coff) : 0);
+                    if constexpr (TF == 2) s.r2[i] = load4_raw<S2_16>(ptr2, ok ? base[i] + (toff[i] + coff) : 0);
                     s.vm |= (ok ? 1u : 0u) << i;
                 }
             }
@@ -430,8 +448,8 @@ struct TileLoader {
                 }
                 if (VEC) {
                     ok = ok && (cvm & 1u);
-                    s.r[i] = *(const v4f*)(ptr + (ok ? off : 0));
-                    if constexpr (TF == 2) s.r2[i] = *(const v4f*)(ptr2 + (ok ? off : 0));
+                    s.r[i] = load4_raw<S16>(ptr, ok ? off : 0);
+                    if constexpr (TF == 2) s.r2[i] = load4_raw<S2_16>(ptr2, ok ? off : 0);
                     s.vm |= (ok ? 1u : 0u) << i;
                 } else {
 #pragma unroll
@@ -448,6 +466,8 @@ struct TileLoader {
     // transform + zero-fill of the tile issued by issue(); first consumer of the loaded registers
     __device__ __forceinline__ void finish_unit(Slot& s, int i, v4f a, v4f b, v4f k) {
         constexpr float HMAX = 65504.f;
+        if constexpr (S16) s.r[i] = widen_bf16x4(__float_as_uint(s.r[i][0]), __float_as_uint(s.r[i][1]));
+        if constexpr (S2_16 && TF == 2) s.r2[i < NU2 ? i : 0] = widen_bf16x4(__float_as_uint(s.r2[i < NU2 ? i : 0][0]), __float_as_uint(s.r2[i < NU2 ? i : 0][1]));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool ok = VEC ? ((s.vm >> i) & 1u) : ((s.vm >> (4 * i + j)) & 1u);
@@ -838,7 +858,8 @@ __device__ __forceinline__ v4i frag_load_kmd(const unsigned* P, int row0, int g,
 // backward mode, second BatchNorm) so that it is branch-free: the loads of four rows go out together before the first
 // is consumed (the generic loop below tests every row and ends up with one load in flight at a time, which held the
 // HBM-bound 1x1-dgrad epilogues at 2-3 TB/s).
-template <int BM, int BN, int NT, bool HAS_R, int MODE, bool HAS_C2>
+// C16: the output tensor is stored as bf16; E16: the BatchNorm-backward operands (c / y / c2) are (KoafGemm.act16 1 / 2)
+template <int BM, int BN, int NT, bool HAS_R, int MODE, bool HAS_C2, bool C16, bool E16>
 __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs, int ldcs, float* Cp, int64_t ldc,
                                               const float* Rp, int m0, int col, int c4, int rr, v4f bv, v4f mu, v4f is,
                                               v4f ms, v4f mh, v4f mu2, v4f is2, v4f& q1, v4f& q2, v4f& q3, v4f& qm) {
@@ -852,9 +873,9 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
             const int64_t orow = m0 + row + u * RPP;
             // (streamed once: non-temporal, like the stores below -- the tile's operands, not these, should stay in L2)
             if constexpr (HAS_R) rv[u] = __builtin_nontemporal_load((const v4f*)(Rp + orow * p.ldr + col));
-            if constexpr (MODE != 0) cv[u] = __builtin_nontemporal_load((const v4f*)(p.bnb_c + orow * ldc + col));
-            if constexpr (MODE == 1) yv[u] = __builtin_nontemporal_load((const v4f*)(p.bnb_y + orow * ldc + col));
-            if constexpr (HAS_C2) c2v[u] = __builtin_nontemporal_load((const v4f*)(p.bnb2_c + orow * ldc + col));
+            if constexpr (MODE != 0) cv[u] = load4_nt<E16>(p.bnb_c, orow * ldc + col);
+            if constexpr (MODE == 1) yv[u] = load4_nt<E16>(p.bnb_y, orow * ldc + col);
+            if constexpr (HAS_C2) c2v[u] = load4_nt<E16>(p.bnb2_c, orow * ldc + col);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -875,7 +896,7 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
 #pragma unroll
                 for (int j = 0; j < 4; ++j) qm[j] = __uint_as_float(max(__float_as_uint(qm[j]), koaf_absbits(v[j])));
             }
-            __builtin_nontemporal_store(v, (v4f*)(Cp + orow * ldc + col));
+            store4_nt<C16>(Cp, orow * ldc + col, v);
         }
     }
 }
@@ -890,8 +911,12 @@ __host__ __device__ constexpr bool persist_mode(int am, int bmd, bool f16, int t
     return f16 && bmd == M_PS && am <= M_KC_G2 && tfa != 2;
 }
 // (the persistent variants carry the next tile's A slot through the epilogue: held to two waves per SIMD = 256 registers)
-template <int BM, int BN, int AM, int BMD, int TFA, int TFB, bool VEC, bool F16, int NT = 256>
+// ACT = KoafGemm.act16: which tensors of this call are bf16 ACTIVATIONS (0: none; 1 forward: A.ptr and C; 2 data gradient:
+// A.ptr2 (the conv output c of a tf-2 apply) and the BatchNorm-backward operands of the epilogue; 3 weight gradient: A.ptr2 and B.ptr)
+template <int BM, int BN, int AM, int BMD, int TFA, int TFB, bool VEC, bool F16, int NT = 256, int ACT = 0>
 __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) koaf_gemm_kernel(const KoafGemm p) {
+    static_assert(ACT == 0 || VEC, "bf16 activation storage needs the vector path");
+    constexpr bool C16 = (ACT == 1), E16 = (ACT == 2);
     static_assert((TFA != 2 && TFB != 2) || VEC, "the two-source prologue needs the vector path");
     constexpr int NPL = F16 ? 2 : 3;
     static_assert(BMD != M_PS || F16, "plane images are fp16");
@@ -968,14 +993,16 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
         }
     }
 
-    const float* Ap = (APS || AH || WPS) ? nullptr : p.A.ptr + z0 * p.A.bs0 + z1 * p.A.bs1;
+    // (batch offsets count elements: a bf16 tensor behind a float-typed pointer advances by half the bytes)
+    auto eoff = [](const float* q, int64_t elems, bool h16) { return h16 ? (const float*)((const unsigned short*)q + elems) : q + elems; };
+    const float* Ap = (APS || AH || WPS) ? nullptr : eoff(p.A.ptr, z0 * p.A.bs0 + z1 * p.A.bs1, ACT == 1);
     const unsigned short* Apl = (APS || AH || WPS) ? p.A.planes + z0 * p.A.bs0 + z1 * p.A.bs1 : nullptr;
-    const float* Bp = (BPS || WPS) ? nullptr : p.B.ptr + z0 * p.B.bs0 + z1 * p.B.bs1;
+    const float* Bp = (BPS || WPS) ? nullptr : eoff(p.B.ptr, z0 * p.B.bs0 + z1 * p.B.bs1, ACT == 3);
     const unsigned short* Bpl = (BPS || WPS) ? p.B.planes + z0 * p.B.bs0 + z1 * p.B.bs1 : nullptr;
 
     // (the unused ones of the loaders are dead code to the compiler)
-    TileLoader<(APS || AH) ? 128 : BM, (APS || AH || WPS) ? M_KC : AM, TFA, VEC, F16> la;
-    TileLoader<BN, (BPS || WPS) ? M_KC : BMD, TFB, VEC, F16> lb;
+    TileLoader<(APS || AH) ? 128 : BM, (APS || AH || WPS) ? M_KC : AM, TFA, VEC, F16, ACT == 1, (ACT == 2 || ACT == 3) && TFA == 2> la;
+    TileLoader<BN, (BPS || WPS) ? M_KC : BMD, TFB, VEC, F16, ACT == 3> lb;
     PlaneKLoader<WPS ? BM : 128, false> wka;
     PlaneKLoader<BN, BMD == M_PKG> wkb;
     PlaneLoader<BN> lp;
@@ -1431,7 +1458,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
         Cp = p.C + (int64_t)(blockIdx.z * p.splitk + split) * p.M * p.N;
         ldc = p.N;
     } else {
-        Cp = p.C + z0 * p.cbs0 + z1 * p.cbs1;
+        Cp = const_cast<float*>(eoff(p.C, z0 * p.cbs0 + z1 * p.cbs1, C16));
         ldc = p.ldc;
     }
     const float* Rp = (p.residual && !slab) ? p.residual + z0 * p.rbs0 + z1 * p.rbs1 : nullptr;
@@ -1488,7 +1515,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
             if (full) {
                 const bool hr = Rp != nullptr, h2 = bnb && p.bnb2_c != nullptr;
                 const int mode = bnb ? p.bnb_mode : 0;
-#define KOAF_EPI(R_, M_, C2_) epi_rows_full<BM, BN, NT, R_, M_, C2_>(p, Cs, LDC_S, Cp, ldc, Rp, m0, col, c4, rr, bv, mu, is, \
+#define KOAF_EPI(R_, M_, C2_) epi_rows_full<BM, BN, NT, R_, M_, C2_, C16, E16>(p, Cs, LDC_S, Cp, ldc, Rp, m0, col, c4, rr, bv, mu, is, \
                                                                  ms, mh, mu2, is2, q1, q2, q3, qm)
                 if (mode == 0) { if (hr) KOAF_EPI(true, 0, false); else KOAF_EPI(false, 0, false); }
                 else if (mode == 1) {
@@ -1516,9 +1543,9 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
                     v4f v = *(const v4f*)&Cs[row * LDC_S + 4 * c4] + bv;
                     if (Rp) v += *(const v4f*)(Rp + orow * p.ldr + col);
                     if (bnb) {
-                        const v4f cv = *(const v4f*)(p.bnb_c + orow * ldc + col);
+                        const v4f cv = load4_nt<E16>(p.bnb_c, orow * ldc + col);
                         if (p.bnb_mode == 1) {
-                            const v4f yv = *(const v4f*)(p.bnb_y + orow * ldc + col);
+                            const v4f yv = load4_nt<E16>(p.bnb_y, orow * ldc + col);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = yv[j] > 0.f ? v[j] : 0.f;
                         } else {
@@ -1530,11 +1557,11 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
 #pragma unroll
                         for (int j = 0; j < 4; ++j) qm[j] = __uint_as_float(max(__float_as_uint(qm[j]), koaf_absbits(v[j])));
                         if (p.bnb2_c) {
-                            const v4f c2 = *(const v4f*)(p.bnb2_c + orow * ldc + col);
+                            const v4f c2 = load4_nt<E16>(p.bnb2_c, orow * ldc + col);
                             q3 += v * ((c2 - mu2) * is2);
                         }
                     }
-                    __builtin_nontemporal_store(v, (v4f*)(Cp + orow * ldc + col));
+                    store4_nt<C16>(Cp, orow * ldc + col, v);
                 }
             }
         }
@@ -1710,45 +1737,65 @@ int operand_mode(const KoafOperand& o) {
 }
 
 #define KOAF_LAUNCH(AMODE, BMODE, TA, TB)                                                                        \
-    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16>), grid, dim3(256), 0, s, g);      \
+    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16, 256, ACT>), grid, dim3(256), 0, s, g);      \
     return koaf_check_launch("koaf_gemm")
 // the persistent variants (fp32 A loader + weight tiles by DMA): at most two blocks per CU, each walking its tiles
 #define KOAF_LAUNCH_P(AMODE, BMODE, TA, TB)                                                                      \
-    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16>), pgrid, dim3(256), 0, s, g);     \
+    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16, 256, ACT>), pgrid, dim3(256), 0, s, g);     \
     return koaf_check_launch("koaf_gemm")
 
 // the operand-mode pairs the library uses: conv fwd (KC|KC_G1 x KC|PS), dgrad (KC|KC_G2 x PS, or KC x KM | KC_G2 x KM_G3
 // on fp32 weights), wgrad (KM x KM|KM_G1), linear / attention (dense pairs).  tf only where a BatchNorm prologue exists.
-template <int BM, int BN, bool VEC, bool F16>
+// ACT (bf16 activation storage, KoafGemm.act16): only the pairs of its role are instantiated -- 1 forward convolutions,
+// 2 data gradients, 3 weight gradients.
+template <int BM, int BN, bool VEC, bool F16, int ACT>
 int launch_modes(const KoafGemm& g, dim3 grid, hipStream_t s) {
     const int am = operand_mode(g.A), bm = operand_mode(g.B);
     const int ta = g.A.tf, tb = g.B.tf;
     dim3 pgrid = grid;
     if (grid.y == 1 && grid.x > PERSIST_BLOCKS) pgrid.x = PERSIST_BLOCKS;
-    if (am == M_KC && bm == M_KC && !tb) { if (ta == 1) { KOAF_LAUNCH(M_KC, M_KC, 1, 0); } else if (!ta) { KOAF_LAUNCH(M_KC, M_KC, 0, 0); } }
-    if (am == M_KC && bm == M_KM && !ta && !tb) { KOAF_LAUNCH(M_KC, M_KM, 0, 0); }
-    if (am == M_KM && bm == M_KM && !ta) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM, 0, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM, 0, 0); } }
+    if constexpr (ACT == 0) {
+        if (am == M_KC && bm == M_KC && !tb) { if (ta == 1) { KOAF_LAUNCH(M_KC, M_KC, 1, 0); } else if (!ta) { KOAF_LAUNCH(M_KC, M_KC, 0, 0); } }
+        if (am == M_KC && bm == M_KM && !ta && !tb) { KOAF_LAUNCH(M_KC, M_KM, 0, 0); }
+        if (am == M_KM && bm == M_KM && !ta) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM, 0, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM, 0, 0); } }
+    }
     if constexpr (VEC) {
-        if (am == M_KC_G1 && bm == M_KC && !tb) { if (ta == 1) { KOAF_LAUNCH(M_KC_G1, M_KC, 1, 0); } else if (!ta) { KOAF_LAUNCH(M_KC_G1, M_KC, 0, 0); } }
-        if (am == M_KC_G2 && bm == M_KM_G3 && !ta && !tb) { KOAF_LAUNCH(M_KC_G2, M_KM_G3, 0, 0); }
-        if (am == M_KM && bm == M_KM_G1 && !ta) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM_G1, 0, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM_G1, 0, 0); } }
+        if constexpr (ACT == 0 || (ACT == 1 && !F16)) {
+            if (am == M_KC_G1 && bm == M_KC && !tb) { if (ta == 1) { KOAF_LAUNCH(M_KC_G1, M_KC, 1, 0); } else if (!ta) { KOAF_LAUNCH(M_KC_G1, M_KC, 0, 0); } }
+        }
+        if constexpr (ACT == 0) {
+            if (am == M_KC_G2 && bm == M_KM_G3 && !ta && !tb) { KOAF_LAUNCH(M_KC_G2, M_KM_G3, 0, 0); }
+        }
+        if constexpr (ACT == 0 || (ACT == 3 && !F16)) {
+            if (am == M_KM && bm == M_KM_G1 && !ta) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM_G1, 0, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM_G1, 0, 0); } }
+        }
         if constexpr (F16) {
-            if (am == M_KC && bm == M_PS) {
-                if (ta == 1) { KOAF_LAUNCH_P(M_KC, M_PS, 1, 0); } else if (ta == 2) { KOAF_LAUNCH(M_KC, M_PS, 2, 0); } else { KOAF_LAUNCH_P(M_KC, M_PS, 0, 0); }
+            if constexpr (ACT == 0 || ACT == 1) {
+                if (am == M_KC && bm == M_PS && ta != 2) { if (ta == 1) { KOAF_LAUNCH_P(M_KC, M_PS, 1, 0); } else { KOAF_LAUNCH_P(M_KC, M_PS, 0, 0); } }
+                if (am == M_KC_G1 && bm == M_PS && ta != 2) { if (ta) { KOAF_LAUNCH_P(M_KC_G1, M_PS, 1, 0); } else { KOAF_LAUNCH_P(M_KC_G1, M_PS, 0, 0); } }
+                if (am == M_PA1 && bm == M_PS) { KOAF_LAUNCH(M_PA1, M_PS, 0, 0); }
             }
-            if (am == M_KC_G1 && bm == M_PS && ta != 2) { if (ta) { KOAF_LAUNCH_P(M_KC_G1, M_PS, 1, 0); } else { KOAF_LAUNCH_P(M_KC_G1, M_PS, 0, 0); } }
-            if (am == M_KC_G2 && bm == M_PS && ta != 1) { if (ta) { KOAF_LAUNCH(M_KC_G2, M_PS, 2, 0); } else { KOAF_LAUNCH_P(M_KC_G2, M_PS, 0, 0); } }
-            if (am == M_PK && bm == M_PKG) { KOAF_LAUNCH(M_PK, M_PKG, 0, 0); }
-            if (am == M_PK && bm == M_PK) { KOAF_LAUNCH(M_PK, M_PK, 0, 0); }
-            if (am == M_PA1 && bm == M_PS) { KOAF_LAUNCH(M_PA1, M_PS, 0, 0); }
-            if (am == M_PA2 && bm == M_PS) { KOAF_LAUNCH(M_PA2, M_PS, 0, 0); }
-            // weight gradient with the BatchNorm-backward apply formed in the A loader (dy = sc * dz + sh - sc2 * c)
-            if (am == M_KM && bm == M_KM && ta == 2) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM, 2, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM, 2, 0); } }
-            if (am == M_KM && bm == M_KM_G1 && ta == 2) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM_G1, 2, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM_G1, 2, 0); } }
+            if constexpr (ACT == 0 || ACT == 2) {
+                if (am == M_KC && bm == M_PS && ta == 2) { KOAF_LAUNCH(M_KC, M_PS, 2, 0); }
+                if (am == M_KC_G2 && bm == M_PS && ta != 1) { if (ta) { KOAF_LAUNCH(M_KC_G2, M_PS, 2, 0); } else { KOAF_LAUNCH_P(M_KC_G2, M_PS, 0, 0); } }
+                if (am == M_PA2 && bm == M_PS) { KOAF_LAUNCH(M_PA2, M_PS, 0, 0); }
+            }
+            if constexpr (ACT == 2) {       // (a data gradient whose dy is a tensor: only the epilogue's operands are bf16)
+                if (am == M_KC && bm == M_PS && ta == 0) { KOAF_LAUNCH(M_KC, M_PS, 0, 0); }
+            }
+            if constexpr (ACT == 0) {
+                if (am == M_PK && bm == M_PKG) { KOAF_LAUNCH(M_PK, M_PKG, 0, 0); }
+                if (am == M_PK && bm == M_PK) { KOAF_LAUNCH(M_PK, M_PK, 0, 0); }
+            }
+            if constexpr (ACT == 0 || ACT == 3) {
+                // weight gradient with the BatchNorm-backward apply formed in the A loader (dy = sc * dz + sh - sc2 * c)
+                if (am == M_KM && bm == M_KM && ta == 2) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM, 2, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM, 2, 0); } }
+                if (am == M_KM && bm == M_KM_G1 && ta == 2) { if (tb == 1) { KOAF_LAUNCH(M_KM, M_KM_G1, 2, 1); } else if (!tb) { KOAF_LAUNCH(M_KM, M_KM_G1, 2, 0); } }
+            }
         }
     }
-    koaf_set_error("koaf_gemm: operand mode pair (%d,%d) tf=(%d,%d) fmt=%d vec=%d is not instantiated", am, bm, ta, tb,
-                   (int)F16, (int)VEC);
+    koaf_set_error("koaf_gemm: operand mode pair (%d,%d) tf=(%d,%d) fmt=%d vec=%d act16=%d is not instantiated", am, bm, ta, tb,
+                   (int)F16, (int)VEC, ACT);
     return KOAF_EINVAL;
 }
 
@@ -1828,6 +1875,44 @@ static void fill_defaults(KoafGemm& g) {
     if (g.B.kind == 2 && g.B.C == 0) { g.B.C = ((g.K + BK - 1) / BK) * BK; g.B.KW = 1; }   // dense: one "tap" spanning the padded K
 }
 
+namespace {
+// all launches of one activation-storage role (KoafGemm.act16)
+template <int ACT>
+int launch_act(const KoafGemm& g, const TilePlan& tp, dim3 grid, hipStream_t s) {
+    const bool vec = tp.vec;
+    if (tp.halo) {
+        // (the halo kernels read plane images: only their epilogue sees the storage type -- forward: the output; data
+        // gradient: the BatchNorm-backward operands)
+        if constexpr (ACT == 3) { koaf_set_error("koaf_gemm: halo kernel with act16 = 3"); return KOAF_EINVAL; }
+        else {
+            if (tp.bm == 128) {
+                if (tp.bn == 128) hipLaunchKernelGGL((koaf_gemm_kernel<128, 128, M_PH, M_PS, 0, 0, true, true, 256, ACT>), grid, dim3(256), 0, s, g);
+                else hipLaunchKernelGGL((koaf_gemm_kernel<128, 64, M_PH, M_PS, 0, 0, true, true, 256, ACT>), grid, dim3(256), 0, s, g);
+                return koaf_check_launch("koaf_gemm/halo128");
+            }
+            if (tp.bn == 128) hipLaunchKernelGGL((koaf_gemm_kernel<256, 128, M_PH, M_PS, 0, 0, true, true, 512, ACT>), grid, dim3(512), 0, s, g);
+            else hipLaunchKernelGGL((koaf_gemm_kernel<256, 64, M_PH, M_PS, 0, 0, true, true, 512, ACT>), grid, dim3(512), 0, s, g);
+            return koaf_check_launch("koaf_gemm/halo");
+        }
+    }
+    if (g.fmt == 1) {
+        KOAF_REQUIRE(vec, "koaf_gemm: the fp16 scheme needs the vector path (16-B aligned operands, K %% 4 == 0, N %% 4 == 0)");
+        if (tp.bm == 128 && tp.bn == 128) return launch_modes<128, 128, true, true, ACT>(g, grid, s);
+        if (tp.bm == 128 && tp.bn == 64) return launch_modes<128, 64, true, true, ACT>(g, grid, s);
+        if (tp.bm == 64 && tp.bn == 128) return launch_modes<64, 128, true, true, ACT>(g, grid, s);
+        return launch_modes<64, 64, true, true, ACT>(g, grid, s);
+    }
+    if (!vec) {
+        if constexpr (ACT == 0) return launch_modes<64, 64, false, false, 0>(g, grid, s);
+        else { koaf_set_error("koaf_gemm: bf16 activation storage needs the vector path"); return KOAF_EINVAL; }
+    }
+    if (tp.bm == 128 && tp.bn == 128) return launch_modes<128, 128, true, false, ACT>(g, grid, s);
+    if (tp.bm == 128 && tp.bn == 64) return launch_modes<128, 64, true, false, ACT>(g, grid, s);
+    if (tp.bm == 64 && tp.bn == 128) return launch_modes<64, 128, true, false, ACT>(g, grid, s);
+    return launch_modes<64, 64, true, false, ACT>(g, grid, s);
+}
+}  // namespace
+
 extern "C" int koaf_gemm_part_rows(const KoafGemm* gp) {
     KoafGemm g = *gp;
     fill_defaults(g);
@@ -1885,28 +1970,14 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     if (tiles <= 0) return KOAF_OK;
     if (tiles >= (1ll << 31)) { koaf_set_error("koaf_gemm: grid too large"); return KOAF_EINVAL; }
     dim3 grid((unsigned)tiles, (unsigned)g.splitk, (unsigned)(g.nb0 * g.nb1));
-    if (tp.halo && tp.bm == 128) {
-        if (tp.bn == 128) hipLaunchKernelGGL((koaf_gemm_kernel<128, 128, M_PH, M_PS, 0, 0, true, true, 256>), grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((koaf_gemm_kernel<128, 64, M_PH, M_PS, 0, 0, true, true, 256>), grid, dim3(256), 0, s, g);
-        return koaf_check_launch("koaf_gemm/halo128");
+    switch (g.act16) {
+        case 0: return launch_act<0>(g, tp, grid, s);
+        case 1: return launch_act<1>(g, tp, grid, s);
+        case 2: return launch_act<2>(g, tp, grid, s);
+        case 3: return launch_act<3>(g, tp, grid, s);
     }
-    if (tp.halo) {
-        if (tp.bn == 128) hipLaunchKernelGGL((koaf_gemm_kernel<256, 128, M_PH, M_PS, 0, 0, true, true, 512>), grid, dim3(512), 0, s, g);
-        else hipLaunchKernelGGL((koaf_gemm_kernel<256, 64, M_PH, M_PS, 0, 0, true, true, 512>), grid, dim3(512), 0, s, g);
-        return koaf_check_launch("koaf_gemm/halo");
-    }
-    if (g.fmt == 1) {
-        KOAF_REQUIRE(vec, "koaf_gemm: the fp16 scheme needs the vector path (16-B aligned operands, K %% 4 == 0, N %% 4 == 0)");
-        if (tp.bm == 128 && tp.bn == 128) return launch_modes<128, 128, true, true>(g, grid, s);
-        if (tp.bm == 128 && tp.bn == 64) return launch_modes<128, 64, true, true>(g, grid, s);
-        if (tp.bm == 64 && tp.bn == 128) return launch_modes<64, 128, true, true>(g, grid, s);
-        return launch_modes<64, 64, true, true>(g, grid, s);
-    }
-    if (!vec) return launch_modes<64, 64, false, false>(g, grid, s);
-    if (tp.bm == 128 && tp.bn == 128) return launch_modes<128, 128, true, false>(g, grid, s);
-    if (tp.bm == 128 && tp.bn == 64) return launch_modes<128, 64, true, false>(g, grid, s);
-    if (tp.bm == 64 && tp.bn == 128) return launch_modes<64, 128, true, false>(g, grid, s);
-    return launch_modes<64, 64, true, false>(g, grid, s);
+    koaf_set_error("koaf_gemm: act16 must be 0 .. 3");
+    return KOAF_EINVAL;
 }
 
 extern "C" int koaf_slab_reduce(const float* slabs, int32_t nslab, int64_t n, float* out, void* stream) {
@@ -2059,7 +2130,8 @@ extern "C" int koaf_wplanes_build(const float* base, uint16_t* planes, float* am
 namespace {
 // TF as in TileLoader (0 none, 1 relu(sc*x+sh), 2 sc*x + sh - sc2*x2); the arithmetic is finish_unit()'s + split2h, so the
 // images hold bit for bit what the fp32 loader of the same operand puts into LDS.
-template <int TF>
+// X16: the activation among the sources is stored as bf16 (tf 0 / 1: x; tf 2: x2 = the conv output c)
+template <int TF, bool X16>
 __global__ void __launch_bounds__(256) act_planes_kernel(const float* __restrict__ x, const float* __restrict__ x2, int64_t n8,
                                                          int C, const float* __restrict__ sc, const float* __restrict__ sh,
                                                          const float* __restrict__ sc2, const float* __restrict__ amax,
@@ -2074,7 +2146,7 @@ __global__ void __launch_bounds__(256) act_planes_kernel(const float* __restrict
         unsigned pl[2][2][2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            v4f v = *(const v4f*)(x + i * 8 + 4 * hf);
+            v4f v = load4<X16 && TF != 2>(x, i * 8 + 4 * hf);
             if constexpr (TF == 1) {
                 const v4f a = *(const v4f*)(sc + c + 4 * hf) * fsc, b = *(const v4f*)(sh + c + 4 * hf) * fsc;
 #pragma unroll
@@ -2086,7 +2158,7 @@ __global__ void __launch_bounds__(256) act_planes_kernel(const float* __restrict
             } else if constexpr (TF == 2) {
                 const v4f a = *(const v4f*)(sc + c + 4 * hf) * fsc, b = *(const v4f*)(sh + c + 4 * hf) * fsc;
                 const v4f k = *(const v4f*)(sc2 + c + 4 * hf) * fsc;
-                const v4f w = *(const v4f*)(x2 + i * 8 + 4 * hf);
+                const v4f w = load4<X16>(x2, i * 8 + 4 * hf);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float u = fmaf(a[j], v[j], fmaf(-k[j], w[j], b[j]));
@@ -2115,7 +2187,7 @@ extern "C" int64_t koaf_act_planes_elems(int64_t npix, int32_t C) { return 2 * n
 
 extern "C" int koaf_act_planes(const float* x, const float* x2, int64_t npix, int32_t C, int32_t tf, const float* sc,
                                const float* sh, const float* sc2, const float* amax, float fscale, uint16_t* planes,
-                               void* stream) {
+                               int32_t act16, void* stream) {
     KOAF_REQUIRE(x && planes && npix > 0 && C > 0 && (C & 7) == 0 && tf >= 0 && tf <= 2, "koaf_act_planes: bad args (C %% 8 == 0)");
     KOAF_REQUIRE(tf == 0 || (sc && sh), "koaf_act_planes: tf needs sc / sh");
     KOAF_REQUIRE(tf != 2 || (x2 && sc2), "koaf_act_planes: tf 2 needs x2 / sc2");
@@ -2125,9 +2197,11 @@ extern "C" int koaf_act_planes(const float* x, const float* x2, int64_t npix, in
     int64_t blocks = cdiv64(n8, 256);
     if (blocks > 16384) blocks = 16384;
     hipStream_t s = (hipStream_t)stream;
-    if (tf == 0) hipLaunchKernelGGL(act_planes_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, x, x2, n8, C, sc, sh, sc2, amax, fscale, planes, ps, koaf_status_ptr());
-    else if (tf == 1) hipLaunchKernelGGL(act_planes_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, x, x2, n8, C, sc, sh, sc2, amax, fscale, planes, ps, koaf_status_ptr());
-    else hipLaunchKernelGGL(act_planes_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, x, x2, n8, C, sc, sh, sc2, amax, fscale, planes, ps, koaf_status_ptr());
+#define KOAF_AP(TF_, X_) hipLaunchKernelGGL((act_planes_kernel<TF_, X_>), dim3((unsigned)blocks), dim3(256), 0, s, x, x2, n8, C, sc, sh, sc2, amax, fscale, planes, ps, koaf_status_ptr())
+    if (tf == 0) { if (act16) KOAF_AP(0, true); else KOAF_AP(0, false); }
+    else if (tf == 1) { if (act16) KOAF_AP(1, true); else KOAF_AP(1, false); }
+    else { if (act16) KOAF_AP(2, true); else KOAF_AP(2, false); }
+#undef KOAF_AP
     return koaf_check_launch("koaf_act_planes");
 }
 

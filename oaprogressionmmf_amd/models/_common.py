@@ -98,7 +98,24 @@ def finish(config, res_out):
     raise ValueError(f"Unknown output_type: {config.output_type}")
 
 
+def apply_activation_storage(model, config):
+    """config key `activation_storage` (not in the reference; default "fp32"): "bf16" stores the forward activations of every
+    encoder trunk as bf16 (KoafTrunk.act_dtype) -- BASELINE.json config 2's "bf16", a throughput mode reported beside the fp32
+    parity mode with its measured error"""
+    try:
+        mode = config["activation_storage"]
+    except (KeyError, AttributeError):
+        mode = "fp32"
+    if mode not in ("fp32", "bf16"):
+        raise ValueError("Unsupported `model.activation_storage` (fp32 | bf16)")
+    for m in model.modules():
+        if isinstance(m, KoafTrunk):
+            m.act_dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+    return mode
+
+
 def maybe_restore(model, config, path_weights):
+    apply_activation_storage(model, config)
     if config["restore_weights"]:
         model.load_state_dict(torch.load(path_weights, map_location="cpu"))
 

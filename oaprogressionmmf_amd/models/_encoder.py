@@ -327,7 +327,8 @@ class EncoderFn(torch.autograd.Function):
         conv1, bn1 = st["conv1"], st["bn1"]
         train = bn1.training
         w1t = ops.stem_fold_w(packed_weight(conv1.weight))
-        c0 = ops.stem_fwd(x, w1t, N, H, W)
+        adt = getattr(trunk, "act_dtype", torch.float32)       # storage type of the forward activations (KoafTrunk.act_dtype)
+        c0 = ops.stem_fwd(x, w1t, N, H, W, dtype=adt)
         H1, W1 = c0.shape[1], c0.shape[2]
         part = ops.colstats(c0, N * H1 * W1, 64, shift=_stat_shift(bn1, train)) if train else None
         s0 = _bn_fin(bn1, part, N * H1 * W1)
@@ -357,11 +358,13 @@ class EncoderFn(torch.autograd.Function):
             out = ops.gap_fwd(y, N, Hc * Wc, C).view(N, C, 1, 1)
         else:
             out = y.permute(0, 3, 1, 2)  # (N,C,h,w) view of the NHWC buffer
+            if out.dtype != torch.float32:
+                out = out.float()        # (what leaves the trunk is fp32; only the trunk's own activations are stored as bf16)
         if keep:
             if 0 in rset:
                 c0 = None          # the stem output is rebuilt in backward too (one cheap 7x7 conv; 64 x H/2 x W/2 floats)
             ctx.state = dict(x=x, c0=c0, s0=s0, am=am, stages=stages_saved, any_recompute=bool(rset), caller=CALLER_STREAM,
-                             block_level=block_level,
+                             block_level=block_level, adt=adt,
                              dims=(N, H, W, H1, W1), last=(Hc, Wc, C), st=st, lane=lane, train=train)
         return out
 
@@ -519,7 +522,7 @@ class EncoderFn(torch.autograd.Function):
         da0 = ops.maxpool_bwd(dy, S["am"], N, H1, W1, 64)
         c0 = S["c0"]
         if c0 is None:
-            c0 = ops.stem_fwd(S["x"], ops.stem_fold_w(packed_weight(conv1.weight)), N, H, W)
+            c0 = ops.stem_fwd(S["x"], ops.stem_fold_w(packed_weight(conv1.weight)), N, H, W, dtype=S["adt"])
         dc0 = _bn_bwd(bn1, da0, c0, S["s0"], N * H1 * W1, 2, dc_out=da0, fused=False)    # (the stem's wgrad is not a GEMM)
         gw, acc = grad_target(conv1.weight)
         ops.stem_wgrad(dc0, S["x"], gw, N, H, W)
@@ -534,7 +537,13 @@ class KoafTrunk(nn.Sequential):
     `1.running_mean`, `4.0.conv1.weight`, ...), executed as the fused HIP schedule above.
 
     forward(x): x = the SINGLE-channel image batch (N,1,H,W); returns (N,C,1,1) with the GAP child
-    present, else (N,C,h,w)."""
+    present, else (N,C,h,w).
+
+    act_dtype: how the trunk's forward activations (stem / conv / block outputs) are STORED in HBM: torch.float32 (default,
+    the parity mode) or torch.bfloat16 (koaf.h "bf16 ACTIVATION STORAGE": half the bytes of every HBM-bound kernel and of the
+    tensors saved for backward; arithmetic, statistics, gradients and parameters stay fp32).  Set per model by the config key
+    `activation_storage: bf16` (models/_common.apply_activation_storage)."""
+    act_dtype = torch.float32
 
     def _koaf_layout(self):
         lay = self.__dict__.get("_koaf_lay")

@@ -57,12 +57,17 @@ def _ptr(t):
         return None
     if not t.is_cuda:
         raise KoafError("koaf ops need tensors on a HIP device (no CPU fallback exists)")
-    if t.dtype not in (torch.float32, torch.int64, torch.uint8, torch.float64):   # float64: reduction workspaces only
+    if t.dtype not in (torch.float32, torch.int64, torch.uint8, torch.float64, torch.bfloat16):   # float64: reduction workspaces only; bfloat16: activation storage mode
         raise KoafError(f"unexpected dtype {t.dtype}")
     return t.data_ptr()
 
 
 _STATUS = None       # device int32[4]: the library's numerics status words (koaf.h koaf_set_status_buffer)
+
+
+def _a16(t):
+    """the `act16` argument of the entry points (koaf.h): 1 when the call's activation tensor is stored as bf16"""
+    return 1 if (t is not None and t.dtype == torch.bfloat16) else 0
 
 
 def _stream():
@@ -137,10 +142,10 @@ class BnApply(object):
         return (self.dz, self.c, self.coef, self.amax, self._koaf_planes, getattr(self.c, "_koaf_xplanes", None))
 
     def materialize(self, out=None, want_amax=False):
-        dc = out if out is not None else torch.empty_like(self.c)
+        dc = out if out is not None else torch.empty(self.c.shape, device=self.c.device, dtype=torch.float32)
         amax = torch.zeros(1, device=self.c.device, dtype=torch.float32) if want_amax else None
         check(lib().koaf_bn_bwd_apply(_ptr(self.dz), _ptr(self.c), _ptr(self.mean), _ptr(self.coef), _ptr(dc), self.rows, self.C,
-                                      _ptr(amax), _stream()), "bn_bwd_apply")
+                                      _ptr(amax), _a16(self.c), _stream()), "bn_bwd_apply")
         if want_amax:
             dc._koaf_amax = amax
         return dc
@@ -170,7 +175,7 @@ def act_planes(x, npix, C, tf=0, sc=None, sh=None, x2=None, sc2=None, amax=None,
     L = lib()
     out = torch.empty(L.koaf_act_planes_elems(npix, C), device=x.device, dtype=torch.int16)
     check(L.koaf_act_planes(_ptr(x), _ptr(x2), npix, C, tf, _ptr(sc), _ptr(sh), _ptr(sc2), _ptr(amax), float(fscale),
-                            out.data_ptr(), _stream()), "act_planes")
+                            out.data_ptr(), _a16(x2 if tf == 2 else x), _stream()), "act_planes")
     return out
 
 
@@ -194,7 +199,7 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     scheme (KoafGemm.fmt 1: half the matrix instructions, same accuracy), the weight tiles DMA'd from F."""
     L = lib()
     OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
-    y = _empty((N, OH, OW, Cout), x)
+    y = _empty((N, OH, OW, Cout), x, dtype=x.dtype)            # (bf16 activation storage: the output follows the input)
     part, rows = None, _i32(0)
     if stats:
         nrows = L.koaf_conv2d_stats_rows(N * OH * OW, Cout)
@@ -210,7 +215,7 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
         xpl = act_planes(x, N * H * W, Cin, 1 if in_sc is not None else 0, in_sc, in_sh, fscale=ACT_SCALE)
     check(L.koaf_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
                             _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _ptr(shift) if stats else None,
-                            _img(wimg), xpl.data_ptr() if xpl is not None else None, _stream()), "conv2d_fwd")
+                            _img(wimg), xpl.data_ptr() if xpl is not None else None, _a16(x), _stream()), "conv2d_fwd")
     if xpl is not None and not torch.is_tensor(aplanes) and xpl.numel() <= KEEP_XPLANES_ELEMS:
         y._koaf_xplanes = xpl       # ride on the output: this conv's weight gradient reads them instead of cutting them again
     _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin, f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}",
@@ -231,6 +236,7 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, 
     apply included) and the kernel's input tiles are DMA'd from them."""
     L = lib()
     dyp, amp, app, like = _dy_args(dy, dy_amax)
+    a16 = _a16(dy.c) if isinstance(dy, BnApply) else (_a16(bnb["c"]) if bnb is not None else 0)
     dx = _empty((N, H, W, Cin), like)
     if aplanes is None:
         aplanes = ((APLANES_MASK & 2) and use_aplanes(wimg, KH, KW, Cout) and wimg[1] is not None and stride in (1, 2) and
@@ -250,7 +256,7 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, 
         tag += " apply"
     if bnb is None:
         check(L.koaf_conv2d_dgrad(dyp, _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
-                                  _ptr(residual), _img(wimg), amp, app, dypp, _stream()), "conv2d_dgrad")
+                                  _ptr(residual), _img(wimg), amp, app, dypp, a16, _stream()), "conv2d_dgrad")
         _prof_end(e0, "gemm", fl, tag, el, mpp=mpp)
         return dx
     sv, sv2 = bnb["saved"], bnb.get("saved2")
@@ -263,7 +269,7 @@ def conv2d_dgrad(dy, w, N, H, W, Cin, Cout, KH, KW, stride, pad, residual=None, 
     rows = _i32(0)
     check(L.koaf_conv2d_dgrad_bnb(dyp, _ptr(w), _ptr(dx), N, H, W, Cin, Cout, KH, KW, stride, pad,
                                   _ptr(residual), ctypes.byref(kb), _ptr(part), ctypes.addressof(rows), _img(wimg),
-                                  amp, app, dypp, _stream()), "conv2d_dgrad_bnb")
+                                  amp, app, dypp, a16, _stream()), "conv2d_dgrad_bnb")
     el += N * H * W * Cin * (1 + (bnb.get("y") is not None) + (bnb.get("c2") is not None))
     _prof_end(e0, "gemm", fl, tag + " +bnb", el, mpp=mpp)
     if dzmax is not None:
@@ -303,7 +309,7 @@ def conv2d_wgrad(dy, x, dw, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None,
             xpl = act_planes(x, N * H * W, Cin, 1 if in_sc is not None else 0, in_sc, in_sh, fscale=ACT_SCALE)
     check(L.koaf_conv2d_wgrad(dyp, _ptr(x), _ptr(dw), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
                               _ptr(in_sh), _ptr(slabs), amp, app, dypl.data_ptr() if dypl is not None else None,
-                              xpl.data_ptr() if xpl is not None else None, _stream()), "conv2d_wgrad")
+                              xpl.data_ptr() if xpl is not None else None, _a16(x), _stream()), "conv2d_wgrad")
     npx = N * conv_out(H, KH, stride, pad) * conv_out(W, KW, stride, pad)
     _prof_end(e0, "gemm", 2.0 * npx * Cout * KH * KW * Cin,
               f"conv_wgrad k{KH}s{stride} {Cin}->{Cout} px{N*H*W}" + (" apply" if app is not None else ""),
@@ -326,13 +332,13 @@ def gconv_compress_dw(dwexp, dw, C, groups):
 def gconv3x3_fwd(x, wexp, N, H, W, C, stride, in_sc=None, in_sh=None, stats=False, shift=None):
     L = lib()
     OH, OW = conv_out(H, 3, stride, 1), conv_out(W, 3, stride, 1)
-    y = _empty((N, OH, OW, C), x)
+    y = _empty((N, OH, OW, C), x, dtype=x.dtype)
     part, rows = None, _i32(0)
     if stats:
         part = _empty(((N * OH * OW + 127) // 128, 2, C), x)
     e0 = _prof_begin()
     check(L.koaf_gconv3x3_fwd(_ptr(x), _ptr(wexp), _ptr(y), N, H, W, C, stride, _ptr(in_sc), _ptr(in_sh), _ptr(part),
-                              ctypes.addressof(rows), _ptr(shift) if stats else None, _stream()), "gconv3x3_fwd")
+                              ctypes.addressof(rows), _ptr(shift) if stats else None, _a16(x), _stream()), "gconv3x3_fwd")
     _prof_end(e0, "gemm", 2.0 * N * OH * OW * C * 9 * (C // 32), f"gconv_fwd s{stride} C{C} px{N*OH*OW}",   # algorithmic (32 groups)
               N * H * W * C + N * OH * OW * C + 9 * C * (C // 32))
     return y, part
@@ -355,7 +361,7 @@ def gconv3x3_wgrad(dy, x, N, H, W, C, stride, in_sc=None, in_sh=None):
     dwexp = _empty((C // 64, 64, 9, 64), dy)
     e0 = _prof_begin()
     check(L.koaf_gconv3x3_wgrad(_ptr(dy), _ptr(x), _ptr(dwexp), N, H, W, C, stride, _ptr(in_sc), _ptr(in_sh),
-                                _ptr(slabs), _stream()), "gconv3x3_wgrad")
+                                _ptr(slabs), _a16(x), _stream()), "gconv3x3_wgrad")
     _prof_end(e0, "gemm", 2.0 * N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C * 9 * (C // 32),
               f"gconv_wgrad s{stride} C{C} px{N*H*W}",
               N * H * W * C + N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C + 9 * C * (C // 32))
@@ -368,9 +374,10 @@ def stem_fold_w(w):
     return w1t
 
 
-def stem_fwd(x, w1t, N, H, W):
-    y = _empty((N, conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3), 64), x)
-    check(lib().koaf_stem_fwd(_ptr(x), _ptr(w1t), _ptr(y), N, H, W, _stream()), "stem_fwd")
+def stem_fwd(x, w1t, N, H, W, dtype=torch.float32):
+    """dtype: storage type of the output activation (torch.float32, or torch.bfloat16: koaf.h "bf16 ACTIVATION STORAGE")"""
+    y = _empty((N, conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3), 64), x, dtype=dtype)
+    check(lib().koaf_stem_fwd(_ptr(x), _ptr(w1t), _ptr(y), N, H, W, _a16(y), _stream()), "stem_fwd")
     return y
 
 
@@ -389,9 +396,9 @@ def stem_wgrad(dy, x, dw, N, H, W):
 # ------------------------------------------------------------------------------------------------
 def colstats(x, rows, C, shift=None):
     L = lib()
-    part = _empty((L.koaf_colpart_rows(rows, C), 2, C), x)
+    part = _empty((L.koaf_colpart_rows(rows, C), 2, C), x)      # (fp32 whatever the storage type of x)
     r = _i32(0)
-    check(L.koaf_colstats(_ptr(x), rows, C, _ptr(part), ctypes.addressof(r), _ptr(shift), _stream()), "colstats")
+    check(L.koaf_colstats(_ptr(x), rows, C, _ptr(part), ctypes.addressof(r), _ptr(shift), _a16(x), _stream()), "colstats")
     return part
 
 
@@ -418,7 +425,7 @@ def bn_add_relu(c, saved, rows, C, idt=None, idsaved=None, out=None):
     y = out if out is not None else torch.empty_like(c)
     check(lib().koaf_bn_add_relu(_ptr(c), _ptr(saved[2]), _ptr(saved[3]), _ptr(idt),
                                  _ptr(idsaved[2]) if idsaved is not None else None,
-                                 _ptr(idsaved[3]) if idsaved is not None else None, _ptr(y), rows, C, _stream()),
+                                 _ptr(idsaved[3]) if idsaved is not None else None, _ptr(y), rows, C, _a16(c), _stream()),
           "bn_add_relu")
     return y
 
@@ -435,7 +442,7 @@ def bn_bwd(g, c, saved, rows, C, count, dgamma, dbeta, mask_mode, ymask=None, dz
     dzmax = _empty((1,), g) if fused else None
     check(L.koaf_bn_bwd_reduce(_ptr(g), _ptr(c), _ptr(ymask), _ptr(saved[2]), _ptr(saved[3]), _ptr(saved[0]),
                                _ptr(saved[1]), mask_mode, _ptr(dz_out), _ptr(part), ctypes.addressof(r), rows, C,
-                               _ptr(dzmax), _stream()), "bn_bwd_reduce")
+                               _ptr(dzmax), _a16(c), _stream()), "bn_bwd_reduce")
     dz = dz_out if dz_out is not None else g
     return _bn_bwd_tail(part[:r.value], 2, 1, dz, c, saved, rows, C, count, dgamma, dbeta, dc_out, fused, dzmax)
 
@@ -449,8 +456,8 @@ def _bn_bwd_tail(part, nsum, i1, dz, c, saved, rows, C, count, dgamma, dbeta, dc
                                  _ptr(saved[0]) if fused else None, _ptr(dzmax), _ptr(amax), _stream()), "bn_bwd_finalize")
     if fused:
         return BnApply(dz, c, coef, amax, saved[0], rows, C)
-    dc = dc_out if dc_out is not None else torch.empty_like(c)
-    check(L.koaf_bn_bwd_apply(_ptr(dz), _ptr(c), _ptr(saved[0]), _ptr(coef), _ptr(dc), rows, C, None, _stream()),
+    dc = dc_out if dc_out is not None else torch.empty(c.shape, device=c.device, dtype=torch.float32)
+    check(L.koaf_bn_bwd_apply(_ptr(dz), _ptr(c), _ptr(saved[0]), _ptr(coef), _ptr(dc), rows, C, None, _a16(c), _stream()),
           "bn_bwd_apply")
     return dc
 
@@ -465,9 +472,9 @@ def bn_bwd_from_part(part, nsum, i1, dz, c, saved, rows, C, count, dgamma, dbeta
 
 def maxpool_fwd(c, saved, N, H, W, C):
     OH, OW = conv_out(H, 3, 2, 1), conv_out(W, 3, 2, 1)
-    y = _empty((N, OH, OW, C), c)
+    y = _empty((N, OH, OW, C), c, dtype=c.dtype)
     am = _empty((N, OH, OW, C), c, dtype=torch.uint8)
-    check(lib().koaf_maxpool_fwd(_ptr(c), _ptr(saved[2]), _ptr(saved[3]), _ptr(y), _ptr(am), N, H, W, C, _stream()),
+    check(lib().koaf_maxpool_fwd(_ptr(c), _ptr(saved[2]), _ptr(saved[3]), _ptr(y), _ptr(am), N, H, W, C, _a16(c), _stream()),
           "maxpool_fwd")
     return y, am
 
@@ -480,7 +487,7 @@ def maxpool_bwd(dy, am, N, H, W, C):
 
 def gap_fwd(y, N, HW, C):
     out = _empty((N, C), y)
-    check(lib().koaf_gap_fwd(_ptr(y), _ptr(out), N, HW, C, _stream()), "gap_fwd")
+    check(lib().koaf_gap_fwd(_ptr(y), _ptr(out), N, HW, C, _a16(y), _stream()), "gap_fwd")
     return out
 
 

@@ -1,0 +1,198 @@
+"""GPU: bf16 ACTIVATION STORAGE (koaf.h; config key `activation_storage: bf16`; BASELINE.json config 2 "batch 32 bf16").
+It is a storage mode, not an arithmetic mode: a kernel widens the stored bf16 values (exact), computes exactly what the fp32
+mode computes, and only a producer's store rounds to nearest even.  So, kernel by kernel, the bf16 mode must equal -- bit for
+bit -- the fp32 mode run on the widened inputs, with the outputs rounded once (first test).  Against the fp32 mode of the same
+model the stored activations differ by 2^-9 relative per layer; the second test MEASURES what that does to logits and
+gradients of a whole model and states it (logits ~1e-2, gradients a few 1e-2: the throughput mode's error, reported by
+bench.py beside its speed; the 1e-3 parity gate is the fp32 mode's)."""
+import numpy as np
+import pytest
+import torch
+
+import procedural as P
+from common import rel
+
+pytestmark = pytest.mark.gpu
+
+G = torch.Generator().manual_seed(4321)
+
+
+def rnd(*shape, scale=1.0):
+    return torch.randn(*shape, generator=G) * scale
+
+
+def test_bf16_storage_equals_fp32_mode_on_widened_inputs(dev):
+    from oaprogressionmmf_amd import ops
+    N, H, W, Cin, Cout = 3, 20, 20, 64, 128
+    rows = N * H * W
+    x16 = rnd(N, H, W, Cin).to(dev).bfloat16()
+    x32 = x16.float()
+    sc, sh = (1.0 + 0.1 * rnd(Cin)).to(dev), (0.1 * rnd(Cin)).to(dev)
+    for k, s, p, ap in ((1, 1, 0, None), (3, 1, 1, None), (3, 1, 1, False), (3, 2, 1, None)):
+        w = rnd(Cout, k, k, Cin, scale=0.05).to(dev)
+        img = ops.build_weight_planes(w, Cout, k * k, Cin)
+        y32, st32 = ops.conv2d_fwd(x32, w, N, H, W, Cin, Cout, k, k, s, p, sc, sh, stats=True, wimg=img, aplanes=ap)
+        y16, st16 = ops.conv2d_fwd(x16, w, N, H, W, Cin, Cout, k, k, s, p, sc, sh, stats=True, wimg=img, aplanes=ap)
+        assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.bfloat16()), (k, s, ap)
+        assert torch.equal(st16, st32), (k, s, ap)            # statistics come from the fp32 accumulators
+        # gradients of the same layer: dy = BatchNorm-backward apply of (dz, c), c stored as bf16
+        OH = ops.conv_out(H, k, s, p)
+        orow = N * OH * OH
+        c16 = rnd(N, OH, OH, Cout).to(dev).bfloat16()
+        g = rnd(N, OH, OH, Cout, scale=1e-2).to(dev)
+        gam, bet = (1.0 + 0.1 * rnd(Cout)).to(dev), (0.1 * rnd(Cout)).to(dev)
+        cx16 = rnd(N, H, W, Cin).to(dev).bfloat16()          # the conv output behind x, for the fused BatchNorm-backward reduction
+        outs = []
+        for c, xx, cx in ((c16.float(), x32, cx16.float()), (c16, x16, cx16)):
+            rm, rv, nbt = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+            sv = ops.bn_finalize(ops.colstats(c, orow, Cout), Cout, orow, gam, bet, rm, rv, nbt, 0.1, 1e-5, True)
+            rmx, rvx = torch.zeros(Cin, device=dev), torch.ones(Cin, device=dev)
+            svx = ops.bn_finalize(ops.colstats(cx, rows, Cin), Cin, rows, torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev),
+                                  rmx, rvx, nbt, 0.1, 1e-5, True)
+            dg, db = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
+            apply = ops.bn_bwd(g.clone(), c, sv, orow, Cout, orow, dg, db, 2, fused=True)
+            dz, part, dzmax = ops.conv2d_dgrad(apply, w, N, H, W, Cin, Cout, k, k, s, p, wimg=img, aplanes=ap,
+                                               bnb=dict(mode=2, c=cx, saved=svx, dz_amax=True))
+            dw = torch.empty_like(w)
+            ops.conv2d_wgrad(apply, xx, dw, N, H, W, Cin, Cout, k, k, s, p, sc, sh, aplanes=ap)
+            dcm = apply.materialize(want_amax=True)
+            assert dz.dtype == dw.dtype == dcm.dtype == torch.float32          # gradients are never stored as bf16
+            outs.append((sv, dg, db, apply.coef, apply.amax, dz, part, dzmax, dw, dcm))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b), (k, s, ap)
+    # element-wise producers / consumers
+    C = Cin
+    c16, i16 = rnd(N, H, W, C).to(dev).bfloat16(), rnd(N, H, W, C).to(dev).bfloat16()
+    saved = torch.stack([0.1 * rnd(C), 1.0 + 0.1 * rnd(C), 1.0 + 0.1 * rnd(C), 0.1 * rnd(C)]).to(dev)
+    for idt16, ids in ((None, None), (i16, None), (i16, saved.flip(1).contiguous())):
+        y32 = ops.bn_add_relu(c16.float(), saved, rows, C, idt=None if idt16 is None else idt16.float(), idsaved=ids)
+        y16 = ops.bn_add_relu(c16, saved, rows, C, idt=idt16, idsaved=ids)
+        assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.bfloat16())
+    p32, a32 = ops.maxpool_fwd(c16.float(), saved, N, H, W, C)
+    p16, a16 = ops.maxpool_fwd(c16, saved, N, H, W, C)
+    assert p16.dtype == torch.bfloat16 and torch.equal(p16, p32.bfloat16()) and torch.equal(a16, a32)
+    assert torch.equal(ops.gap_fwd(c16, N, H * W, C), ops.gap_fwd(c16.float(), N, H * W, C))
+    assert torch.equal(ops.colstats(c16, rows, C), ops.colstats(c16.float(), rows, C))
+    for tf, kw in ((0, {}), (1, dict(sc=saved[2], sh=saved[3]))):
+        assert torch.equal(ops.act_planes(c16, rows, C, tf, fscale=16.0, **kw), ops.act_planes(c16.float(), rows, C, tf, fscale=16.0, **kw))
+    img_x = rnd(2, 1, 40, 36).to(dev)
+    w1t = rnd(49, 64, scale=0.1).to(dev)
+    s32, s16 = ops.stem_fwd(img_x, w1t, 2, 40, 36), ops.stem_fwd(img_x, w1t, 2, 40, 36, dtype=torch.bfloat16)
+    assert s16.dtype == torch.bfloat16 and torch.equal(s16, s32.bfloat16())
+    # grouped 3x3 (ResNeXt): forward and weight gradient read bf16 activations
+    Cg = 128
+    xg16 = rnd(N, H, W, Cg).to(dev).bfloat16()
+    wg = rnd(Cg, 3, 3, Cg // 32, scale=0.1).to(dev)
+    wexp = ops.gconv_expand_w(wg, Cg, 32)
+    scg, shg = torch.ones(Cg, device=dev), torch.zeros(Cg, device=dev)
+    yg32, sg32 = ops.gconv3x3_fwd(xg16.float(), wexp, N, H, W, Cg, 1, scg, shg, stats=True)
+    yg16, sg16 = ops.gconv3x3_fwd(xg16, wexp, N, H, W, Cg, 1, scg, shg, stats=True)
+    assert torch.equal(yg16, yg32.bfloat16()) and torch.equal(sg16, sg32)
+    dyg = rnd(N, H, W, Cg, scale=1e-2).to(dev)
+    assert torch.equal(ops.gconv3x3_wgrad(dyg, xg16, N, H, W, Cg, 1, scg, shg), ops.gconv3x3_wgrad(dyg, xg16.float(), N, H, W, Cg, 1, scg, shg))
+
+
+@pytest.mark.parametrize("case", [(256, 64, 1, 1, 64), (256, 128, 2, 1, 64), (256, 64, 1, 32, 4)], ids=["s1", "s2ds", "g32"])
+def test_bf16_storage_one_bottleneck_error(dev, case):
+    """ONE Bottleneck (three BatchNorms deep: no chaotic amplification yet), train mode, forward and backward, in both storage
+    modes from the same weights and input.  Every stored activation is rounded to 8 significand bits (2^-9 = 2e-3 relative): the
+    block output agrees with the fp32 mode to ~4e-3.  Gradients: the ReLU masks are taken from the ROUNDED pre-activations (in
+    forward and backward alike: the bf16 run is the exact gradient of its own forward), so the ~0.3 % of the elements that lie
+    within one rounding of zero take the other branch than in the fp32 mode, which alone is sqrt(0.003) = 5e-2 of a gradient's
+    norm -- measured 5e-2 ... 1e-1 per tensor.  This is the storage mode's stated gradient error (what any bf16-activation
+    training has), printed here and by bench.py."""
+    from torch import nn
+    from oaprogressionmmf_amd.arena import get_arena
+    from oaprogressionmmf_amd.models._core_fes import Bottleneck
+    from oaprogressionmmf_amd.models._encoder import EncoderFn, _block_fwd
+    inpl, planes, stride, groups, bw = case
+    N, H, W = 4, 24, 24
+    x = torch.relu(rnd(N, H, W, inpl)).to(dev)
+    gy = None
+    res = {}
+    for mode in ("fp32", "bf16"):
+        ds = None
+        if stride != 1 or inpl != planes * 4:
+            ds = nn.Sequential(nn.Conv2d(inpl, planes * 4, 1, stride=stride, bias=False), nn.BatchNorm2d(planes * 4))
+        blk = Bottleneck(inpl, planes, stride, ds, groups, bw)
+        P.fill_state_dict(blk.state_dict())
+        blk = blk.to(dev).train()
+        get_arena(blk)
+        with torch.no_grad():
+            xin = x.bfloat16() if mode == "bf16" else x
+            r = _block_fwd(blk, xin, N, H, W, True, None)
+            assert r.y.dtype == xin.dtype and r.c1.dtype == xin.dtype
+            if gy is None:
+                gy = rnd(*r.y.shape).to(dev)
+            dx = EncoderFn._blocks_bwd([r], gy.clone(), None)
+            torch.cuda.synchronize()
+        assert dx.dtype == torch.float32
+        out = {"y": r.y.float().cpu().numpy(), "dx": dx.cpu().numpy()}
+        out.update({"grad:" + k: p.grad.detach().cpu().numpy() for k, p in blk.named_parameters()})
+        out.update({"buf:" + k: b.detach().cpu().numpy() for k, b in blk.named_buffers() if b.dtype.is_floating_point})
+        res[mode] = out
+    errs = {k: rel(res["bf16"][k], v) for k, v in res["fp32"].items()}
+    worst = max(errs, key=errs.get)
+    print(f"\n[bf16 storage, one Bottleneck {case}] y {errs['y']:.1e} dx {errs['dx']:.1e}; worst {errs[worst]:.1e} ({worst}); "
+          f"median over parameter gradients {np.median([v for k, v in errs.items() if k.startswith('grad:')]):.1e}")
+    assert errs["y"] < 6e-3 and errs["dx"] < 0.12, errs
+    assert all(v < 0.15 for v in errs.values()), {k: v for k, v in errs.items() if v >= 0.15}
+    assert all(v < 5e-4 for k, v in errs.items() if k.startswith("buf:"))        # running statistics: from fp32 accumulators
+
+
+@pytest.mark.parametrize("which", ["xr1cnn_resnext", "mr1_resnet50"])
+def test_bf16_storage_model_error_against_the_fp32_mode(dev, which):
+    """the throughput mode's error, measured: same weights, same batch, one train step in both storage modes"""
+    from oaprogressionmmf_amd.config import ConfigDict
+    from oaprogressionmmf_amd.models import KoafTrunk, dict_models
+    from oaprogressionmmf_amd.various import dict_losses
+    if which == "xr1cnn_resnext":
+        cfg, B = P.cfg_xr1cnn(size=160), 4
+    else:
+        cfg, B = P.cfg_mr1(shape=(96, 96, 8), depth=1), 2
+    xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(cfg, B, 9)]
+    y = torch.from_numpy(P.make_target("target", B, 9)).to(dev)
+    loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
+    res = {}
+    # third run: the fp32 mode on inputs perturbed by ONE bf16 rounding (2^-9 relative) -- how far this (random-weight,
+    # small-batch, train-mode BatchNorm) network moves when 8-bit-significand noise enters at a single place.  Through ~50
+    # batch-statistics layers the map is chaotic (the reference's own fp32 run sits 1e-4 ... 2e-2 from its float64 twin on 1e-7
+    # noise, fixtures' e32), so the storage mode's error is stated against this sensitivity, not as an absolute bound.
+    for mode in ("fp32", "bf16", "perturbed"):
+        if mode == "perturbed":
+            xs = [x.bfloat16().float() if x.dim() >= 4 else x for x in xs]
+        m = dict_models[cfg["name"]](config=ConfigDict(dict(cfg, activation_storage="fp32" if mode == "perturbed" else mode)), path_weights=None)
+        P.fill_state_dict(m.state_dict())
+        m = m.to(dev).train()
+        trunks = [t for t in m.modules() if isinstance(t, KoafTrunk)]
+        assert trunks and all(t.act_dtype == (torch.bfloat16 if mode == "bf16" else torch.float32) for t in trunks)
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        logits = m(*xs)["main"]
+        loss = loss_fn(input=logits.squeeze(1), target=y.long().squeeze(1))
+        peak = torch.cuda.max_memory_allocated() - base
+        loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = (logits.detach().cpu().numpy(), float(loss.detach()), peak,
+                     {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None})
+        with torch.no_grad():
+            m.eval()
+            res[mode] += (m(*xs)["main"].cpu().numpy(),)
+    (l32, loss32, mem32, g32, e32), (l16, loss16, mem16, g16, e16), (lp, _, _, gp, ep) = res["fp32"], res["bf16"], res["perturbed"]
+    errs = np.array([rel(g16[k], g32[k]) for k in g32])
+    sens = np.array([rel(gp[k], g32[k]) for k in g32])
+    print(f"\n[bf16 storage, {which}] eval logits {rel(e16, e32):.2e} (input-rounding sensitivity {rel(ep, e32):.2e}); train logits "
+          f"{rel(l16, l32):.2e} (sensitivity {rel(lp, l32):.2e}), loss {abs(loss16 - loss32):.2e}; gradients: median {np.median(errs):.2e} "
+          f"worst {errs.max():.2e} (sensitivity: median {np.median(sens):.2e} worst {sens.max():.2e}); "
+          f"forward activation memory {mem16 / mem32:.2f} of the fp32 mode")
+    assert sorted(g16) == sorted(g32)
+    assert all(np.isfinite(v).all() for v in g16.values())
+    assert rel(e16, e32) < 3e-2                                   # eval mode (running statistics): ~1e-2 on logits
+    # train mode at these test sizes is the chaotic regime: ONE rounding of the input already moves the fp32 mode's logits by
+    # several 1e-2 and its gradients by ~100 % (printed), so the storage mode -- the same noise at ~50 places -- is held to a
+    # small multiple of that sensitivity; bench.py repeats the measurement at the headline batch
+    assert rel(l16, l32) < max(3e-2, 5 * rel(lp, l32))
+    assert np.median(errs) < max(0.15, 2 * np.median(sens))
+    assert mem16 < 0.85 * mem32                                   # (the peak also holds fp32 transients: plane images, statistics)
+    with pytest.raises(ValueError):
+        dict_models[cfg["name"]](config=ConfigDict(dict(cfg, activation_storage="fp8")), path_weights=None)
