@@ -261,13 +261,37 @@ def _oracle_job(cfg_fn, B, shapes=None):
     return om, xs, y
 
 
+def host_threads():
+    """threads the CPU baseline runs on: the cores this process may use -- its affinity mask, cut to the container's CPU-time
+    quota (cgroup cpu.max) when there is one: with more runnable threads than quota the kernel throttles the whole group and
+    a 64-thread run on a 16-core share is slower than a 16-thread one -- and at most 64"""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    n = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    n = min(n, 64)
+    return n, f"affinity {aff} cores, cgroup CPU quota {'none' if quota is None else f'{quota:.1f} cores'}"
+
+
 def cpu_baseline(workload):
     """The oracle (CPU port of the same train step) on this box's host cores; bounded sample."""
     import torch
     import procedural as P
     if workload in ("mr1c1", "eval3", "syn"):
         return None
-    n = min(len(os.sched_getaffinity(0)), 64)
+    n, why_n = host_threads()
     torch.set_num_threads(n)
     if workload == "syn3":
         # One knee of the headline workload is XR + 3 x 160 slices of 384^2 (minutes on a host CPU).  The slice-wise encoders
@@ -302,7 +326,7 @@ def cpu_baseline(workload):
                           f"linear in the slice count, so one knee at 160 slices = t({lo}) + {160 - lo} x (t({hi}) - t({lo})) / {hi - lo} "
                           f"= {t160:.0f} s",
                 "measured_s": {f"slices_{hi}": round(ts[hi], 2), f"slices_{lo}": round(ts[lo], 2)},
-                "extrapolated_s_per_knee": round(t160, 1),
+                "extrapolated_s_per_knee": round(t160, 1), "host": why_n,
                 "one_thread_footnote": {"value": round(1.0 / t160_1, 6), "unit": "knees/s", "cores": 1,
                                         "why": "the reference ships OMP_NUM_THREADS=1 (train_prog_fus.py:7-9)",
                                         "measured_s": {"slices_2": round(t1[2], 2), "slices_1": round(t1[1], 2)},
@@ -371,12 +395,21 @@ def main(args):
     comm_ms = []
     jobs_ddp = []
 
+    job_state = {}
+
     def make_job(name, batch, recompute="auto"):
-        """model + optimizer + resident synthetic batch of one workload -> (cfg, B, policy, step)"""
-        cfg, bdef, rdef = workload_cfg(name)
+        """model + optimizer + resident synthetic batch of one workload -> (cfg, B, policy, step).  A name ending in `_bf16`
+        is the same workload in the bf16 activation-storage mode (config key `activation_storage`), with its own default
+        recompute policy where the halved activations allow a lighter one."""
+        bf16 = name.endswith("_bf16")
+        cfg, bdef, rdef = workload_cfg(name[:-5] if bf16 else name)
+        if bf16:
+            cfg["activation_storage"] = "bf16"
+            rdef = BF16_POLICY.get(name[:-5], rdef)
         B = batch or bdef
         shapes = cfg.pop("_tensor_shapes", None)
         model = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None).to(dev)
+        job_state.update(model=model, cfg=cfg, shapes=shapes, B=B)
         policy = apply_recompute(model, rdef if (recompute == "auto" and B >= bdef) else ("none" if recompute == "auto" else recompute))
         ddp = DataParallelRCCL(model, exchange_always=dist_on)
         ddp.time_exposed = dist_on
@@ -385,6 +418,7 @@ def main(args):
         opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=bool(args.graph))
         xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(dict(cfg, input_size=shapes) if shapes else cfg, B, seed=1234 + rank)]
         y = torch.from_numpy(P.make_target("target", B, seed=1234 + rank)).to(dev)
+        job_state.update(xs=xs, y=y, loss_fn=loss_fn)
         model.train()
         if name == "eval3":
             from oaprogressionmmf_amd.run import predict_batch
@@ -525,12 +559,113 @@ def main(args):
         except (ValueError, KeyError):
             pass
 
+    def one_step_outputs(perturb=False):
+        """eval logits, train logits / loss and the flat gradient arena of ONE forward + backward of the current job's model on
+        its batch, dropout seeded alike on every call (the masks are index hashes: the same in either storage mode).
+        perturb: MRI / XR inputs rounded to bf16 once -- how far one 8-bit-significand rounding moves the fp32 mode."""
+        from oaprogressionmmf_amd.arena import get_arena
+        m, xs_, y_, lf = job_state["model"], job_state["xs"], job_state["y"], job_state["loss_fn"]
+        if perturb:
+            xs_ = [x.bfloat16().float() if x.dim() >= 4 else x for x in xs_]
+        with torch.no_grad():
+            m.eval()
+            ev = m(*xs_)["main"].float().clone()
+        m.train()
+        bufs = {k: b.detach().clone() for k, b in m.named_buffers()}
+        set_ultimate_seed(4242)
+        m.zero_grad()
+        lg = m(*xs_)["main"]
+        ls = lf(input=lg.squeeze(1), target=y_.long().squeeze(1))
+        ls.backward()
+        torch.cuda.synchronize()
+        out = dict(eval=ev, logits=lg.detach().float().clone(), loss=float(ls.detach()), grad=get_arena(m).G.clone())
+        with torch.no_grad():
+            for k, b in m.named_buffers():
+                b.copy_(bufs[k])                    # (the measurement leaves the running statistics as it found them)
+        m.zero_grad()
+        return out
+
+    def rel_(a, b):
+        return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+    def storage_pair(name, steps2, warm2, timed_fp32):
+        """the bf16 activation-storage mode of workload `name` beside its fp32 mode: throughput of both, and the MEASURED
+        difference of one train step from the same weights (eval logits, train logits, loss, the whole gradient vector) --
+        with, for scale, what a single bf16 rounding of the inputs does to the fp32 mode"""
+        res = {}
+        if timed_fp32 is None:
+            cfgf, Bf, polf, stepf = make_job(name, 0)
+            dtf, lvf, perf = timed(stepf, warm2, steps2)
+            timed_fp32 = {"value": round(world * Bf * steps2 / dtf, 3), "ms_per_step": round(dtf / steps2 * 1e3, 2), "steps": steps2,
+                          "warmup": warm2, "activation_recompute": polf}
+            del stepf
+        res["fp32"] = timed_fp32
+        ref = one_step_outputs()
+        sens = one_step_outputs(perturb=True)
+        weights = {k: v.detach().clone() for k, v in job_state["model"].state_dict().items()}
+        job_state.clear()
+        free()
+        cfgb, Bb, polb, stepb = make_job(name + "_bf16", 0)
+        job_state["model"].load_state_dict(weights)
+        del weights
+        got = one_step_outputs()
+        torch.cuda.reset_peak_memory_stats()
+        dtb, lvb, perb = timed(stepb, warm2, steps2)
+        val = world * Bb * steps2 / dtb
+        gf = algorithmic_train_gflop_per_sample(name)
+        res["bf16"] = {"value": round(val, 3), "unit": "knees/s", "ms_per_step": round(dtb / steps2 * 1e3, 2),
+                       "ms_per_step_median": round(statistics.median(perb), 2), "steps": steps2, "warmup": warm2,
+                       "per_gpu_batch": Bb, "activation_recompute": polb, "last_loss": round(lvb, 6),
+                       "hbm_peak_gib": {"allocated": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                                        "reserved": round(torch.cuda.max_memory_reserved() / 2**30, 1)},
+                       "speedup_vs_fp32_mode": round(val / res["fp32"]["value"], 3),
+                       "algorithmic_tflops": round(gf * val / 1e3 / world, 1),
+                       # SURVEY 8(d): bf16 activations put the fused conv chain at AI ~ 160 FLOP/B: HBM-bound ceiling 160 x 8 TB/s
+                       "frac_of_hbm_ceiling": round(gf * val / 1e3 / world / (160.0 * HBM_PEAK_TBPS), 4),
+                       "hbm_ceiling_is": "SURVEY 8(d): 7 x sum(conv in+out elements) x 2 B per slice against its FLOPs = AI 160 FLOP/B; "
+                                         "x 8 TB/s = 1280 TFLOP/s algorithmic",
+                       "measured_error_vs_fp32_mode": {
+                           "eval_logits_rel": float(f"{rel_(got['eval'], ref['eval']):.3e}"),
+                           "train_logits_rel": float(f"{rel_(got['logits'], ref['logits']):.3e}"),
+                           "loss_abs": float(f"{abs(got['loss'] - ref['loss']):.3e}"),
+                           "gradient_rel_l2": float(f"{rel_(got['grad'], ref['grad']):.3e}"),
+                           "for_scale_one_bf16_rounding_of_the_inputs_in_fp32_mode": {
+                               "eval_logits_rel": float(f"{rel_(sens['eval'], ref['eval']):.3e}"),
+                               "train_logits_rel": float(f"{rel_(sens['logits'], ref['logits']):.3e}"),
+                               "gradient_rel_l2": float(f"{rel_(sens['grad'], ref['grad']):.3e}")},
+                           "what": "one forward + backward from the same weights, batch and dropout masks in both storage modes; "
+                                   "rel = ||a - b|| / ||b||, gradient = the whole flat gradient arena.  Storage only: arithmetic, "
+                                   "statistics, gradients and parameters stay fp32 (tests/test_bf16_gpu.py: bit-identical to the fp32 mode on "
+                                   "widened inputs, kernel by kernel).  ReLU masks are taken from the rounded activations, which alone moves "
+                                   "a gradient by ~5e-2 per block; through ~50 train-mode BatchNorms with random weights the map amplifies "
+                                   "any perturbation (see the for_scale entry)"}}
+        del stepb, ref, sens, got
+        job_state.clear()
+        free()
+        return res
+
     secondary = {}
     if (args.workload == "syn3" and not args.batch and args.recompute == "auto" and not args.no_secondary
             and args.steps >= 10):
-        del step
-        free()
         _common.USE_LANES, _encoder.USE_SIDE_STREAM = (False, False) if args.serial else lanes_default
+        try:
+            del step
+            pr = storage_pair("syn3", 10, 3, {"value": round(world * B * args.steps / dt, 3), "ms_per_step": round(dt / args.steps * 1e3, 2),
+                                              "steps": args.steps, "warmup": args.warmup, "activation_recompute": policy})
+            secondary["syn3_bf16"] = dict(pr["bf16"], workload=WORKLOAD_TEXT["syn3"] + "; bf16 activation storage")
+        except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
+            secondary["syn3_bf16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            job_state.clear()
+            free()
+        try:
+            pr = storage_pair("xr1c1", 20, 5, None)
+            secondary["xr1c1"] = dict(pr["fp32"], per_gpu_batch=32, workload=WORKLOAD_TEXT["xr1c1"] + " (fp32 mode)")
+            secondary["xr1c1_bf16"] = dict(pr["bf16"], workload=WORKLOAD_TEXT["xr1c1"] + "; bf16 activation storage = the configuration "
+                                                                                        "as BASELINE.json writes it (batch 32 bf16)")
+        except Exception as e:  # noqa: BLE001
+            secondary["xr1c1_bf16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            job_state.clear()
+            free()
         for name in ("native3", "native"):
             try:
                 cfg2, B2, pol2, step2 = make_job(name, 0)
@@ -605,6 +740,10 @@ def main(args):
     if dist_on:
         torch.distributed.destroy_process_group()
 
+
+# recompute policies of the bf16 activation-storage mode (half the bytes per saved activation: layer3 is kept everywhere,
+# layer2 in the encoder whose backward runs first)
+BF16_POLICY = {"syn3": "01,01,0"}
 
 OOM_EXIT = 42
 FALLBACK_POLICY = "012,012,012"     # rebuild layer1-3 of every MRI encoder: ~25 GB less at the peak for ~2 % of the step

@@ -107,18 +107,34 @@ def _train_twice(m, xs, y, dev):
     return out
 
 
-def test_config2_xr_clinical_batch32_properties(dev):
-    """BASELINE config 2 as written for its size (XR 350^2 + clinical MLP head, batch 32; fp32 here -- the product has no
-    bf16 mode): eval logits of every sample equal the sample run alone (and follow a permutation), the train step is
-    deterministic with finite gradients"""
-    cfg = P.cfg_xr1c1(size=350, dropout=0.0)
-    m = _model("xr1c1", cfg, dev)
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_config2_xr_clinical_batch32_properties(dev, storage):
+    """BASELINE config 2 as written for its size -- XR 350^2 + clinical MLP head, batch 32 -- in the fp32 mode and as
+    BASELINE.json writes it, "bf16" (the activation-storage mode, `activation_storage: bf16`): eval logits of every sample
+    equal the sample run alone (and follow a permutation), the train step is deterministic with finite gradients; the bf16
+    mode's eval logits sit within 1e-2 of the fp32 mode's"""
+    cfg = dict(P.cfg_xr1c1(size=350, dropout=0.0), activation_storage=storage)
+    m = _model("xr1c1_" + storage, cfg, dev)
     xs = _inputs(cfg, 32, dev, 21)
-    _independence(m, xs, 2e-5)
-    y = torch.from_numpy(P.make_target("target", 32, 21)).to(dev)
+    _independence(m, xs, 2e-5 if storage == "fp32" else 1e-2)      # (bf16: a sample's rounded activations do not depend on its
+    y = torch.from_numpy(P.make_target("target", 32, 21)).to(dev)    #  neighbours, but tile-dependent summation order shows at 2^-9)
     (l0, g0), (l1, g1) = _train_twice(m, xs, y, dev)
     assert l0 == l1 and np.isfinite(l0)
     assert all(torch.equal(g0[k], g1[k]) and torch.isfinite(g0[k]).all() for k in g0)
+    if storage == "bf16":
+        from oaprogressionmmf_amd.models import KoafTrunk
+        assert all(t.act_dtype == torch.bfloat16 for t in m.modules() if isinstance(t, KoafTrunk))
+        m.eval()
+        with torch.no_grad():
+            e16 = m(*xs)["main"].float().clone()
+            for t in m.modules():
+                if isinstance(t, KoafTrunk):
+                    t.act_dtype = torch.float32
+            e32 = m(*xs)["main"].float()
+            for t in m.modules():
+                if isinstance(t, KoafTrunk):
+                    t.act_dtype = torch.bfloat16
+        assert rel(e16.cpu().numpy(), e32.cpu().numpy()) < 1e-2
 
 
 def test_config3_mr_clinical_160x384x384_batch4_properties(dev):
