@@ -71,7 +71,10 @@ typedef struct KoafOperand {
     int32_t _pad1;
     int32_t tf;       /* transform on load (c = source channel): 0 none; 1 relu(sc[c]*x + sh[c]); 2 (A operand, fmt 1, vector
                          path) sc[c]*x + sh[c] - sc2[c]*x2 with x2 read from ptr2 (same layout and strides as ptr): the
-                         BatchNorm-backward apply formed on load, see koaf_bn_bwd_finalize */
+                         BatchNorm-backward apply formed on load, see koaf_bn_bwd_finalize; 3 (A operand, dense K-contiguous,
+                         fmt 1 with a pre-split B) y = relu(sc[c]*x + sh[c] + x2): the BOTTLENECK TAIL relu(bn3(c3) + identity)
+                         (_torchvision.py:132-136) formed in the loader of the next block's conv1 -- koaf_bn_add_relu's
+                         arithmetic bit for bit -- with y written once to `side` by the blocks of the first column tile */
     int32_t tf_bs;    /* channel offset of sc/sh per batch index z1 (grouped-conv slabs) */
     const float* sc;
     const float* sh;
@@ -101,6 +104,7 @@ typedef struct KoafOperand {
        at planes + q*plane_stride + k*ld + r (A, gather 0; ld = channels per pixel), or gathered like a kind-1 gather-1 operand
        (B: column = tap*C + c, k = output pixel -> source pixel by H/W/PH/PW/KH/KW/stride/pad; C % 8 == 0).  Rows % 8 == 0. */
     const uint16_t* zeros;
+    float* side;        /* tf 3: where the loader stores y (same layout as ptr; nullable: y is then not kept) */
 } KoafOperand;
 
 typedef struct KoafGemm {
@@ -251,10 +255,20 @@ typedef struct KoafBnApply {
  * gathered input tiles are then DMA'd as well and x / in_sc / in_sh are not read -- bit-identical, and what the 3x3
  * convolutions use: their fp32 loader converts every element nine times.  */
 #define KOAF_ACT_SCALE 16.0f   /* activations are O(1) behind BatchNorm: |x| * 16 clamps at 65504, 2^-29 absolute resolution */
+/* tail (nullable; 1x1 / stride 1 convolutions on the fp16 scheme with wimg->f): x is the raw output c3 of the PREVIOUS block's
+ * last convolution, in_sc / in_sh its BatchNorm's coefficients, tail->idt that block's identity: the convolution's input
+ * y = relu(in_sc*x + in_sh + idt) -- the bottleneck tail, _torchvision.py:132-136 -- is formed on load (KoafOperand.tf 3) and
+ * written once to tail->y_out [N,H,W,Cin] (nullable), so the element-wise tail pass (koaf_bn_add_relu: 12 B per element) and
+ * this convolution's own read of y (4 B) become one read of c3 + idt and one write of y. */
+typedef struct KoafTail {
+    const float* idt;
+    float* y_out;
+} KoafTail;
 int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W,
                     int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                     const float* in_sc, const float* in_sh, float* stats, int32_t* stats_rows,
-                    const float* stats_shift, const KoafWImg* wimg, const uint16_t* x_planes, int32_t act16, void* stream);
+                    const float* stats_shift, const KoafWImg* wimg, const uint16_t* x_planes, const KoafTail* tail,
+                    int32_t act16, void* stream);
 /* rows of the stats buffer koaf_conv2d_fwd writes for M output pixels */
 int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout);
 /* dx [N,H,W,Cin] = conv_transpose(dy [N,OH,OW,Cout], w) (+residual: the other branch's gradient);

@@ -48,6 +48,7 @@ class KoafOperand(ctypes.Structure):
         ("ptr2", ctypes.c_void_p),
         ("sc2", ctypes.c_void_p),
         ("zeros", ctypes.c_void_p),
+        ("side", ctypes.c_void_p),
     ]
 
 
@@ -143,6 +144,10 @@ class KoafWImg(ctypes.Structure):
     _fields_ = [("f", ctypes.c_void_p), ("d", ctypes.c_void_p), ("amax", ctypes.c_void_p)]
 
 
+class KoafTail(ctypes.Structure):
+    _fields_ = [("idt", ctypes.c_void_p), ("y_out", ctypes.c_void_p)]
+
+
 class KoafBnApply(ctypes.Structure):
     _fields_ = [("dz", ctypes.c_void_p), ("c", ctypes.c_void_p), ("coef", ctypes.c_void_p), ("amax", ctypes.c_void_p)]
 
@@ -169,6 +174,8 @@ def _ctype(decl: str):
             return ctypes.POINTER(KoafWImg)
         if base == "KoafBnApply":
             return ctypes.POINTER(KoafBnApply)
+        if base == "KoafTail":
+            return ctypes.POINTER(KoafTail)
         if base == "char":
             return ctypes.c_char_p
         return ctypes.c_void_p

@@ -240,10 +240,17 @@ __global__ void __launch_bounds__(256) bn_add_relu_kernel(const float* __restric
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * EB) {
         const int cv = (int)(i % C4) * 4;
         v4f v = load4_nt<H>(c, i * 4);       // (streams: read / written once, kept out of L2's way)
-        v = v * *(const v4f*)&sc[cv] + *(const v4f*)&sh[cv];
+        // (explicit fused multiply-adds: the loader that forms this tail on load -- KoafOperand.tf 3 -- rounds exactly alike)
+        const v4f s4 = *(const v4f*)&sc[cv], h4 = *(const v4f*)&sh[cv];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], s4[j], h4[j]);
         if (idt) {
             v4f d = load4_nt<H>(idt, i * 4);
-            if (idsc) d = d * *(const v4f*)&idsc[cv] + *(const v4f*)&idsh[cv];
+            if (idsc) {
+                const v4f is4 = *(const v4f*)&idsc[cv], ih4 = *(const v4f*)&idsh[cv];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[j] = fmaf(d[j], is4[j], ih4[j]);
+            }
             v += d;
         }
 #pragma unroll

@@ -170,7 +170,8 @@ struct TileLoader {
     static_assert(!(S16 || S2_16) || VEC, "bf16 sources need the vector path");
     static constexpr int NU = ROWS / 32;
     static constexpr bool KC = mode_is_kc(MODE);
-    static constexpr int NU2 = (TF == 2) ? NU : 1;
+    static constexpr int NU2 = (TF == 2 || TF == 3) ? NU : 1;
+    static_assert(TF != 3 || (MODE == M_KC && VEC && F16), "the bottleneck-tail prologue (tf 3) serves the dense K-contiguous fp16-scheme loader");
     // registers of one k-tile in flight
     struct Slot {
         v4f r[NU];
@@ -317,7 +318,7 @@ struct TileLoader {
     // s_waitcnt lands in finish(), after the MFMAs of the tile currently in LDS.
     __device__ __forceinline__ void issue(Slot& s, const KoafOperand& op, const float* ptr, int k0, int kend, int z1) {
         const int t = threadIdx.x;
-        [[maybe_unused]] const float* ptr2 = (TF == 2) ? op.ptr2 + (ptr - op.ptr) : nullptr;   // (same batch offset)
+        [[maybe_unused]] const float* ptr2 = (TF == 2 || TF == 3) ? op.ptr2 + (ptr - op.ptr) : nullptr;   // (same batch offset; batches of one where the storage types differ)
         s.vm = 0;
         if constexpr (KC) {
             const int kk = k0 + 4 * (t & 7);
@@ -391,7 +392,7 @@ struct TileLoader {
                     if (VEC) {
                         const bool ok = rok && kok;
                         s.r[i] = load4_raw<S16>(ptr, ok ? base[i] + k0 : 0);
-                        if constexpr (TF == 2) s.r2[i] = load4_raw<S2_16>(ptr2, ok ? base[i] + k0 : 0);
+                        if constexpr (TF == 2 || TF == 3) s.r2[i] = load4_raw<S2_16>(ptr2, ok ? base[i] + k0 : 0);
                         s.vm |= (ok ? 1u : 0u) << i;
                     } else {
 #pragma unroll
@@ -464,10 +465,15 @@ struct TileLoader {
     }
 
     // transform + zero-fill of the tile issued by issue(); first consumer of the loaded registers
+    // TF 3 (the bottleneck tail formed on load): y = relu(sc[c] * x + sh[c] + x2) of the conv output x at ptr and the identity x2
+    // at ptr2 -- the arithmetic of koaf_bn_add_relu, bit for bit; y itself is written to `side` (same layout as x) when this
+    // block owns the column range (side != nullptr: the first column tile), at element offset base[i] + k0s.
+    float* side = nullptr;
+    int k0s = 0;
     __device__ __forceinline__ void finish_unit(Slot& s, int i, v4f a, v4f b, v4f k) {
         constexpr float HMAX = 65504.f;
         if constexpr (S16) s.r[i] = widen_bf16x4(__float_as_uint(s.r[i][0]), __float_as_uint(s.r[i][1]));
-        if constexpr (S2_16 && TF == 2) s.r2[i < NU2 ? i : 0] = widen_bf16x4(__float_as_uint(s.r2[i < NU2 ? i : 0][0]), __float_as_uint(s.r2[i < NU2 ? i : 0][1]));
+        if constexpr (S2_16 && (TF == 2 || TF == 3)) s.r2[i < NU2 ? i : 0] = widen_bf16x4(__float_as_uint(s.r2[i < NU2 ? i : 0][0]), __float_as_uint(s.r2[i < NU2 ? i : 0][1]));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool ok = VEC ? ((s.vm >> i) & 1u) : ((s.vm >> (4 * i + j)) & 1u);
@@ -478,15 +484,26 @@ struct TileLoader {
             } else if constexpr (TF == 2) {
                 x = fmaf(a[j], x, fmaf(-k[j], s.r2[i < NU2 ? i : 0][j], b[j]));
                 if constexpr (F16) x = __builtin_amdgcn_fmed3f(x, -HMAX, HMAX);
+            } else if constexpr (TF == 3) {
+                x = fmaxf(fmaf(x, a[j], b[j]) + s.r2[i < NU2 ? i : 0][j], 0.f);      // (a, b unscaled here: y is stored as it is)
+                if constexpr (S16) x = widen_bf16x4(round_bf16x4((v4f){x, 0.f, 0.f, 0.f}).x, 0u)[0];   // bf16 storage: everyone reads the ROUNDED y
+                s.r2[i < NU2 ? i : 0][j] = x;
+                x = fminf(x * fsc, HMAX);
             } else if constexpr (F16) {
                 x = __builtin_amdgcn_fmed3f(x * fsc, -HMAX, HMAX);
             }
             s.r[i][j] = ok ? x : 0.f;
         }
+        if constexpr (TF == 3) {
+            if (side != nullptr && ((s.vm >> i) & 1u)) {
+                if constexpr (S16) store4<true>(side, base[i] + k0s, s.r2[i < NU2 ? i : 0]);
+                else *(v4f*)(side + base[i] + k0s) = s.r2[i < NU2 ? i : 0];
+            }
+        }
     }
     __device__ __forceinline__ void finish(Slot& s) {
         v4f a = KC ? s.ts4 : kts4, b = KC ? s.th4 : kth4, k = KC ? s.tk4 : ktk4;
-        if constexpr (F16 && KC && TF != 0) { a *= fsc; b *= fsc; k *= fsc; }     // (KM coefficients were scaled once in init)
+        if constexpr (F16 && KC && TF != 0 && TF != 3) { a *= fsc; b *= fsc; k *= fsc; }     // (KM coefficients were scaled once in init)
 #pragma unroll
         for (int i = 0; i < NU; ++i) finish_unit(s, i, a, b, k);
     }
@@ -511,7 +528,7 @@ struct TileLoader {
             unsigned pl[NPL][2];
             if constexpr (F16) split2h(s.r[i], pl);
             else split3v(s.r[i], pl);
-            if constexpr (F16 && TF == 1 && KC) {
+            if constexpr (F16 && (TF == 1 || TF == 3) && KC) {
                 // saturation watch of the fixed activation scale: behind the ReLU the hi pieces are non-negative fp16, whose
                 // bits order like the values -- one packed 16-bit maximum per two elements; a tile that reached 65504 (0x7bff)
                 // clamped something (koaf.h koaf_set_status_buffer)
@@ -908,7 +925,7 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
 // convolutions gain 4-11 %, while the two-source (BatchNorm-backward apply) data-gradient kernels, whose second slot and
 // fused-reduction epilogue already fill the register file, spill 40-250 B per lane and lose 8-20 %.
 __host__ __device__ constexpr bool persist_mode(int am, int bmd, bool f16, int tfa) {
-    return f16 && bmd == M_PS && am <= M_KC_G2 && tfa != 2;
+    return f16 && bmd == M_PS && am <= M_KC_G2 && tfa != 2 && tfa != 3;
 }
 // (the persistent variants carry the next tile's A slot through the epilogue: held to two waves per SIMD = 256 registers)
 // ACT = KoafGemm.act16: which tensors of this call are bf16 ACTIVATIONS (0: none; 1 forward: A.ptr and C; 2 data gradient:
@@ -917,7 +934,7 @@ template <int BM, int BN, int AM, int BMD, int TFA, int TFB, bool VEC, bool F16,
 __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) koaf_gemm_kernel(const KoafGemm p) {
     static_assert(ACT == 0 || VEC, "bf16 activation storage needs the vector path");
     constexpr bool C16 = (ACT == 1), E16 = (ACT == 2);
-    static_assert((TFA != 2 && TFB != 2) || VEC, "the two-source prologue needs the vector path");
+    static_assert((TFA < 2 && TFB < 2) || VEC, "the two-source prologues need the vector path");
     constexpr int NPL = F16 ? 2 : 3;
     static_assert(BMD != M_PS || F16, "plane images are fp16");
     constexpr int NW = NT / 64, WGM = NW / 2;                        // waves: WGM along M x 2 along N
@@ -1001,7 +1018,8 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
     const unsigned short* Bpl = (BPS || WPS) ? p.B.planes + z0 * p.B.bs0 + z1 * p.B.bs1 : nullptr;
 
     // (the unused ones of the loaders are dead code to the compiler)
-    TileLoader<(APS || AH) ? 128 : BM, (APS || AH || WPS) ? M_KC : AM, TFA, VEC, F16, ACT == 1, (ACT == 2 || ACT == 3) && TFA == 2> la;
+    TileLoader<(APS || AH) ? 128 : BM, (APS || AH || WPS) ? M_KC : AM, TFA, VEC, F16, ACT == 1,
+               ((ACT == 2 || ACT == 3) && TFA == 2) || (ACT == 1 && TFA == 3)> la;
     TileLoader<BN, (BPS || WPS) ? M_KC : BMD, TFB, VEC, F16, ACT == 3> lb;
     PlaneKLoader<WPS ? BM : 128, false> wka;
     PlaneKLoader<BN, BMD == M_PKG> wkb;
@@ -1388,6 +1406,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
         if constexpr (BPS) lp.template issue<NPL>(p.B, Bpl, sb0);
         if constexpr (!PERSIST) la.issue(la.sa, p.A, Ap, kbeg, kend, z1);       // (PERSIST: in flight since the last tile's epilogue)
         if constexpr (!BPS) lb.issue(lb.sa, p.B, Bp, kbeg, kend, z1);
+        if constexpr (TFA == 3) { la.side = (n0 == 0) ? p.A.side : nullptr; la.k0s = kbeg; }
         la.finish(la.sa);
         la.template store<NPL>(la.sa, smem);
         if constexpr (!BPS) {
@@ -1416,6 +1435,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
         if constexpr (BPS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else __syncthreads();
         if (more) {
+            if constexpr (TFA == 3) la.k0s = k0 + BK;
             la.finish(la.sa);
             la.template store<NPL>(la.sa, smem);
             if constexpr (!BPS) {
@@ -1445,7 +1465,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
         }
     }
 
-    if constexpr (F16 && TFA == 1 && AKC && !APS && !AH && !WPS) {
+    if constexpr (F16 && (TFA == 1 || TFA == 3) && AKC && !APS && !AH && !WPS) {
         if (((la.satmax & 0xffffu) >= 0x7bffu) | ((la.satmax >> 16) >= 0x7bffu)) koaf_status_add(p.status, 0, 1u);
         la.satmax = 0u;
     }
@@ -1771,8 +1791,9 @@ int launch_modes(const KoafGemm& g, dim3 grid, hipStream_t s) {
         }
         if constexpr (F16) {
             if constexpr (ACT == 0 || ACT == 1) {
-                if (am == M_KC && bm == M_PS && ta != 2) { if (ta == 1) { KOAF_LAUNCH_P(M_KC, M_PS, 1, 0); } else { KOAF_LAUNCH_P(M_KC, M_PS, 0, 0); } }
-                if (am == M_KC_G1 && bm == M_PS && ta != 2) { if (ta) { KOAF_LAUNCH_P(M_KC_G1, M_PS, 1, 0); } else { KOAF_LAUNCH_P(M_KC_G1, M_PS, 0, 0); } }
+                if (am == M_KC && bm == M_PS && ta == 3) { KOAF_LAUNCH(M_KC, M_PS, 3, 0); }
+                if (am == M_KC && bm == M_PS && ta < 2) { if (ta == 1) { KOAF_LAUNCH_P(M_KC, M_PS, 1, 0); } else { KOAF_LAUNCH_P(M_KC, M_PS, 0, 0); } }
+                if (am == M_KC_G1 && bm == M_PS && ta < 2) { if (ta) { KOAF_LAUNCH_P(M_KC_G1, M_PS, 1, 0); } else { KOAF_LAUNCH_P(M_KC_G1, M_PS, 0, 0); } }
                 if (am == M_PA1 && bm == M_PS) { KOAF_LAUNCH(M_PA1, M_PS, 0, 0); }
             }
             if constexpr (ACT == 0 || ACT == 2) {
@@ -1947,7 +1968,10 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
                  "koaf_gemm: tapped gather needs a K-major operand");
     KOAF_REQUIRE(!(g.B.kind == 0 && g.B.gather), "koaf_gemm: K-contiguous B cannot be gathered");
     KOAF_REQUIRE(g.fmt == 0 || g.fmt == 1, "koaf_gemm: fmt must be 0 (bf16 x 3) or 1 (fp16 x 2)");
-    KOAF_REQUIRE(g.A.tf >= 0 && g.A.tf <= 2 && g.B.tf >= 0 && g.B.tf <= 1, "koaf_gemm: tf is 0 | 1 (A, B) | 2 (A)");
+    KOAF_REQUIRE(g.A.tf >= 0 && g.A.tf <= 3 && g.B.tf >= 0 && g.B.tf <= 1, "koaf_gemm: tf is 0 | 1 (A, B) | 2 | 3 (A)");
+    KOAF_REQUIRE(g.A.tf != 3 || (g.A.kind == 0 && g.A.gather == 0 && g.A.ptr2 && g.A.sc && g.A.sh && g.fmt == 1 && g.B.kind == 2 &&
+                                 g.nb0 * g.nb1 == 1 && g.splitk == 1 && aligned16(g.A.ptr2) && (!g.A.side || aligned16(g.A.side))),
+                 "koaf_gemm: the bottleneck-tail prologue (tf 3) needs a dense K-contiguous A, ptr2 / sc / sh, the fp16 scheme with a pre-split B");
     KOAF_REQUIRE(g.A.tf != 2 || (g.A.ptr2 && g.A.sc && g.A.sh && g.A.sc2 && g.fmt == 1),
                  "koaf_gemm: the two-source prologue needs ptr2 / sc / sh / sc2 and the fp16 scheme");
     if (g.B.kind == 2) {

@@ -31,7 +31,7 @@ USE_SIDE_STREAM = os.environ.get("KOAF_SIDE_STREAM", "1") != "0"
 
 
 class _Rec:
-    __slots__ = ("kind", "blk", "yin", "c1", "s1", "c2", "s2", "c3", "s3", "cd", "sd", "y", "dims", "wexp")
+    __slots__ = ("kind", "blk", "yin", "c1", "s1", "c2", "s2", "c3", "s3", "cd", "sd", "y", "dims", "wexp", "tail")
 
     def __init__(self):
         for k in self.__slots__:
@@ -43,14 +43,38 @@ def _stat_shift(bn, train):
     return bn.running_mean if (train and bn is not None and bn.running_mean is not None) else None
 
 
-def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None):
-    """bn: the BatchNorm that consumes this conv's output statistics"""
+# The bottleneck tail y = relu(bn3(c3) + identity) of a block whose identity is a plain tensor is not run as an element-wise
+# pass: the NEXT block's conv1 forms it while it loads its operand and writes y once (ops.conv2d_fwd tail_idt; koaf.h
+# KoafOperand.tf 3) -- 12 B per element of c3 / identity / y traffic instead of 12 + 4.  KOAF_FUSE_TAIL=0 keeps the pass.
+FUSE_TAIL = os.environ.get("KOAF_FUSE_TAIL", "1") != "0"
+
+
+def _can_take_tail(blk):
+    """can this block's first convolution form the previous block's tail on load?  (1x1 / stride 1 on the fp16 scheme with
+    its weight plane images current)"""
+    c = getattr(blk, "conv1", None)
+    if not (FUSE_TAIL and isinstance(blk, Bottleneck) and c is not None and ops.CONV_F16):
+        return False
+    if c.kernel_size != (1, 1) or c.stride != (1, 1) or c.groups != 1 or c.in_channels % 32:
+        return False
+    img = weight_planes(c.weight)
+    return img is not None and img[0] is not None
+
+
+def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None, tail_idt=None):
+    """bn: the BatchNorm that consumes this conv's output statistics; tail_idt: x / in_saved are the previous block's last
+    conv output and BatchNorm, tail_idt its identity -- the input is their bottleneck tail, formed on load (then the sixth
+    return value is that input, written by the convolution)"""
     w = packed_weight(conv.weight)
     cin, cout = conv.in_channels, conv.out_channels
     k, s, p, g = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.groups
     sc, sh = (in_saved[2], in_saved[3]) if in_saved is not None else (None, None)
     wexp = None
     shift = _stat_shift(bn, train)
+    if tail_idt is not None:
+        y, part, yin = ops.conv2d_fwd(x, w, N, H, W, cin, cout, k, k, s, p, sc, sh, stats=train, shift=shift,
+                                      wimg=weight_planes(conv.weight), tail_idt=tail_idt)
+        return y, part, ops.conv_out(H, k, s, p), ops.conv_out(W, k, s, p), wexp, yin
     if g == 1:
         y, part = ops.conv2d_fwd(x, w, N, H, W, cin, cout, k, k, s, p, sc, sh, stats=train, shift=shift,
                                  wimg=weight_planes(conv.weight))
@@ -255,10 +279,13 @@ def _tail_bnb(prev):
     return d
 
 
-def _block_fwd(blk, y, N, Hc, Wc, train, given):
+def _block_fwd(blk, y, N, Hc, Wc, train, given, tail=None, defer=False):
     """Forward of one residual block.  given = None: statistics are collected by the conv epilogues and
     finalised (normal forward).  given = (s1, s2, s3, sd): activation RECOMPUTE in backward -- the saved
-    BatchNorm statistics are reused, nothing is reduced and no running statistic is touched."""
+    BatchNorm statistics are reused, nothing is reduced and no running statistic is touched.
+    tail = (c_last, s_last, identity) of the PREVIOUS block whose tail was deferred (y is None then): this block's conv1 forms
+    its own input on load and writes it (r.yin).  defer: leave THIS block's tail to the next block (r.y stays None, r.tail
+    holds what the next call needs) -- only for a plain identity; the caller checks _can_take_tail(next block)."""
     r = _Rec()
     r.blk, r.yin = blk, y
     want = train and given is None
@@ -267,7 +294,11 @@ def _block_fwd(blk, y, N, Hc, Wc, train, given):
         return given[idx] if given is not None else _bn_fin(bn, part, count)
     if isinstance(blk, Bottleneck):
         r.kind = "bottleneck"
-        r.c1, part, _, _, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, want, blk.bn1)
+        if tail is not None:
+            r.c1, part, _, _, _, y = _conv_fwd(tail[0], blk.conv1, N, Hc, Wc, tail[1], want, blk.bn1, tail_idt=tail[2])
+            r.yin = y
+        else:
+            r.c1, part, _, _, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, want, blk.bn1)
         r.s1 = fin(blk.bn1, part, N * Hc * Wc, 0)
         r.c2, part, OH, OW, r.wexp = _conv_fwd(r.c1, blk.conv2, N, Hc, Wc, r.s1, want, blk.bn2)
         r.s2 = fin(blk.bn2, part, N * OH * OW, 1)
@@ -288,10 +319,36 @@ def _block_fwd(blk, y, N, Hc, Wc, train, given):
         r.cd, part, _, _, _ = _conv_fwd(y, blk.downsample[0], N, Hc, Wc, None, want, blk.downsample[1])
         r.sd = fin(blk.downsample[1], part, rows_o, 3)
         r.y = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=r.cd, idsaved=r.sd)
+    elif defer:
+        r.tail = (last_c, last_s, y)         # y = relu(bn(last_c) + identity) is formed (and written) by the next block's conv1
     else:
         r.y = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=y)
     r.dims = (N, Hc, Wc, OH, OW)
     return r
+
+
+def _blocks_fwd(blocks, y, N, Hc, Wc, train, givens=None, tail=None, defer_last=False, slim=False):
+    """forward of consecutive blocks with the bottleneck tails left to the following conv1 where possible; -> (records, y of the
+    last block or None when its tail was deferred (records[-1].tail), H, W).  tail: a deferred tail entering the first block.
+    slim: the records are not needed for backward (a stage that will be rebuilt, or no gradient at all): each one gives up its
+    conv outputs as soon as the following block has consumed them, so that only ~two blocks are alive at a time."""
+    recs, yin0 = [], None
+    for i, blk in enumerate(blocks):
+        nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+        defer = (nxt is not None and _can_take_tail(nxt)) or (nxt is None and defer_last)
+        r = _block_fwd(blk, y, N, Hc, Wc, train, givens[i] if givens is not None else None, tail=tail, defer=defer)
+        if i == 0:
+            yin0 = r.yin                     # the input of the first block (written by its conv1 when a tail came in)
+        if recs:
+            if tail is not None:
+                recs[-1].y = r.yin           # the previous block's output, written by this block's conv1
+            if slim:
+                p = recs[-1]
+                p.c1 = p.c2 = p.c3 = p.cd = p.y = p.yin = p.tail = p.wexp = None
+        recs.append(r)
+        y, Hc, Wc = r.y, r.dims[3], r.dims[4]
+        tail = r.tail
+    return recs, y, Hc, Wc, yin0
 
 
 def _recompute_plan(trunk, nstages):
@@ -340,18 +397,29 @@ class EncoderFn(torch.autograd.Function):
         if not keep:
             rset = frozenset()
         stages_saved = []
+        tail, prev_recs = None, None
+        nst = len(st["stages"])
         for si, stage in enumerate(st["stages"]):
             rec_stage = si in rset
-            sv = dict(yin=y, H=Hc, W=Wc, stats=[], recs=[], recompute=rec_stage)
-            for blk in stage:
-                r = _block_fwd(blk, y, N, Hc, Wc, train, None)
-                y, Hc, Wc = r.y, r.dims[3], r.dims[4]
-                if rec_stage:
-                    sv["stats"].append((r.s1, r.s2, r.s3, r.sd))
-                elif keep:
-                    sv["recs"].append(r)
-            if not rec_stage:
-                sv["yin"] = None
+            # (the last block's tail of this stage is left to the first conv1 of the next stage where that one can take it)
+            defer_last = si + 1 < nst and _can_take_tail(st["stages"][si + 1][0])
+            recs, y_out, Ho, Wo, yin0 = _blocks_fwd(stage, y, N, Hc, Wc, train, tail=tail, defer_last=defer_last, slim=rec_stage or not keep)
+            if tail is not None:
+                y = yin0                              # this stage's input: written by its first conv1
+                if prev_recs:
+                    prev_recs[-1].y = y               # = the previous stage's last block output
+            sv = dict(yin=y if rec_stage else None, H=Hc, W=Wc, stats=[], recs=[], recompute=rec_stage)
+            if rec_stage:
+                sv["stats"] = [(r.s1, r.s2, r.s3, r.sd) for r in recs]
+            elif keep:
+                sv["recs"] = recs
+            tail = recs[-1].tail
+            prev_recs = sv["recs"]
+            if rec_stage or not keep:
+                for r in recs:                        # (drop what is left of the conv outputs; a deferred tail holds what it needs)
+                    r.c1 = r.c2 = r.c3 = r.cd = r.yin = r.y = None
+            del recs
+            y, Hc, Wc = y_out, Ho, Wo
             stages_saved.append(sv)
         C = y.shape[-1]
         if st["gap"]:
@@ -510,13 +578,9 @@ class EncoderFn(torch.autograd.Function):
                     del r, yb
                 del y
                 continue
-            recs = []
-            for blk, given in zip(stages[si], sv["stats"]):
-                r = _block_fwd(blk, y, N, Hc2, Wc2, S["train"], given)
-                recs.append(r)
-                y, Hc2, Wc2 = r.y, r.dims[3], r.dims[4]
+            recs, y, Hc2, Wc2, _ = _blocks_fwd(stages[si], y, N, Hc2, Wc2, S["train"], givens=sv["stats"])
             dy = EncoderFn._blocks_bwd(recs, dy, side)
-            del recs, r, y
+            del recs, y
         # stem: max-pool, BN0, conv1 weight gradient (no data gradient: the input is a leaf)
         conv1, bn1 = st["conv1"], st["bn1"]
         da0 = ops.maxpool_bwd(dy, S["am"], N, H1, W1, 64)

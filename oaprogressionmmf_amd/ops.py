@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from ._lib import KoafBnApply, KoafBnb, KoafGemm, KoafError, KoafWImg, check, lib
+from ._lib import KoafBnApply, KoafBnb, KoafGemm, KoafError, KoafTail, KoafWImg, check, lib
 
 _i32 = ctypes.c_int32
 
@@ -192,11 +192,14 @@ def use_aplanes(wimg, KH, KW, C):
 
 
 def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, stats=False, shift=None, wimg=None,
-               aplanes=None):
+               aplanes=None, tail_idt=None, tail_out=None):
     """x [N,H,W,Cin] (any view with that memory), w packed [Cout,KH,KW,Cin] -> y [N,OH,OW,Cout],
     (part, rows) per-tile column statistics if stats, summed about `shift` [Cout] (hand the same tensor to bn_finalize).
     wimg = (F, D, amax) plane images of w (arena.weight_planes) or None: with them the contraction runs on the fp16
-    scheme (KoafGemm.fmt 1: half the matrix instructions, same accuracy), the weight tiles DMA'd from F."""
+    scheme (KoafGemm.fmt 1: half the matrix instructions, same accuracy), the weight tiles DMA'd from F.
+    tail_idt (1x1 / stride 1 with wimg): x is the PREVIOUS block's raw last conv output c3, in_sc / in_sh its BatchNorm
+    coefficients and tail_idt that block's identity: the input y = relu(in_sc*x + in_sh + tail_idt) (the bottleneck tail) is
+    formed on load and written to tail_out (allocated here when None); returns (y, part, tail_out)."""
     L = lib()
     OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
     y = _empty((N, OH, OW, Cout), x, dtype=x.dtype)            # (bf16 activation storage: the output follows the input)
@@ -209,19 +212,28 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
         aplanes = (APLANES_MASK & 1) and use_aplanes(wimg, KH, KW, Cin) and wimg[0] is not None and stride == 1     # (stride 2: the pre-pass
         #                                           would cut four times the pixels the kernel reads)
     xpl = None
+    tail = None
+    if tail_idt is not None:
+        if tail_out is None:
+            tail_out = torch.empty_like(x)
+        tail = ctypes.byref(KoafTail(idt=_ptr(tail_idt), y_out=_ptr(tail_out)))
+        aplanes = False
     if torch.is_tensor(aplanes):
         xpl = aplanes                   # images cut by the caller (act_planes with this call's transform and ACT_SCALE)
     elif aplanes:
         xpl = act_planes(x, N * H * W, Cin, 1 if in_sc is not None else 0, in_sc, in_sh, fscale=ACT_SCALE)
     check(L.koaf_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
                             _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _ptr(shift) if stats else None,
-                            _img(wimg), xpl.data_ptr() if xpl is not None else None, _a16(x), _stream()), "conv2d_fwd")
+                            _img(wimg), xpl.data_ptr() if xpl is not None else None, tail, _a16(x), _stream()), "conv2d_fwd")
     if xpl is not None and not torch.is_tensor(aplanes) and xpl.numel() <= KEEP_XPLANES_ELEMS:
         y._koaf_xplanes = xpl       # ride on the output: this conv's weight gradient reads them instead of cutting them again
-    _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin, f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}",
-              N * H * W * Cin + Cout * KH * KW * Cin + N * OH * OW * Cout, mpp=3 if wimg is not None else 6)
+    _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin,
+              f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}" + (" +tail" if tail is not None else ""),
+              N * H * W * Cin * (3 if tail is not None else 1) + Cout * KH * KW * Cin + N * OH * OW * Cout, mpp=3 if wimg is not None else 6)
     if stats:
         part = part[:rows.value]
+    if tail is not None:
+        return y, part, tail_out
     return y, part
 
 
