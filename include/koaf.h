@@ -432,6 +432,12 @@ int koaf_slice_fold(const float* x, float* out, int32_t B, int32_t R, int32_t Cc
 int koaf_downscale2(const float* x, float* out, int32_t B, int32_t R, int32_t Cc, int32_t S,
                     int32_t fs, void* stream);
 
+/* F.interpolate(x, scale_factor, mode = linear | bilinear | trilinear, align_corners=False, recompute_scale_factor=True) for any
+ * scale factor (preproc/_pt.py:175-192): x [BC, in_size...] -> out [BC, out_size...], ndim = 1 .. 3 spatial dimensions,
+ * out_size[d] = floor(in_size[d] * scale[d]) (computed by the caller as torch does). */
+int koaf_resize(const float* x, float* out, int64_t BC, int32_t ndim, const int32_t* in_size, const int32_t* out_size,
+                void* stream);
+
 /* ---- Transformer pieces (_core_trf.py) ------------------------------------------------------- */
 /* nn.Linear: y[M,N] = x[M,K] w[N,K]^T + b (+residual).  Small grids (few tokens) run split-K: ws = workspace
  * of koaf_linear_ws(M, N, K) floats (0 = not needed; NULL ws falls back to the unsplit kernel). */
@@ -485,21 +491,24 @@ int koaf_add(const float* a, const float* b, float* out, int64_t n, void* stream
 int64_t koaf_colsum_ws(int32_t rows, int32_t C);
 int koaf_colsum(const float* x, float* out, int32_t rows, int32_t C, float* part, void* stream);
 
-/* ---- FocalLoss (_losses.py:89-108): loss = mean|sum( -(1-pt)^gamma * logpt ) ------------------
- * logits [B,C], target int64 [B]; writes scalar loss and dlogits (= d loss / d logits).  */
-int koaf_focal_loss(const float* logits, const int64_t* target, float* loss, float* dlogits,
-                    int32_t B, int32_t C, float gamma, int32_t reduction_mean, void* stream);
-/* plain softmax-CE (CrossEntropyLoss wrapper, _losses.py:13-49), mean reduction */
-int koaf_ce_loss(const float* logits, const int64_t* target, float* loss, float* dlogits,
-                 int32_t B, int32_t C, void* stream);
+/* ---- FocalLoss (_losses.py:89-108): loss = mean|sum( -(1-pt)^gamma * logpt ), logpt = -F.cross_entropy(x, t, weight, 'none') ----
+ * logits [B,C,S] -- S = product of the spatial dims of a (b, ch, d0, d1, ...) input, 1 for (b, ch) --, target int64 [B,S],
+ * class_weight [C] or NULL; writes the scalar loss and dlogits (= d loss / d logits, same layout).  */
+int koaf_focal_loss(const float* logits, const int64_t* target, const float* class_weight, float* loss, float* dlogits,
+                    int32_t B, int32_t C, int64_t S, float gamma, int32_t reduction_mean, void* stream);
+/* softmax-CE (CrossEntropyLoss wrapper = nn.CrossEntropyLoss(weight=class_weight), _losses.py:13-49): weighted mean
+ * sum_i w[t_i] * (-log p_i[t_i]) / sum_i w[t_i] */
+int koaf_ce_loss(const float* logits, const int64_t* target, const float* class_weight, float* loss, float* dlogits,
+                 int32_t B, int32_t C, int64_t S, void* stream);
 
 /* ---- torch.optim.Adam (coupled L2) over a flat arena (_optimizers.py:47-52) ------------------ */
-int koaf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                   float beta2, float eps, float weight_decay, int32_t step, int32_t adamw,
-                   const float* hyper, void* stream);
+/* vmax (nullable): amsgrad -- the running maximum of the second moment, updated in place and used in the denominator */
+int koaf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, double beta1,
+                   double beta2, float eps, float weight_decay, int32_t step, int32_t adamw,
+                   const float* hyper, float* vmax, void* stream);
 /* Device-resident optimizer step state for captured (HIP-graph) train steps: ++*step; hyper[3] = {lr, lr / (1 - beta1^step),
  * sqrt(1 - beta2^step)} from the device scalars; hand `hyper` to koaf_adam_step (its host lr / step are then ignored). */
-int koaf_adam_hyper(int32_t* step, const float* lr, float beta1, float beta2, float* hyper, void* stream);
+int koaf_adam_hyper(int32_t* step, const float* lr, double beta1, double beta2, float* hyper, void* stream);
 int koaf_fill(float* p, float value, int64_t n, void* stream);
 
 #ifdef __cplusplus

@@ -159,6 +159,7 @@ _SCALARS = {
     "uint64_t": ctypes.c_uint64,
     "uint32_t": ctypes.c_uint32,
     "float": ctypes.c_float,
+    "double": ctypes.c_double,
 }
 
 

@@ -210,8 +210,11 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const T* __restrict__
             if (shift) dm += (double)shift[c];          // (read before running_mean, possibly the same buffer, is updated)
             m = (float)dm;
             var = (float)dv;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(dv * unbias);
+            // momentum < 0 = nn.BatchNorm2d(momentum=None): cumulative moving average, factor 1 / num_batches_tracked (which
+            // the entry point has already incremented for this batch: torch increments first, torch/nn/modules/batchnorm.py)
+            const float f = momentum < 0.f ? 1.f / (float)(*nbt) : momentum;
+            running_mean[c] = (1.f - f) * running_mean[c] + f * m;
+            running_var[c] = (1.f - f) * running_var[c] + f * (float)(dv * unbias);
         } else {
             m = running_mean[c];
             var = running_var[c];
@@ -226,7 +229,7 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const T* __restrict__
         // consumers' fp16 clamp would turn relu(NaN * x + NaN) into 0)
         if (!koaf_bits_finite(koaf_absbits(g * is)) || !koaf_bits_finite(koaf_absbits(b - m * g * is))) koaf_status_add(status, 1, 1u);
     }
-    if (train && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+    if (train && nbt && momentum >= 0.f && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
 }
 
 // y = relu(sc*c+sh [+ identity])   (H: c, idt and y are bf16 activations)
@@ -622,6 +625,41 @@ __global__ void __launch_bounds__(256) downscale2_kernel(const float* __restrict
     }
 }
 
+// F.interpolate(x, scale_factor, mode = linear | bilinear | trilinear, align_corners=False, recompute_scale_factor=True) for
+// ANY scale (preproc/_pt.py:175-192): x [BC][I0][I1][I2] -> out [BC][O0][O1][O2] (absent dimensions have size 1).  torch's rule:
+// source coordinate = (in / out) * (dst + 0.5) - 0.5 clamped at 0, its two neighbours (the upper one clamped at in - 1)
+// weighted linearly.
+struct ResizeGeom { int I[3], O[3]; float rs[3]; };
+__device__ __forceinline__ void resize_axis(int dst, int in, float rs, int& i0, int& i1, float& w1) {
+    float src = rs * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = min((int)src, in - 1);
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    w1 = src - (float)i0;
+}
+__global__ void __launch_bounds__(256) resize_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t BC,
+                                                     ResizeGeom g) {
+    const int64_t on = (int64_t)g.O[0] * g.O[1] * g.O[2], in = (int64_t)g.I[0] * g.I[1] * g.I[2];
+    const int64_t total = BC * on;
+    for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < total; i += (int64_t)gridDim.x * EB) {
+        int64_t p = i;
+        const int o2 = (int)(p % g.O[2]); p /= g.O[2];
+        const int o1 = (int)(p % g.O[1]); p /= g.O[1];
+        const int o0 = (int)(p % g.O[0]);
+        const int64_t bc = p / g.O[0];
+        int a0, a1, b0, b1, c0, c1;
+        float wa, wb, wc;
+        resize_axis(o0, g.I[0], g.rs[0], a0, a1, wa);
+        resize_axis(o1, g.I[1], g.rs[1], b0, b1, wb);
+        resize_axis(o2, g.I[2], g.rs[2], c0, c1, wc);
+        const float* xb = x + bc * in;
+        auto at = [&](int a, int b, int c) { return xb[((int64_t)a * g.I[1] + b) * g.I[2] + c]; };
+        const float v00 = at(a0, b0, c0) * (1.f - wc) + at(a0, b0, c1) * wc, v01 = at(a0, b1, c0) * (1.f - wc) + at(a0, b1, c1) * wc;
+        const float v10 = at(a1, b0, c0) * (1.f - wc) + at(a1, b0, c1) * wc, v11 = at(a1, b1, c0) * (1.f - wc) + at(a1, b1, c1) * wc;
+        out[i] = (v00 * (1.f - wb) + v01 * wb) * (1.f - wa) + (v10 * (1.f - wb) + v11 * wb) * wa;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row
 // ------------------------------------------------------------------------------------------------
@@ -827,22 +865,42 @@ __global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ p, float 
 // ------------------------------------------------------------------------------------------------
 // losses (tiny: one block)
 // ------------------------------------------------------------------------------------------------
+// logits [B][C][S] (S = product of the spatial dims of a (b, ch, d0, d1, ...) input; 1 for (b, ch)), target [B][S], cw = class
+// weights [C] or NULL.  F.cross_entropy(reduction='none', weight=cw) per element: ce = -cw[t] * log_softmax(x)[t];
+//   focal (FocalLoss, _losses.py:101-108):  logpt = -ce, pt = exp(logpt), l = -(1 - pt)^gamma * logpt, plain mean | sum over elements
+//   else  (nn.CrossEntropyLoss(weight=cw), _losses.py:36,49):  sum ce / sum cw[t]   (weighted mean)
 __global__ void __launch_bounds__(256) focal_loss_kernel(const float* __restrict__ logits,
-                                                         const int64_t* __restrict__ target, float* loss,
-                                                         float* __restrict__ dlogits, int B, int C, float gamma,
-                                                         int mean, int focal) {
+                                                         const int64_t* __restrict__ target, const float* __restrict__ cw,
+                                                         float* loss, float* __restrict__ dlogits, int B, int C, int64_t S,
+                                                         float gamma, int mean, int focal) {
     __shared__ float red[256];
+    const int64_t n = (int64_t)B * S;
+    float wsum = (float)n;
+    if (!focal && cw) {       // the weighted mean's denominator first
+        float a = 0.f;
+        for (int64_t i = threadIdx.x; i < n; i += 256) a += cw[(int)target[i]];
+        red[threadIdx.x] = a;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        wsum = red[0];
+        __syncthreads();
+    }
     float acc = 0.f;
-    const float wgt = mean ? 1.f / (float)B : 1.f;
-    for (int i = threadIdx.x; i < B; i += 256) {
-        const float* x = logits + (int64_t)i * C;
+    const float wgt = mean ? 1.f / wsum : 1.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int64_t b = i / S, sp = i - b * S;
+        const float* x = logits + b * C * S + sp;        // class j at x[j * S]
         float m = -INFINITY;
-        for (int j = 0; j < C; ++j) m = fmaxf(m, x[j]);
+        for (int j = 0; j < C; ++j) m = fmaxf(m, x[j * S]);
         float s = 0.f;
-        for (int j = 0; j < C; ++j) s += expf(x[j] - m);
+        for (int j = 0; j < C; ++j) s += expf(x[j * S] - m);
         const float lse = m + logf(s);
         const int tg = (int)target[i];
-        const float logpt = x[tg] - lse;
+        const float w = cw ? cw[tg] : 1.f;
+        const float logpt = w * (x[tg * S] - lse);
         const float pt = expf(logpt);
         float li, dl;  // loss_i, d loss_i / d logpt
         if (focal) {
@@ -856,9 +914,10 @@ __global__ void __launch_bounds__(256) focal_loss_kernel(const float* __restrict
             dl = -1.f;
         }
         acc += li;
+        float* d = dlogits + b * C * S + sp;
         for (int j = 0; j < C; ++j) {
-            const float pj = expf(x[j] - lse);
-            dlogits[(int64_t)i * C + j] = dl * ((j == tg ? 1.f : 0.f) - pj) * wgt;
+            const float pj = expf(x[j * S] - lse);
+            d[j * S] = dl * w * ((j == tg ? 1.f : 0.f) - pj) * wgt;
         }
     }
     red[threadIdx.x] = acc;
@@ -875,10 +934,10 @@ __global__ void __launch_bounds__(256) focal_loss_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // ++step; hyper = {lr, lr / (1 - b1^step), sqrt(1 - b2^step)}: what koaf_adam_step derives on the host from (lr, step), derived
 // on the device so that a captured (HIP-graph) optimizer step advances from replay to replay
-__global__ void adam_hyper_kernel(int32_t* step, const float* lr, float b1, float b2, float* hyper) {
+__global__ void adam_hyper_kernel(int32_t* step, const float* lr, double b1, double b2, float* hyper) {
     const int st = *step + 1;
     *step = st;
-    const double bc1 = 1.0 - pow((double)b1, (double)st), bc2 = 1.0 - pow((double)b2, (double)st);
+    const double bc1 = 1.0 - pow(b1, (double)st), bc2 = 1.0 - pow(b2, (double)st);
     hyper[0] = *lr;
     hyper[1] = (float)((double)*lr / bc1);
     hyper[2] = (float)sqrt(bc2);
@@ -886,21 +945,28 @@ __global__ void adam_hyper_kernel(int32_t* step, const float* lr, float b1, floa
 
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
-                                                   float b1, float b2, float eps, float wd, float step_size,
-                                                   float bc2_sqrt, int adamw, const float* __restrict__ hyper) {
+                                                   float omb1, float b2, float omb2, float eps, float wd, float step_size,
+                                                   float bc2_sqrt, int adamw, const float* __restrict__ hyper,
+                                                   float* __restrict__ vmax) {
+    // (omb1 = 1 - beta1 and omb2 = 1 - beta2 arrive rounded from the DOUBLE differences, as torch forms them: 1.f - 0.999f is
+    // 1.3e-5 away from float(1 - 0.999), which showed in the second moments)
     if (hyper) { lr = hyper[0]; step_size = hyper[1]; bc2_sqrt = hyper[2]; }   // device-resident step state (koaf_adam_hyper)
     const int64_t nvec = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * EB) {
         v4f pv = *(const v4f*)&p[i * 4], gv = *(const v4f*)&g[i * 4];
         v4f mv = *(const v4f*)&m[i * 4], vv = *(const v4f*)&v[i * 4];
+        v4f xv = {0.f, 0.f, 0.f, 0.f};
+        if (vmax) xv = *(const v4f*)&vmax[i * 4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float gj = gv[j], pj = pv[j];
             if (adamw) pj *= (1.f - lr * wd);
             else gj += wd * pj;
-            const float mj = mv[j] + (gj - mv[j]) * (1.f - b1);
-            const float vj = vv[j] * b2 + (1.f - b2) * gj * gj;
-            const float denom = sqrtf(vj) / bc2_sqrt + eps;
+            const float mj = mv[j] + (gj - mv[j]) * omb1;
+            const float vj = vv[j] * b2 + omb2 * gj * gj;
+            float vd = vj;
+            if (vmax) { vd = fmaxf(xv[j], vj); xv[j] = vd; }     // amsgrad: the running maximum of the second moment
+            const float denom = sqrtf(vd) / bc2_sqrt + eps;
             pv[j] = pj - step_size * (mj / denom);
             mv[j] = mj;
             vv[j] = vj;
@@ -908,15 +974,18 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
         *(v4f*)&p[i * 4] = pv;
         *(v4f*)&m[i * 4] = mv;
         *(v4f*)&v[i * 4] = vv;
+        if (vmax) *(v4f*)&vmax[i * 4] = xv;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = nvec * 4 + threadIdx.x;
         float gj = g[i], pj = p[i];
         if (adamw) pj *= (1.f - lr * wd);
         else gj += wd * pj;
-        const float mj = m[i] + (gj - m[i]) * (1.f - b1);
-        const float vj = v[i] * b2 + (1.f - b2) * gj * gj;
-        p[i] = pj - step_size * (mj / (sqrtf(vj) / bc2_sqrt + eps));
+        const float mj = m[i] + (gj - m[i]) * omb1;
+        const float vj = v[i] * b2 + omb2 * gj * gj;
+        float vd = vj;
+        if (vmax) { vd = fmaxf(vmax[i], vj); vmax[i] = vd; }
+        p[i] = pj - step_size * (mj / (sqrtf(vd) / bc2_sqrt + eps));
         m[i] = mj;
         v[i] = vj;
     }
@@ -953,6 +1022,13 @@ extern "C" int koaf_bn_finalize(const float* stats, int32_t rows, int32_t C, int
     KOAF_REQUIRE(!train || (stats && rows > 0 && count > 0), "koaf_bn_finalize: train mode needs stats");
     const double inv = train ? 1.0 / (double)count : 0.0;
     const double unbias = (train && count > 1) ? (double)count / (double)(count - 1) : 1.0;
+    if (train && momentum < 0.f) {
+        // cumulative average (momentum None): the factor is 1 / (the count INCLUDING this batch); the blocks of the kernel
+        // below all read it, so the increment is its own stream-ordered launch in front of them
+        KOAF_REQUIRE(num_batches_tracked, "koaf_bn_finalize: momentum < 0 (cumulative average) needs num_batches_tracked");
+        int rc = koaf_counter_add(num_batches_tracked, 1, stream);
+        if (rc != KOAF_OK) return rc;
+    }
     const int S = train ? part_reduce(stats, rows, C, 2, 1, ws, STREAM) : 0;
     if (S)
         hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((C + 63) / 64), dim3(1024), 0, STREAM, ws, S, C, inv, unbias,
@@ -1096,6 +1172,22 @@ extern "C" int koaf_downscale2(const float* x, float* out, int32_t B, int32_t R,
     return koaf_check_launch("koaf_downscale2");
 }
 
+extern "C" int koaf_resize(const float* x, float* out, int64_t BC, int32_t ndim, const int32_t* in_size, const int32_t* out_size,
+                           void* stream) {
+    KOAF_REQUIRE(x && out && BC > 0 && ndim >= 1 && ndim <= 3 && in_size && out_size, "koaf_resize: bad args (1..3 spatial dims)");
+    ResizeGeom g;
+    for (int d = 0; d < 3; ++d) {
+        const int k = d - (3 - ndim);         // leading absent dimensions have size 1
+        g.I[d] = k >= 0 ? in_size[k] : 1;
+        g.O[d] = k >= 0 ? out_size[k] : 1;
+        KOAF_REQUIRE(g.I[d] > 0 && g.O[d] > 0, "koaf_resize: empty dimension");
+        g.rs[d] = (float)g.I[d] / (float)g.O[d];
+    }
+    const int64_t total = BC * g.O[0] * g.O[1] * g.O[2];
+    hipLaunchKernelGGL(resize_kernel, dim3(ew_grid(total)), dim3(EB), 0, STREAM, x, out, BC, g);
+    return koaf_check_launch("koaf_resize");
+}
+
 extern "C" int64_t koaf_minmax_ws(int64_t n) {
     int64_t nb = cdiv64(n, 256 * 16);
     return (nb < 1 ? 1 : (nb > 256 ? 256 : nb)) * 2;      // floats per sample
@@ -1235,37 +1327,38 @@ extern "C" int64_t koaf_colsum_ws(int32_t rows, int32_t C) {
     return (int64_t)g.nblk * C;
 }
 
-extern "C" int koaf_focal_loss(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t B,
-                               int32_t C, float gamma, int32_t reduction_mean, void* stream) {
-    KOAF_REQUIRE(logits && target && loss && dlogits && B > 0 && C > 0, "koaf_focal_loss: bad args");
-    hipLaunchKernelGGL(focal_loss_kernel, dim3(1), dim3(256), 0, STREAM, logits, target, loss, dlogits, B, C, gamma,
-                       reduction_mean, 1);
+extern "C" int koaf_focal_loss(const float* logits, const int64_t* target, const float* class_weight, float* loss,
+                               float* dlogits, int32_t B, int32_t C, int64_t S, float gamma, int32_t reduction_mean,
+                               void* stream) {
+    KOAF_REQUIRE(logits && target && loss && dlogits && B > 0 && C > 0 && S > 0, "koaf_focal_loss: bad args");
+    hipLaunchKernelGGL(focal_loss_kernel, dim3(1), dim3(256), 0, STREAM, logits, target, class_weight, loss, dlogits, B, C, S,
+                       gamma, reduction_mean, 1);
     return koaf_check_launch("koaf_focal_loss");
 }
-extern "C" int koaf_ce_loss(const float* logits, const int64_t* target, float* loss, float* dlogits, int32_t B,
-                            int32_t C, void* stream) {
-    KOAF_REQUIRE(logits && target && loss && dlogits && B > 0 && C > 0, "koaf_ce_loss: bad args");
-    hipLaunchKernelGGL(focal_loss_kernel, dim3(1), dim3(256), 0, STREAM, logits, target, loss, dlogits, B, C, 0.f, 1,
-                       0);
+extern "C" int koaf_ce_loss(const float* logits, const int64_t* target, const float* class_weight, float* loss,
+                            float* dlogits, int32_t B, int32_t C, int64_t S, void* stream) {
+    KOAF_REQUIRE(logits && target && loss && dlogits && B > 0 && C > 0 && S > 0, "koaf_ce_loss: bad args");
+    hipLaunchKernelGGL(focal_loss_kernel, dim3(1), dim3(256), 0, STREAM, logits, target, class_weight, loss, dlogits, B, C, S,
+                       0.f, 1, 0);
     return koaf_check_launch("koaf_ce_loss");
 }
 
-extern "C" int koaf_adam_hyper(int32_t* step, const float* lr, float beta1, float beta2, float* hyper, void* stream) {
+extern "C" int koaf_adam_hyper(int32_t* step, const float* lr, double beta1, double beta2, float* hyper, void* stream) {
     KOAF_REQUIRE(step && lr && hyper, "koaf_adam_hyper: bad args");
     hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(1), 0, STREAM, step, lr, beta1, beta2, hyper);
     return koaf_check_launch("koaf_adam_hyper");
 }
-extern "C" int koaf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int32_t step, int32_t adamw,
-                              const float* hyper, void* stream) {
+extern "C" int koaf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, double beta1,
+                              double beta2, float eps, float weight_decay, int32_t step, int32_t adamw,
+                              const float* hyper, float* vmax, void* stream) {
     if (hyper) step = 1;      // (lr / step come from the device; the host values are ignored)
     KOAF_REQUIRE(p && g && m && v && n > 0 && step >= 1, "koaf_adam_step: bad args");
-    KOAF_REQUIRE(al16(p) && al16(g) && al16(m) && al16(v), "koaf_adam_step: unaligned");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    KOAF_REQUIRE(al16(p) && al16(g) && al16(m) && al16(v) && (!vmax || al16(vmax)), "koaf_adam_step: unaligned");
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EB), 0, STREAM, p, g, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, step_size, bc2_sqrt, adamw, hyper);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EB), 0, STREAM, p, g, m, v, n, lr, (float)(1.0 - beta1),
+                       (float)beta2, (float)(1.0 - beta2), eps, weight_decay, step_size, bc2_sqrt, adamw, hyper, vmax);
     return koaf_check_launch("koaf_adam_step");
 }

@@ -233,16 +233,16 @@ class LossFn(torch.autograd.Function):
     (koafusion/various/_losses.py:89-108; the softmax-CE backward of BASELINE.json)."""
 
     @staticmethod
-    def forward(ctx, logits, target, gamma, mean, focal):
+    def forward(ctx, logits, target, gamma, mean, focal, class_weight=None):
         lg = logits if logits.is_contiguous() else logits.contiguous()
-        loss, dl = ops.focal_loss(lg, target.contiguous(), gamma, mean=mean, focal=focal)
+        loss, dl = ops.focal_loss(lg, target.contiguous(), gamma, mean=mean, focal=focal, class_weight=class_weight)
         ctx.dl = dl
         return loss
 
     @staticmethod
     def backward(ctx, g):
         dl = ctx.dl * g
-        return dl, None, None, None, None
+        return dl, None, None, None, None, None
 
 
 def linear(x, weight, bias=None, residual=None):

@@ -88,11 +88,10 @@ def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None, tail_idt=None):
 
 def _bn_fin(bn, part, count):
     train = bn.training or bn.running_mean is None
-    if bn.momentum is None:
-        raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not built")
+    # momentum None = cumulative moving average (factor 1 / num_batches_tracked): -1 to the kernel (koaf.h koaf_bn_finalize)
     return ops.bn_finalize(part if train else None, bn.num_features, count, bn.weight.detach(), bn.bias.detach(),
-                           bn.running_mean, bn.running_var, bn.num_batches_tracked if train else None, bn.momentum,
-                           bn.eps, train, shift=_stat_shift(bn, train))
+                           bn.running_mean, bn.running_var, bn.num_batches_tracked if train else None,
+                           -1.0 if bn.momentum is None else bn.momentum, bn.eps, train, shift=_stat_shift(bn, train))
 
 
 _LANES = {}

@@ -202,6 +202,9 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     formed on load and written to tail_out (allocated here when None); returns (y, part, tail_out)."""
     L = lib()
     OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
+    if tail_idt is not None and tail_out is None:
+        tail_out = torch.empty_like(x)     # (before the output, like the element-wise tail pass it replaces: same allocation order,
+        #                                     same caching-allocator block reuse -- the other order cost 17 GB of reserved memory)
     y = _empty((N, OH, OW, Cout), x, dtype=x.dtype)            # (bf16 activation storage: the output follows the input)
     part, rows = None, _i32(0)
     if stats:
@@ -214,8 +217,6 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     xpl = None
     tail = None
     if tail_idt is not None:
-        if tail_out is None:
-            tail_out = torch.empty_like(x)
         tail = ctypes.byref(KoafTail(idt=_ptr(tail_idt), y_out=_ptr(tail_out)))
         aplanes = False
     if torch.is_tensor(aplanes):
@@ -518,6 +519,20 @@ def slice_fold(x, B, R, Cc, S):
     return out
 
 
+def resize(x, out_size):
+    """F.interpolate(x, size given as recompute_scale_factor computes it, linear | bilinear | trilinear, align_corners=False) of
+    a contiguous fp32 (B, CH, d0[, d1[, d2]]) tensor -> (B, CH, *out_size)  (koaf_resize)"""
+    nd = x.dim() - 2
+    if nd < 1 or nd > 3 or len(out_size) != nd:
+        raise KoafError(f"resize: (B, CH, 1..3 spatial dims) tensors, got {tuple(x.shape)} -> {tuple(out_size)}")
+    out = _empty(tuple(x.shape[:2]) + tuple(int(v) for v in out_size), x)
+    ins = (ctypes.c_int32 * nd)(*[int(v) for v in x.shape[2:]])
+    outs = (ctypes.c_int32 * nd)(*[int(v) for v in out_size])
+    check(lib().koaf_resize(_ptr(x), _ptr(out), int(x.shape[0]) * int(x.shape[1]), nd, ctypes.addressof(ins), ctypes.addressof(outs),
+                            _stream()), "resize")
+    return out
+
+
 def downscale2(x, B, R, Cc, S, fs):
     out = _empty((B, R // 2, Cc // 2, S // fs), x)
     check(lib().koaf_downscale2(_ptr(x), _ptr(out), B, R, Cc, S, fs, _stream()), "downscale2")
@@ -679,22 +694,29 @@ def add(a, b):
     return out
 
 
-def focal_loss(logits, target, gamma, mean=True, focal=True):
-    B, C = logits.shape
+def focal_loss(logits, target, gamma, mean=True, focal=True, class_weight=None):
+    """logits (B, C[, d0, d1, ...]) contiguous, target (B[, d0, d1, ...]) int64, class_weight (C,) or None -> (loss, dlogits)"""
+    B, C = logits.shape[0], logits.shape[1]
+    S = 1
+    for d in logits.shape[2:]:
+        S *= int(d)
+    if tuple(target.shape) != (B,) + tuple(logits.shape[2:]):
+        raise KoafError(f"loss: target shape {tuple(target.shape)} does not match logits {tuple(logits.shape)}")
     loss = _empty((), logits)
     dl = torch.empty_like(logits)
     if focal:
-        check(lib().koaf_focal_loss(_ptr(logits), _ptr(target), _ptr(loss), _ptr(dl), B, C, gamma, 1 if mean else 0,
-                                    _stream()), "focal_loss")
+        check(lib().koaf_focal_loss(_ptr(logits), _ptr(target), _ptr(class_weight), _ptr(loss), _ptr(dl), B, C, S, gamma,
+                                    1 if mean else 0, _stream()), "focal_loss")
     else:
-        check(lib().koaf_ce_loss(_ptr(logits), _ptr(target), _ptr(loss), _ptr(dl), B, C, _stream()), "ce_loss")
+        check(lib().koaf_ce_loss(_ptr(logits), _ptr(target), _ptr(class_weight), _ptr(loss), _ptr(dl), B, C, S, _stream()), "ce_loss")
     return loss, dl
 
 
-def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, adamw=False, hyper=None):
-    """hyper: optional device float[3] from adam_hyper() -- lr and step then come from the device (captured steps)"""
+def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, step, adamw=False, hyper=None, vmax=None):
+    """hyper: optional device float[3] from adam_hyper() -- lr and step then come from the device (captured steps);
+    vmax: amsgrad's running maximum of the second moment (updated in place)"""
     check(lib().koaf_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, b1, b2, eps, wd, step, 1 if adamw else 0,
-                               _ptr(hyper), _stream()), "adam_step")
+                               _ptr(hyper), _ptr(vmax), _stream()), "adam_step")
 
 
 def adam_hyper(step, lr, b1, b2, hyper):

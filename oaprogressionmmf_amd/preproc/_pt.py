@@ -11,27 +11,49 @@ from .. import ops
 
 
 class PTInterpolate(object):
+    """F.interpolate(image, scale_factor, recompute_scale_factor=True, align_corners=False, mode = linear | bilinear |
+    trilinear by rank) exactly as the reference's transform (preproc/_pt.py:175-200), for any scale factor: output size
+    floor(in * scale) per dimension, coordinates from in / out.  The recipes' factors (0.5, 0.5[, 0.5 | 1.0]) on even
+    single-channel inputs take the 2x-average-pooling kernel (identical values).  A mask raises ValueError, as in the
+    reference: its mask branch hands align_corners=False to mode="nearest", which torch refuses (fixture F8 records it)."""
+
     def __init__(self, scale_factor):
-        self.scale_factor = tuple(scale_factor) if not isinstance(scale_factor, (int, float)) else (scale_factor,)
+        self.scale_factor = tuple(scale_factor) if not isinstance(scale_factor, (int, float)) else scale_factor
+
+    def _factors(self, nd):
+        sf = self.scale_factor
+        if isinstance(sf, (int, float)):
+            return (float(sf),) * nd
+        if len(sf) != nd:
+            raise ValueError(f"scale_factor {sf} does not match the {nd} spatial dimensions of the input")
+        return tuple(float(v) for v in sf)
 
     def __call__(self, image, mask=None):
-        """image: (B, CH, D0[, D1[, D2]]) -- returns the resized image (mask is not built)"""
+        """image: (B, CH, D0[, D1[, D2]]) device tensor -> resized image"""
+        if image.ndim not in (3, 4, 5):
+            raise KeyError(image.ndim)          # (the reference indexes {3: "linear", 4: "bilinear", 5: "trilinear"})
         if mask is not None:
-            raise NotImplementedError("mask resizing is not on the train path")
-        sf = self.scale_factor
-        if all(float(s) == 1.0 for s in sf):
+            raise ValueError("align_corners option can only be set with the interpolating modes: linear | bilinear | bicubic | "
+                             "trilinear")      # (what the reference's mask branch raises, _pt.py:193-197)
+        sf = self._factors(image.ndim - 2)
+        if all(s == 1.0 for s in sf):
             return image
-        if image.shape[1] != 1:
-            raise NotImplementedError("single-channel inputs only")
         x = image.contiguous()
-        if image.ndim == 4 and tuple(map(float, sf)) == (0.5, 0.5):
-            B, _, R, C = image.shape
-            return ops.downscale2(x, B, R, C, 1, 1).view(B, 1, R // 2, C // 2)
-        if image.ndim == 5 and tuple(map(float, sf[:2])) == (0.5, 0.5) and float(sf[2]) in (0.5, 1.0):
-            B, _, R, C, S = image.shape
-            fs = 2 if float(sf[2]) == 0.5 else 1
-            return ops.downscale2(x, B, R, C, S, fs).view(B, 1, R // 2, C // 2, S // fs)
-        raise NotImplementedError(f"scale_factor {sf} is not built (the recipes use 0.5 / 1.0 only, runner.sh:347-361)")
+        if x.dtype != torch.float32:
+            x = x.float()
+        t = image
+        if t.shape[1] == 1 and all(s in (0.5, 1.0) for s in sf):
+            if t.ndim == 4 and sf == (0.5, 0.5) and t.shape[2] % 2 == 0 and t.shape[3] % 2 == 0:
+                B, _, R, C = t.shape
+                return ops.downscale2(x, B, R, C, 1, 1).view(B, 1, R // 2, C // 2)
+            if t.ndim == 5 and sf[:2] == (0.5, 0.5) and t.shape[2] % 2 == 0 and t.shape[3] % 2 == 0 and (sf[2] == 1.0 or t.shape[4] % 2 == 0):
+                B, _, R, C, S = t.shape
+                fs = 2 if sf[2] == 0.5 else 1
+                return ops.downscale2(x, B, R, C, S, fs).view(B, 1, R // 2, C // 2, S // fs)
+        out_size = [int(math.floor(float(n) * s)) for n, s in zip(t.shape[2:], sf)]     # recompute_scale_factor=True
+        if min(out_size) < 1:
+            raise ValueError(f"scale_factor {sf} empties an input of spatial size {tuple(t.shape[2:])}")
+        return ops.resize(x, out_size)
 
 
 class PTBatchAugment(object):

@@ -15,6 +15,13 @@ logger = logging.getLogger("losses")
 logger.setLevel(logging.DEBUG)
 
 
+def _weight_on(class_weight, like):
+    """class_weight (None | tensor | sequence) as a contiguous fp32 tensor on the logits' device"""
+    if class_weight is None:
+        return None
+    return torch.as_tensor(class_weight, dtype=torch.float32).to(like.device).contiguous()
+
+
 class CrossEntropyLoss(nn.Module):
     def __init__(self, num_classes, batch_avg=True, batch_weight=None, class_avg=True, class_weight=None, **kwargs):
         super().__init__()
@@ -24,11 +31,10 @@ class CrossEntropyLoss(nn.Module):
         self.batch_weight = batch_weight
         self.class_weight = class_weight
         logger.warning(f"Redundant loss function arguments:\n{repr(kwargs)}")
-        if class_weight is not None:
-            raise NotImplementedError("class_weight is not built (the reference recipes never set it)")
 
     def forward(self, input, target, **kwargs):
-        return LossFn.apply(input, target, 0.0, True, False)
+        """nn.CrossEntropyLoss(weight=class_weight) on (b, ch[, d0, d1, ...]) logits (_losses.py:36,49)"""
+        return LossFn.apply(input, target, 0.0, True, False, _weight_on(self.class_weight, input))
 
 
 class FocalLoss(nn.Module):
@@ -45,14 +51,13 @@ class FocalLoss(nn.Module):
         self.reduction = reduction
         self.gamma = gamma
         logger.warning(f"Redundant loss function arguments:\n{repr(kwargs)}")
-        if class_weight is not None:
-            raise NotImplementedError("class_weight is not built (the reference recipes never set it)")
 
     def forward(self, input, target, **kwargs):
-        """input (B, C) logits, target (B,) int64 -> scalar: mean|sum of -(1-pt)^gamma * log pt"""
-        if input.dim() != 2:
-            raise NotImplementedError("only (B, C) logits are built (the train loop passes (B, 2))")
-        return LossFn.apply(input, target, float(self.gamma), self.reduction == "mean", True)
+        """input (b, ch[, d0, d1, ...]) logits, target (b[, d0, d1, ...]) int64 -> scalar: mean|sum over all elements of
+        -(1-pt)^gamma * logpt with logpt = -F.cross_entropy(input, target, weight=class_weight, reduction='none')"""
+        if input.dim() < 2:
+            raise ValueError("FocalLoss: logits need a class dimension (b, ch, ...)")
+        return LossFn.apply(input, target, float(self.gamma), self.reduction == "mean", True, _weight_on(self.class_weight, input))
 
 
 dict_losses = {

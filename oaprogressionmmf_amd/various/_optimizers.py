@@ -19,11 +19,9 @@ class Adam(optim.Optimizer):
         """capturable (as in torch.optim.Adam): learning rate and step count live in device memory (koaf_adam_hyper), so that
         step() can be captured into a HIP graph and still advance on every replay (run.GraphedTrainStep); arena parameters
         only, one shared update count (every trained parameter receives a gradient every step)."""
-        if amsgrad:
-            raise NotImplementedError("amsgrad is not built")
         if lr < 0 or eps < 0 or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=bool(amsgrad)))
         self.capturable = bool(capturable)
         self._dev = {}       # capturable: (id(arena), group index) -> dict(step int32[1], lr float[1], hyper float[3], lr_host)
         self._flat = {}      # id(arena) -> dict(m, v) flat moment buffers
@@ -57,7 +55,7 @@ class Adam(optim.Optimizer):
                         # (its step count would live on the host: a captured step would replay with a frozen count)
                         raise RuntimeError("koaf Adam(capturable=True) updates arena parameters only: this parameter lives "
                                            "outside the model's arena (run one forward of the model before the first step)")
-                    self._step_loose(p, lr, b1, b2, eps, wd)
+                    self._step_loose(p, lr, b1, b2, eps, wd, ams=bool(group.get("amsgrad")))
             for a, plist in by_arena.values():
                 stt = self._arena_state(a)
                 if self.capturable:
@@ -70,10 +68,11 @@ class Adam(optim.Optimizer):
                     n = self._steps.get(id(p), 0) + 1
                     self._steps[id(p)] = n
                     by_step.setdefault(n, []).append(p)
+                vmax = self._vmax(stt, a.P) if group.get("amsgrad") else None
                 for n, ps in by_step.items():
                     for lo, hi in a.active_ranges(ps):
                         ops.adam_step(a.P[lo:hi], a.G[lo:hi], stt["m"][lo:hi], stt["v"][lo:hi], hi - lo, lr, b1, b2,
-                                      eps, wd, n, self._ADAMW)
+                                      eps, wd, n, self._ADAMW, vmax=vmax[lo:hi] if vmax is not None else None)
                 a.epoch += 1             # the weights changed under the arena's plane images (arena.ensure_planes)
         return loss
 
@@ -101,9 +100,10 @@ class Adam(optim.Optimizer):
             self.sync_hyper()
         d["params"].update(id(p) for p in plist)
         ops.adam_hyper(d["step"], d["lr"], b1, b2, d["hyper"])
+        vmax = self._vmax(stt, a.P) if group.get("amsgrad") else None
         for lo, hi in a.active_ranges(plist):
             ops.adam_step(a.P[lo:hi], a.G[lo:hi], stt["m"][lo:hi], stt["v"][lo:hi], hi - lo, lr, b1, b2, eps, wd, 1,
-                          self._ADAMW, hyper=d["hyper"])
+                          self._ADAMW, hyper=d["hyper"], vmax=vmax[lo:hi] if vmax is not None else None)
         a.epoch += 1
 
     def _sync_steps(self):
@@ -112,6 +112,13 @@ class Adam(optim.Optimizer):
             n = int(d["step"].item())
             for pid in d["params"]:
                 self._steps[pid] = n
+
+    @staticmethod
+    def _vmax(stt, like):
+        """amsgrad: the running maximum of the second moment, a flat twin of `v` (created on first use)"""
+        if "vmax" not in stt:
+            stt["vmax"] = torch.zeros_like(like)
+        return stt["vmax"]
 
     def _arena_state(self, a):
         stt = self._flat.get(id(a))
@@ -128,19 +135,21 @@ class Adam(optim.Optimizer):
         return stt
 
     # ---- checkpointing: torch.optim.Adam's state_dict layout, so either side resumes the other's run ----------
-    def _moments(self, p, create=False):
-        """(exp_avg, exp_avg_sq) of p as tensors of p's logical shape (views of the flat buffers), or None"""
+    def _moments(self, p, create=False, amsgrad=False):
+        """(exp_avg, exp_avg_sq[, max_exp_avg_sq]) of p as tensors of p's logical shape (views of the flat buffers), or None"""
         a = getattr(p, "_koaf_arena", None)
         if a is not None and a.valid():
             if id(a) not in self._flat and not create:
                 return None
             stt = self._arena_state(a)
             o, n = a.slot(p)
-            return a._view(stt["m"], o, n, p), a._view(stt["v"], o, n, p)
+            out = (a._view(stt["m"], o, n, p), a._view(stt["v"], o, n, p))
+            return out + (a._view(self._vmax(stt, a.P), o, n, p),) if amsgrad else out
         if id(p) not in self._loose and not create:
             return None
         stt = self._loose_state(p)
-        return stt["m"].view(p.shape), stt["v"].view(p.shape)
+        out = (stt["m"].view(p.shape), stt["v"].view(p.shape))
+        return out + (self._vmax(stt, stt["v"]).view(p.shape),) if amsgrad else out
 
     def _place_pending(self):
         """moments loaded by load_state_dict() go to their flat buffers once the parameters' final placement is known
@@ -152,24 +161,26 @@ class Adam(optim.Optimizer):
                     continue
                 if not p.is_cuda:
                     raise RuntimeError("koaf Adam updates HIP-resident parameters only (no CPU fallback)")
-                m, v = self._moments(p, create=True)
-                m.copy_(mv[0].to(device=p.device, dtype=torch.float32))
-                v.copy_(mv[1].to(device=p.device, dtype=torch.float32))
+                dst = self._moments(p, create=True, amsgrad=len(mv) > 2)
+                for d, src in zip(dst, mv):
+                    d.copy_(src.to(device=p.device, dtype=torch.float32))
         self._pending = {}
 
     def state_dict(self):
         if self.capturable:
             self._sync_steps()
         sd = super().state_dict()            # param_groups with index lists; `state` is kept outside self.state
-        params = [p for g in self.param_groups for p in g["params"]]
+        params = [(p, bool(g.get("amsgrad"))) for g in self.param_groups for p in g["params"]]
         state = {}
-        for idx, p in enumerate(params):
+        for idx, (p, ams) in enumerate(params):
             n = self._steps.get(id(p), 0)
-            mv = self._pending.get(id(p)) or (self._moments(p) if n else None)   # loaded but not yet placed / live
+            mv = self._pending.get(id(p)) or (self._moments(p, amsgrad=ams) if n else None)   # loaded but not yet placed / live
             if mv is None:
                 continue                      # never updated (no gradient so far): torch has no entry either
             state[idx] = dict(step=torch.tensor(float(n)), exp_avg=mv[0].detach().to("cpu").contiguous().clone(),
                               exp_avg_sq=mv[1].detach().to("cpu").contiguous().clone())
+            if len(mv) > 2:
+                state[idx]["max_exp_avg_sq"] = mv[2].detach().to("cpu").contiguous().clone()
         sd["state"] = state
         return sd
 
@@ -192,18 +203,20 @@ class Adam(optim.Optimizer):
         for stt in list(self._flat.values()) + list(self._loose.values()):
             stt["m"].zero_()
             stt["v"].zero_()
+            if "vmax" in stt:
+                stt["vmax"].zero_()
         for key, st in state_dict["state"].items():
             p = params[ids.index(key)] if key in ids else None
             if p is None:
                 raise KeyError(f"optimizer state for unknown parameter index {key}")
-            if st.get("amsgrad") or "max_exp_avg_sq" in st:
-                raise NotImplementedError("amsgrad state is not built")
             if tuple(st["exp_avg"].shape) != tuple(p.shape):
                 raise ValueError(f"optimizer state shape {tuple(st['exp_avg'].shape)} != parameter shape {tuple(p.shape)}")
             self._pending[id(p)] = (st["exp_avg"].detach().clone(), st["exp_avg_sq"].detach().clone())
+            if "max_exp_avg_sq" in st:
+                self._pending[id(p)] += (st["max_exp_avg_sq"].detach().clone(),)
             self._steps[id(p)] = int(round(float(st["step"])))
 
-    def _step_loose(self, p, lr, b1, b2, eps, wd):
+    def _step_loose(self, p, lr, b1, b2, eps, wd, ams=False):
         if not p.is_cuda:
             raise RuntimeError("koaf Adam updates HIP-resident parameters only (no CPU fallback)")
         stt = self._loose_state(p)
@@ -211,7 +224,8 @@ class Adam(optim.Optimizer):
         self._steps[id(p)] = n
         pc = p.data.contiguous().view(-1)
         g = p.grad.contiguous().view(-1)
-        ops.adam_step(pc, g, stt["m"], stt["v"], pc.numel(), lr, b1, b2, eps, wd, n, self._ADAMW)
+        ops.adam_step(pc, g, stt["m"], stt["v"], pc.numel(), lr, b1, b2, eps, wd, n, self._ADAMW,
+                      vmax=self._vmax(stt, stt["v"]) if ams else None)
         if pc.data_ptr() != p.data.data_ptr():
             p.data.copy_(pc.view_as(p.data))
 

@@ -450,16 +450,21 @@ def forward(cfg, sd, inputs, train):
 # ------------------------------------------------------------------------------------------------
 # loss, downscale, schedules, optimizer
 # ------------------------------------------------------------------------------------------------
-def focal_loss(logits, target, gamma=2.0, reduction="mean"):
-    """FocalLoss.forward (koafusion/various/_losses.py:101-108)"""
-    logpt = -F.cross_entropy(logits, target, reduction="none")
+def focal_loss(logits, target, gamma=2.0, reduction="mean", class_weight=None):
+    """FocalLoss.forward (koafusion/various/_losses.py:101-108); logits (b, ch[, d0, d1]), target (b[, d0, d1])"""
+    logpt = -F.cross_entropy(logits, target, weight=class_weight, reduction="none")
     pt = torch.exp(logpt)
     loss = -((1 - pt) ** gamma) * logpt
     return loss.mean() if reduction == "mean" else loss.sum()
 
 
+def ce_loss(logits, target, class_weight=None):
+    """CrossEntropyLoss.forward = nn.CrossEntropyLoss(weight=class_weight) (koafusion/various/_losses.py:36,49)"""
+    return F.cross_entropy(logits, target, weight=class_weight)
+
+
 def interpolate(x, scale_factor):
-    """PTInterpolate.__call__ (koafusion/preproc/_pt.py:179-200)"""
+    """PTInterpolate.__call__ (koafusion/preproc/_pt.py:179-200), image branch (the mask branch raises in the reference)"""
     mode = {3: "linear", 4: "bilinear", 5: "trilinear"}[x.ndim]
     return F.interpolate(x, scale_factor=scale_factor, recompute_scale_factor=True, align_corners=False, mode=mode)
 

@@ -375,6 +375,25 @@ def case_f7_focal(losses, **_):
     loss.backward()
     out["ce:loss"] = np.float64(loss.item())
     out["ce:dlogits"] = lt.grad.numpy().copy()
+    # the documented input of FocalLoss.forward is (b, ch, d0, d1) with target (b, d0, d1) (_losses.py:91-94), and both
+    # losses take class weights (:56-57,36): 3 classes on a 5 x 4 grid, weights (0.2, 1.0, 3.0)
+    lg4 = P.make_input("focal4", (3, 3, 5, 4)) * 2
+    tg4 = (np.abs(P.make_input("focal4_t", (3, 5, 4))) * 1.7).astype(np.int64) % 3
+    cw = np.array([0.2, 1.0, 3.0], dtype=np.float32)
+    out.update({"nd:logits": lg4, "nd:target": tg4, "nd:class_weight": cw})
+    for tag, weight in (("nd", None), ("ndw", t(cw))):
+        for red in ("mean", "sum"):
+            l4 = t(lg4).requires_grad_(True)
+            fl = losses.FocalLoss(reduction=red, gamma=2.0, num_classes=3, class_weight=weight)
+            loss = fl(input=l4, target=t(tg4))
+            loss.backward()
+            out[f"{tag}:focal_{red}:loss"] = np.float64(loss.item())
+            out[f"{tag}:focal_{red}:dlogits"] = l4.grad.numpy().copy()
+        l4 = t(lg4).requires_grad_(True)
+        loss = losses.CrossEntropyLoss(num_classes=3, class_weight=weight)(l4, t(tg4))
+        loss.backward()
+        out[f"{tag}:ce:loss"] = np.float64(loss.item())
+        out[f"{tag}:ce:dlogits"] = l4.grad.numpy().copy()
     np.savez_compressed(HERE / "f7_focal.npz", **out)
     print("  wrote f7_focal.npz")
 
@@ -386,6 +405,20 @@ def case_f8_interp(preproc, **_):
     v = t(P.make_input("interp_mr", (2, 1, 36, 28, 26)))
     out["mr_half"] = preproc.PTInterpolate(scale_factor=(0.5, 0.5, 0.5))(v).numpy()
     out["mr_keep"] = preproc.PTInterpolate(scale_factor=(0.5, 0.5, 1.0))(v).numpy()
+    # any scale factor (the transform takes whatever the config's `downscale` holds): odd sizes, up- and down-scaling,
+    # several channels and the 3-D (B, CH, D0) "linear" rank.  (The transform's MASK branch passes align_corners=False together
+    # with mode="nearest", which torch refuses -- ValueError: it is dead code in the reference, recorded below as such.)
+    x2 = t(P.make_input("interp_xr2", (2, 3, 37, 29)))
+    v2 = t(P.make_input("interp_mr2", (1, 2, 19, 23, 11)))
+    l2 = t(P.make_input("interp_lin", (2, 2, 41)))
+    for tag, img, sf in (("xr_075", x2, (0.75, 0.75)), ("xr_up", x2, (1.5, 2.0)), ("xr_mix", x, (0.3, 0.85)),
+                         ("mr_mix", v2, (0.6, 0.8, 1.0)), ("mr_up", v2, (1.3, 0.5, 2.0)), ("lin", l2, (0.4,))):
+        out[tag] = preproc.PTInterpolate(scale_factor=sf)(img).numpy()
+    try:
+        preproc.PTInterpolate(scale_factor=(0.75, 0.6))(x2, (x2 > 0.3).float())
+        out["mask_branch"] = np.array("returns")
+    except ValueError as e:
+        out["mask_branch"] = np.array("ValueError: " + str(e))
     np.savez_compressed(HERE / "f8_interp.npz", **out)
     print("  wrote f8_interp.npz")
 

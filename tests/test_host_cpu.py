@@ -210,6 +210,27 @@ def test_adamw_takes_capturable():
         opt.step()                   # a parameter outside an arena cannot take a device-resident step count
 
 
+def test_fused_adam_amsgrad_state_round_trip():
+    """Adam(amsgrad=True): the registry accepts it like torch's, and torch.optim.Adam's state (with max_exp_avg_sq) loads and
+    comes back unchanged -- no device involved"""
+    from oaprogressionmmf_amd.various import dict_optimizers
+    torch.manual_seed(1)
+    ps = [torch.nn.Parameter(torch.randn(4, 3, 3, 3)), torch.nn.Parameter(torch.randn(7))]
+    ref = torch.optim.Adam(ps, lr=3e-4, amsgrad=True)
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    ref.step()
+    sd = ref.state_dict()
+    mine = dict_optimizers["Adam"](ps, lr=1.0, amsgrad=True)
+    mine.load_state_dict(sd)
+    out = mine.state_dict()
+    assert out["param_groups"][0]["amsgrad"] is True
+    for k, st in sd["state"].items():
+        for name in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+            assert torch.equal(out["state"][k][name], st[name]), (k, name)
+        assert float(out["state"][k]["step"]) == float(st["step"])
+
+
 def test_fused_adam_state_dict_is_torch_layout():
     """resume bookkeeping without a device: a torch.optim.Adam state_dict loads into the fused Adam and comes back
     unchanged (same keys, steps, moment tensors, hyper-parameters); nothing is computed on the CPU"""

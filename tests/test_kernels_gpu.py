@@ -779,3 +779,79 @@ def test_bottleneck_tail_formed_in_the_conv1_loader(dev, C, Cout, bf16):
     big[2] = 5000.0
     ops.conv2d_fwd(c3, w, N, H, W, C, Cout, 1, 1, 1, 0, big[2], big[3], wimg=img, tail_idt=idt)
     assert ops.numerics_status(reset=True)["saturated"] > 0
+
+
+def test_losses_on_spatial_logits_with_class_weights_vs_reference(dev):
+    """FocalLoss / CrossEntropyLoss as the reference documents them: (b, ch, d0, d1) logits with a (b, d0, d1) target, and
+    class weights (_losses.py:36,56-57,91-108) -- fixture F7's extension, produced by the imported reference"""
+    from oaprogressionmmf_amd.various import dict_losses
+    g = load("f7_focal.npz")
+    lg, tg, cw = torch.from_numpy(g["nd:logits"]).to(dev), torch.from_numpy(g["nd:target"]).to(dev), torch.from_numpy(g["nd:class_weight"])
+    for tag, w in (("nd", None), ("ndw", cw)):
+        for red in ("mean", "sum"):
+            x = lg.clone().requires_grad_(True)
+            loss = dict_losses["FocalLoss"](reduction=red, gamma=2.0, num_classes=3, class_weight=w)(input=x, target=tg)
+            loss.backward()
+            ref = float(g[f"{tag}:focal_{red}:loss"])
+            assert abs(loss.item() - ref) < 2e-6 * max(1.0, abs(ref)), (tag, red)
+            assert rel_err(x.grad, torch.from_numpy(g[f"{tag}:focal_{red}:dlogits"])) < 1e-5, (tag, red)
+        x = lg.clone().requires_grad_(True)
+        loss = dict_losses["CrossEntropyLoss"](num_classes=3, class_weight=w)(x, tg)
+        loss.backward()
+        assert abs(loss.item() - float(g[f"{tag}:ce:loss"])) < 2e-6
+        assert rel_err(x.grad, torch.from_numpy(g[f"{tag}:ce:dlogits"])) < 1e-5
+
+
+def test_interpolate_any_scale_vs_reference(dev):
+    """PTInterpolate for any scale factor (the reference hands the config's `downscale` to F.interpolate: _pt.py:175-192):
+    odd sizes, up- and down-scaling, several channels, the (B, CH, D0) linear rank -- fixture F8's extension; the mask branch
+    raises ValueError exactly like the reference's (dead) one"""
+    from oaprogressionmmf_amd.preproc import PTInterpolate
+    g = load("f8_interp.npz")
+    mk = lambda name, shape: torch.from_numpy(P.make_input(name, shape)).to(dev)   # noqa: E731
+    x, x2, v2, l2 = mk("interp_xr", (2, 1, 70, 50)), mk("interp_xr2", (2, 3, 37, 29)), mk("interp_mr2", (1, 2, 19, 23, 11)), mk("interp_lin", (2, 2, 41))
+    for tag, img, sf in (("xr_075", x2, (0.75, 0.75)), ("xr_up", x2, (1.5, 2.0)), ("xr_mix", x, (0.3, 0.85)),
+                         ("mr_mix", v2, (0.6, 0.8, 1.0)), ("mr_up", v2, (1.3, 0.5, 2.0)), ("lin", l2, (0.4,))):
+        out = PTInterpolate(scale_factor=sf)(img)
+        assert tuple(out.shape) == g[tag].shape, (tag, out.shape, g[tag].shape)
+        assert float((out.cpu() - torch.from_numpy(g[tag])).abs().max()) < 2e-6 * float(np.abs(g[tag]).max()), tag
+    assert str(g["mask_branch"]).startswith("ValueError")
+    with pytest.raises(ValueError):
+        PTInterpolate(scale_factor=(0.75, 0.6))(x2, (x2 > 0.3).float())
+    assert PTInterpolate(scale_factor=(1.0, 1.0))(x2) is x2
+    # the recipes' factors still take the average-pooling kernel, with the same values as the general one
+    a = PTInterpolate(scale_factor=(0.5, 0.5))(x)
+    from oaprogressionmmf_amd import ops
+    b = ops.resize(x, [35, 25])
+    assert float((a - b).abs().max()) < 1e-6 and rel_err(a, torch.from_numpy(g["xr"])) < 1e-6
+
+
+def test_adam_amsgrad_and_batchnorm_cumulative_average(dev):
+    """the two optimiser / normalisation options the registries accept from torch that were declared holes: Adam(amsgrad=True)
+    against torch.optim.Adam on the same gradients, and BatchNorm2d(momentum=None) -- cumulative moving average, factor
+    1 / num_batches_tracked -- against nn.BatchNorm2d on the CPU"""
+    from oaprogressionmmf_amd import ops
+    n = 10007
+    p0, gs = rnd(n), [rnd(n) * (3.0 if s == 0 else 1.0) for s in range(4)]       # (a large first gradient: the maximum matters)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pr], lr=1e-3, weight_decay=1e-4, amsgrad=True)
+    pd = p0.clone().to(dev)
+    m, v, vmax = torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for s in range(4):
+        pr.grad = gs[s].clone()
+        opt.step()
+        ops.adam_step(pd, gs[s].to(dev), m, v, n, 1e-3, 0.9, 0.999, 1e-8, 1e-4, s + 1, vmax=vmax)
+    assert rel_err(pd, pr.detach()) < 1e-6
+    assert rel_err(vmax, opt.state[pr]["max_exp_avg_sq"]) < 1e-6 and float((vmax - v).max()) > 0
+    # BatchNorm2d(momentum=None) over three batches
+    C, rows = 64, 500
+    bn = torch.nn.BatchNorm2d(C, momentum=None).train()
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    nbt = torch.zeros(1, dtype=torch.int64, device=dev)
+    gam, bet = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    for it in range(3):
+        xb = rnd(rows, C) * (1.0 + it) + 0.3 * it
+        bn(xb.t().reshape(1, C, rows, 1))
+        ops.bn_finalize(ops.colstats(xb.to(dev), rows, C), C, rows, gam, bet, rm, rv, nbt, -1.0, 1e-5, True)
+        assert int(nbt) == it + 1 == int(bn.num_batches_tracked)
+        assert rel_err(rm, bn.running_mean) < 1e-5 and rel_err(rv, bn.running_var) < 1e-5

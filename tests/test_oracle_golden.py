@@ -236,7 +236,26 @@ def test_oracle_focal_interp_sched():
         loss.backward()
         assert abs(loss.item() - float(g[f"focal_{red}:loss"])) < 1e-6 * max(1, abs(float(g[f"focal_{red}:loss"])))
         assert rel(lt.grad.numpy(), g[f"focal_{red}:dlogits"]) < 1e-6
+    # (b, ch, d0, d1) logits and class weights (_losses.py:56-57,91-94), both losses
+    lg4, tg4, cw = t(g["nd:logits"]), t(g["nd:target"]), t(g["nd:class_weight"])
+    for tag, w in (("nd", None), ("ndw", cw)):
+        for red in ("mean", "sum"):
+            l4 = lg4.clone().requires_grad_(True)
+            loss = O.focal_loss(l4, tg4, 2.0, red, class_weight=w)
+            loss.backward()
+            assert abs(loss.item() - float(g[f"{tag}:focal_{red}:loss"])) < 1e-6 * max(1, abs(float(g[f"{tag}:focal_{red}:loss"])))
+            assert rel(l4.grad.numpy(), g[f"{tag}:focal_{red}:dlogits"]) < 1e-6
+        l4 = lg4.clone().requires_grad_(True)
+        loss = O.ce_loss(l4, tg4, class_weight=w)
+        loss.backward()
+        assert abs(loss.item() - float(g[f"{tag}:ce:loss"])) < 1e-6 and rel(l4.grad.numpy(), g[f"{tag}:ce:dlogits"]) < 1e-6
     g = load("f8_interp.npz")
+    x2, v2, l2 = t(P.make_input("interp_xr2", (2, 3, 37, 29))), t(P.make_input("interp_mr2", (1, 2, 19, 23, 11))), t(P.make_input("interp_lin", (2, 2, 41)))
+    for tag, img, sf in (("xr_075", x2, (0.75, 0.75)), ("xr_up", x2, (1.5, 2.0)), ("xr_mix", t(P.make_input("interp_xr", (2, 1, 70, 50))), (0.3, 0.85)),
+                         ("mr_mix", v2, (0.6, 0.8, 1.0)), ("mr_up", v2, (1.3, 0.5, 2.0)), ("lin", l2, (0.4,))):
+        got = O.interpolate(img, sf).numpy()
+        assert got.shape == g[tag].shape and rel(got, g[tag]) < 1e-7, tag
+    assert str(g["mask_branch"]).startswith("ValueError")        # the reference's mask branch is dead code
     assert rel(O.interpolate(t(P.make_input("interp_xr", (2, 1, 70, 50))), (0.5, 0.5)).numpy(), g["xr"]) < 1e-7
     v = t(P.make_input("interp_mr", (2, 1, 36, 28, 26)))
     assert rel(O.interpolate(v, (0.5, 0.5, 0.5)).numpy(), g["mr_half"]) < 1e-7
