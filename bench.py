@@ -746,7 +746,11 @@ def main(args):
 BF16_POLICY = {"syn3": "01,01,0"}
 
 OOM_EXIT = 42
-FALLBACK_POLICY = "012,012,012"     # rebuild layer1-3 of every MRI encoder: ~25 GB less at the peak for ~2 % of the step
+# Every stage of every trunk rebuilt ONE BLOCK AT A TIME: the rebuilt activations alive at once shrink from a whole stage
+# (layer1 of one encoder: 102 GB at batch 8) to one block plus the stage's block inputs -- ~20 GB less at the peak, for one
+# more forward of most blocks.  (Moving layer3 of the third encoder into the rebuilt set, "012,012,012", does NOT lower the
+# peak: it sits at that encoder's layer1 rebuild either way -- measured in tests/test_fullsize_gpu.py.)
+FALLBACK_POLICY = "block"
 
 
 def is_oom(e):
@@ -764,10 +768,11 @@ def fallback_argv(argv):
 
 
 def launch_with_fallback(args, argv, program=None):
-    """start the ranks; if one of them ran out of memory on the headline's default policy, ONE more launch with the leaner one"""
+    """start the ranks; if one of them ran out of memory on the headline's default policy, ONE more launch with the leaner one
+    (FALLBACK_POLICY)"""
     rc = launch_workers(args.gpus, argv, program=program)
     if rc != 0 and OOM_EXIT in LAST_WORKER_CODES and fallback_allowed(args):
-        print(f"bench.py: a rank ran out of memory with the default recompute policy: one retry with {FALLBACK_POLICY}", file=sys.stderr)
+        print(f"bench.py: a rank ran out of memory with the default recompute policy: one retry with --recompute {FALLBACK_POLICY}", file=sys.stderr)
         os.environ["KOAF_BENCH_OOM_RETRY"] = "1"
         try:
             rc = launch_workers(args.gpus, fallback_argv(argv), program=program)

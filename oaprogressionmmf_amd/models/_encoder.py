@@ -61,7 +61,7 @@ def _can_take_tail(blk):
     return img is not None and img[0] is not None
 
 
-def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None, tail_idt=None):
+def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None, tail_idt=None, tail_out=None):
     """bn: the BatchNorm that consumes this conv's output statistics; tail_idt: x / in_saved are the previous block's last
     conv output and BatchNorm, tail_idt its identity -- the input is their bottleneck tail, formed on load (then the sixth
     return value is that input, written by the convolution)"""
@@ -73,7 +73,7 @@ def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None, tail_idt=None):
     shift = _stat_shift(bn, train)
     if tail_idt is not None:
         y, part, yin = ops.conv2d_fwd(x, w, N, H, W, cin, cout, k, k, s, p, sc, sh, stats=train, shift=shift,
-                                      wimg=weight_planes(conv.weight), tail_idt=tail_idt)
+                                      wimg=weight_planes(conv.weight), tail_idt=tail_idt, tail_out=tail_out)
         return y, part, ops.conv_out(H, k, s, p), ops.conv_out(W, k, s, p), wexp, yin
     if g == 1:
         y, part = ops.conv2d_fwd(x, w, N, H, W, cin, cout, k, k, s, p, sc, sh, stats=train, shift=shift,
@@ -294,7 +294,7 @@ def _block_fwd(blk, y, N, Hc, Wc, train, given, tail=None, defer=False):
     if isinstance(blk, Bottleneck):
         r.kind = "bottleneck"
         if tail is not None:
-            r.c1, part, _, _, _, y = _conv_fwd(tail[0], blk.conv1, N, Hc, Wc, tail[1], want, blk.bn1, tail_idt=tail[2])
+            r.c1, part, _, _, _, y = _conv_fwd(tail[0], blk.conv1, N, Hc, Wc, tail[1], want, blk.bn1, tail_idt=tail[2], tail_out=tail[3])
             r.yin = y
         else:
             r.c1, part, _, _, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, want, blk.bn1)
@@ -319,7 +319,10 @@ def _block_fwd(blk, y, N, Hc, Wc, train, given, tail=None, defer=False):
         r.sd = fin(blk.downsample[1], part, rows_o, 3)
         r.y = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=r.cd, idsaved=r.sd)
     elif defer:
-        r.tail = (last_c, last_s, y)         # y = relu(bn(last_c) + identity) is formed (and written) by the next block's conv1
+        # y = relu(bn(last_c) + identity) is formed (and written) by the next block's conv1.  Its buffer is allocated HERE, where
+        # the element-wise pass would have allocated its output: the caching allocator then sees the same request order as
+        # without the fusion (allocating it at the next conv1 instead cost 17 GB of reserved memory on the headline step)
+        r.tail = (last_c, last_s, y, torch.empty_like(last_c))
     else:
         r.y = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=y)
     r.dims = (N, Hc, Wc, OH, OW)

@@ -75,8 +75,8 @@ def test_launcher_retries_once_with_the_lean_policy_after_an_oom(tmp_path, capfd
     args = bench.parse_args(["--gpus", "2"])
     rc = bench.launch_with_fallback(args, ["--gpus", "2"], program=str(stub))
     cap = capfd.readouterr()
-    assert rc == 0 and "one retry with 012,012,012" in cap.err
-    assert json.loads(cap.out.strip().splitlines()[-1])["argv"] == ["--gpus", "2", "--recompute", "012,012,012"]
+    assert rc == 0 and f"one retry with --recompute {bench.FALLBACK_POLICY}" in cap.err
+    assert json.loads(cap.out.strip().splitlines()[-1])["argv"] == ["--gpus", "2", "--recompute", bench.FALLBACK_POLICY]
     assert "KOAF_BENCH_OOM_RETRY" not in __import__("os").environ
     args = bench.parse_args(["--gpus", "2", "--recompute", "none"])            # an explicit policy is never overridden
     assert bench.launch_with_fallback(args, ["--gpus", "2"], program=str(stub)) == 1
