@@ -549,13 +549,15 @@ def main(args):
     f16_share = sum(fl for f, fl, ms, tag, nb, mpp in prof if mpp == 3) / gemm_flop if gemm_flop else 0.0
     # HBM-side bytes per launch of the dominant kernel cannot be counted from inside the process: they come from
     # the committed PMC summary of this same workload (profiles/README.md has the command and the corrections)
-    traffic, traffic_src = None, None
-    tj = ROOT / "profiles" / f"r02_gemm_traffic_{args.workload}.json"
-    if tj.exists():
+    traffic, traffic_src, traffic_step = None, None, None
+    for tj in sorted((ROOT / "profiles").glob(f"r*_gemm_traffic_{args.workload}.json"), reverse=True):      # the newest round's
         try:
             tjd = json.loads(tj.read_text())
             if tjd.get("batch") == B:
                 traffic, traffic_src = tjd["bytes_per_launch"], f"profiles/{tj.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                traffic_step = {k: tjd[k] for k in ("bytes_per_step", "act_planes_bytes_per_step", "algorithmic_bytes_per_step",
+                                                    "ratio_to_algorithmic", "ratio_to_algorithmic_with_act_planes") if k in tjd}
+                break
         except (ValueError, KeyError):
             pass
 
@@ -707,6 +709,7 @@ def main(args):
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak_mix, 1),
                          "unit": "TFLOP/s", "frac": round(achieved / peak_mix, 4), "traffic": traffic,
                          "traffic_unit": "bytes per koaf_gemm_kernel launch (average)", "traffic_source": traffic_src,
+                         "traffic_per_step": traffic_step,
                          "kernel": "koaf_gemm_kernel (implicit GEMM: conv fwd/dgrad/wgrad, linear, attention; fp32 in/out/accumulate; "
                                    "products on v_mfma_f32_32x32x16_f16 from two scaled fp16 pieces per operand (3 MFMAs per product: "
                                    "convolutions) or on v_mfma_f32_32x32x16_bf16 from three bf16 pieces (6 MFMAs: linear, attention, "

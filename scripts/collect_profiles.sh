@@ -7,11 +7,13 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
+if [ -z "$ONLY_PMC" ]; then      # (ONLY_PMC=1: just the two counter passes, into a directory that already holds the rest)
 python3 $GRAFT_REPO_ROOT/bench.py "$@" --breakdown $OUT/breakdown.txt > $OUT/bench.log 2> $OUT/bench.err || exit 1
 echo "bench done" > $OUT/progress
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -o s -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --serial --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/serial.log 2>&1 || exit 2
 find /tmp/prof_s -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 echo "trace done" >> $OUT/progress
+fi
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_f -o f -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --serial --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/pmc_fetch.log 2>&1 || exit 3
 find /tmp/prof_f -name "*counter_collection.csv" -exec cp {} $OUT/fetch_counter_collection.csv \;
 echo "fetch done" >> $OUT/progress
@@ -32,7 +34,8 @@ for tag, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     with open(f"{out}/{tag}_per_dispatch.csv", "w") as fh:
         fh.write("dispatch,kernel,value_kb\n")
         for k, v in per.items():
-            short = "koaf_gemm_kernel" if "koaf_gemm_kernel" in kn[k] else kn[k].split("(")[0][-60:]
+            name = kn[k].replace("void ", "").replace("(anonymous namespace)::", "")
+            short = "koaf_gemm_kernel" if "koaf_gemm_kernel" in name else name.split("(")[0].split("<")[0][-60:]
             fh.write(f"{k},{short},{v}\n")
 import os
 for tag in ("fetch", "write"):

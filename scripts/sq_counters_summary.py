@@ -1,5 +1,7 @@
 """Reduce the two rocprofv3 --pmc passes of scripts/collect_sq_counters.sh to per-kernel averages ->
-profiles/r02_gemm_sq_counters.json.  Usage: python scripts/sq_counters_summary.py gpurun_out/<dir>
+profiles/<round>_gemm_sq_counters[_short].json.  Usage: python scripts/sq_counters_summary.py gpurun_out/<dir> [round tag]
+(with a plan.json in the directory -- the `short` collection -- each kernel template's dispatches are split, in launch order,
+among the plan's entries that use it)
 Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves;
 SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
 import collections
@@ -10,7 +12,9 @@ import sys
 from pathlib import Path
 
 O = Path(sys.argv[1])
+RND = sys.argv[2] if len(sys.argv) > 2 else "r03"
 ROOT = Path(__file__).resolve().parent.parent
+PLAN = json.loads((O / "plan.json").read_text()) if (O / "plan.json").exists() else None
 LABEL = {
     "128, 128, 0, 0, 0, 0, true, false, 256": "dense forward 4096^3, bf16 x 3 (6 MFMAs per product)",
     "128, 128, 1, 6, 1, 0, true, true, 256": "conv 3x3 256->256 forward, fp16 x 2 (3 MFMAs), fp32 activation loader: BN prologue + split in the k-loop, weight tiles by LDS-DMA",
@@ -41,11 +45,30 @@ def load(tag):
 out = []
 pa, na, da = load("a")
 pb, nb, db = load("b")
-for key, label in LABEL.items():
-    A = [pa[d] for d in pa if na[d] == key][2:]          # (the first launches of a series warm the caches / clocks)
-    B = [pb[d] for d in pb if nb[d] == key][2:]
-    us = [da[d] for d in pa if na[d] == key][2:]
+
+
+def series(key, per, names, idx=None, count=None):
+    """counter dicts of the dispatches of template `key` (a prefix of the template argument list), in launch order; with a
+    plan: the idx-th run of `count` launches of that template"""
+    ds = sorted((d for d in per if names[d].startswith(key)), key=int)
+    if idx is not None:
+        ds = ds[idx * count:(idx + 1) * count]
+    return ds[2:]                                    # (the first launches of a series warm the caches / clocks)
+
+
+if PLAN is not None:
+    items, seen = [], collections.Counter()
+    for e in PLAN:
+        items.append((e["template"], e["label"], seen[e["template"]], e["launches"]))
+        seen[e["template"]] += 1
+else:
+    items = [(k, lab, None, None) for k, lab in LABEL.items()]
+for key, label, idx, count in items:
+    A = [pa[d] for d in series(key, pa, na, idx, count)]
+    B = [pb[d] for d in series(key, pb, nb, idx, count)]
+    us = [da[d] for d in series(key, pa, na, idx, count)]
     if not A or not B:
+        print("no dispatches for", key, label)
         continue
     avg = lambda L, c: sum(x[c] for x in L) / len(L)      # noqa: E731
     t_us = sum(us) / len(us)
@@ -61,11 +84,11 @@ for key, label in LABEL.items():
         "wait_any": round(avg(A, "SQ_WAIT_ANY") / wave, 3), "wait_inst_any": round(avg(A, "SQ_WAIT_INST_ANY") / wave, 3),
         "active_inst_any": round(avg(A, "SQ_ACTIVE_INST_ANY") / wave, 3),
     })
-doc = {"command": "bash scripts/collect_sq_counters.sh <dir> (two rocprofv3 --pmc passes, --kernel-trace --output-format csv, no other "
-                  "trace domain, over scripts/bench_gemm_pmc.py 20), reduced by scripts/sq_counters_summary.py",
-       "note": "averages over 18 launches per kernel on random operands; *_per_mfma are wave-instruction counts per matrix instruction; "
+doc = {"command": "bash scripts/collect_sq_counters.sh <dir> [short] (two rocprofv3 --pmc passes, --kernel-trace --output-format csv, no other "
+                  "trace domain, over scripts/bench_gemm_pmc.py 20 | scripts/bench_gemm_pmc_short.py 12), reduced by scripts/sq_counters_summary.py",
+       "note": "averages over the launches of each kernel but its first two, on random operands; *_per_mfma are wave-instruction counts per matrix instruction; "
                "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (duration x clock); wait_* / active_* are shares of SQ_WAVE_CYCLES",
        "kernels": out}
-json.dump(doc, open(ROOT / "profiles" / "r02_gemm_sq_counters.json", "w"), indent=1)
+json.dump(doc, open(ROOT / "profiles" / (f"{RND}_gemm_sq_counters_short.json" if PLAN is not None else f"{RND}_gemm_sq_counters.json"), "w"), indent=1)
 for k in out:
     print(k)
