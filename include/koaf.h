@@ -459,7 +459,8 @@ int koaf_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
                        const float* rstd, float* dx, float* dgamma, float* dbeta, float* part,
                        int32_t rows, int32_t D, void* stream);
 /* Attention core (_core_trf.py:170-180): qkv [B,n,3*h*d] with '(qkv h d)' split; scale applied to
- * QK^T; attn [B,h,n,n] emitted (it is returned by the reference, :182); out [B,n,h*d].  */
+ * QK^T; attn [B,h,n,n] emitted (it is returned by the reference, :182); out [B,n,h*d].  One launch
+ * for n <= 512 and d % 4 == 0 (scores kept in LDS); larger n: two batched GEMMs + koaf_softmax_rows. */
 int koaf_attention_fwd(const float* qkv, float* attn, float* out, int32_t B, int32_t n, int32_t h,
                        int32_t d, float scale, void* stream);
 /* dqkv (every element written) from dout; ws: workspace of B*h*n*n floats (dS).  */

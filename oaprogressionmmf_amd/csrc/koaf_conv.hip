@@ -799,9 +799,17 @@ extern "C" int koaf_linear_wgrad(const float* dy, const float* x, float* dw, flo
 // attention core: S = scale*Q K^T -> softmax -> P V, and its backward (all on koaf_gemm, batched
 // over (b, head) with strided operands straight out of the fused qkv buffer)
 // ================================================================================================
+int koaf_attention_fwd_fused(const float* qkv, float* attn, float* out, int32_t B, int32_t n, int32_t h, int32_t d, float scale,
+                             void* stream);       // koaf_gemm.hip: ONE launch for n <= 512
+
 extern "C" int koaf_attention_fwd(const float* qkv, float* attn, float* out, int32_t B, int32_t n, int32_t h,
                                   int32_t d, float scale, void* stream) {
     KOAF_REQUIRE(qkv && attn && out && B > 0 && n > 0 && h > 0 && d > 0, "koaf_attention_fwd: bad args");
+    {
+        static const bool off = [] { const char* e = getenv("KOAF_ATTN_FUSED"); return e && e[0] == '0'; }();    // (A/B switch)
+        const int rc = off ? 1 : koaf_attention_fwd_fused(qkv, attn, out, B, n, h, d, scale, stream);
+        if (rc <= 0) return rc;               // taken (or failed); 1 = shape outside the fused kernel: three launches below
+    }
     const int64_t ld = 3ll * h * d;
     KoafGemm g;
     zero_gemm(&g);

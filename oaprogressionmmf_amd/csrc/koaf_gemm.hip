@@ -2037,6 +2037,182 @@ extern "C" int koaf_slab_reduce_epilogue(const float* slabs, int32_t nslab, int3
 
 
 // ================================================================================================
+// fusion attention, forward, ONE launch (reference: koafusion/models/_core_trf.py:170-180): per (batch, head) and 32-query tile
+//   S = scale * Q K^T  (all n <= 512 keys; scores stay in LDS)  ->  softmax rows  ->  attn written ONCE  ->  O = P V
+// with the products formed like every other fp32 contraction here (three bf16 pieces per operand, six MFMAs, KoafGemm.fmt 0).
+// Replaces GEMM -> softmax kernel -> GEMM with two (B, h, n, n) round trips; the attention maps are still emitted (they are
+// returned by the reference, :182).  Block = 4 waves; wave w owns columns [32 w, 32 w + 32) of each 128-wide column chunk.
+// ================================================================================================
+namespace {
+constexpr int ATT_BM = 32, ATT_NMAX = 512, ATT_SP = ATT_NMAX + 4;
+
+__global__ void __launch_bounds__(512) attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ attn,
+                                                            float* __restrict__ out, int n, int h, int d, float scale) {
+    constexpr int A_PL = plane_dwords(ATT_BM, true), BK_PL = plane_dwords(128, true), BV_PL = plane_dwords(128, false);
+    constexpr int B_PL = BK_PL > BV_PL ? BK_PL : BV_PL;
+    __shared__ __attribute__((aligned(16))) float Ss[ATT_BM * ATT_SP];
+    __shared__ __attribute__((aligned(16))) float Aps[2][3 * A_PL];
+    __shared__ __attribute__((aligned(16))) float Bps[2][3 * B_PL];
+    // block = (256, 2): two groups of four waves, each with its own operand planes, take alternate column chunks -- the operand
+    // split (vector ALU) of one group runs under the MFMAs of the other (one group per CU left every SIMD with a single wave)
+    const int t = threadIdx.x, grp = threadIdx.y, lane = t & 63, w = t >> 6, r = lane & 31, hh = lane >> 5;
+    float* const Ap = Aps[grp];
+    float* const Bp = Bps[grp];
+    const int b = blockIdx.y / h, head = blockIdx.y - b * h;
+    const int m0 = blockIdx.x * ATT_BM;
+    const int64_t ld = 3ll * h * d;
+    const float* Q = qkv + (int64_t)b * n * ld + (int64_t)head * d;
+    const float* K = Q + (int64_t)h * d;
+    const float* V = Q + 2ll * h * d;
+    KoafOperand op{};
+    op.ld = ld;
+    constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};       // piece products, smallest first
+    auto mma = [&](v16f& acc, bool bkc) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            v4i ap[3], bp[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                ap[q] = frag_load<ATT_BM, true>((const unsigned*)Ap + q * A_PL, 0, g, lane);
+                bp[q] = bkc ? frag_load<128, true>((const unsigned*)Bp + q * BK_PL, 32 * w, g, lane)
+                            : frag_load<128, false>((const unsigned*)Bp + q * BV_PL, 32 * w, g, lane);
+            }
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[PA3[term]]),
+                                                              __builtin_bit_cast(bf16x8, bp[PB3[term]]), acc, 0, 0, 0);
+        }
+    };
+    // ---- S = scale * Q K^T, 128 keys at a time ----
+    const int nchunk = (n + 127) / 128;
+    for (int c = grp; c < ((nchunk + 1) & ~1); c += 2) {       // (both groups run the same number of barriers; a chunk past n is all zero rows)
+        TileLoader<ATT_BM, M_KC, 0, true, false> la;
+        TileLoader<128, M_KC, 0, true, false> lb;
+        la.init(op, m0, n, 0, 1.f);
+        lb.init(op, 128 * c, n, 0, 1.f);
+        la.seek(op, 0);
+        lb.seek(op, 0);
+        v16f acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        // two k-steps of loads in flight (slots sa / sb alternate): with one block of four waves per CU nothing else hides
+        // the load latency
+        la.issue(la.sa, op, Q, 0, d, 0);
+        lb.issue(lb.sa, op, K, 0, d, 0);
+        if (BK < d) {
+            la.issue(la.sb, op, Q, BK, d, 0);
+            lb.issue(lb.sb, op, K, BK, d, 0);
+        }
+        la.finish(la.sa);
+        la.template store<3>(la.sa, Ap);
+        lb.finish(lb.sa);
+        lb.template store<3>(lb.sa, Bp);
+        __syncthreads();
+        auto step = [&](int k0, auto& fa, auto& fb, auto& na, auto& nb) {     // f*: the slot this step's tile came from (free)
+            if (k0 + 2 * BK < d) {
+                la.issue(fa, op, Q, k0 + 2 * BK, d, 0);
+                lb.issue(fb, op, K, k0 + 2 * BK, d, 0);
+            }
+            mma(acc, true);
+            __syncthreads();
+            if (k0 + BK < d) {
+                la.finish(na);
+                la.template store<3>(na, Ap);
+                lb.finish(nb);
+                lb.template store<3>(nb, Bp);
+                __syncthreads();
+            }
+        };
+        for (int k0 = 0; k0 < d; k0 += 2 * BK) {
+            step(k0, la.sa, lb.sa, la.sb, lb.sb);
+            if (k0 + BK < d) step(k0 + BK, la.sb, lb.sb, la.sa, lb.sa);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e)      // (keys past n multiplied zero rows: their scores are 0 and the softmax skips them)
+            if (c < nchunk) Ss[((e & 3) + 8 * (e >> 2) + 4 * hh) * ATT_SP + 128 * c + 32 * w + r] = scale * acc[e];
+    }
+    __syncthreads();
+    // ---- softmax rows (the arithmetic of koaf_softmax_rows: one wave per row), attn written once ----
+    for (int row = w + 4 * grp; row < ATT_BM; row += 8) {
+        float* xr = Ss + row * ATT_SP;
+        float m = -INFINITY;
+        for (int i = lane; i < n; i += 64) m = fmaxf(m, xr[i]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int i = lane; i < n; i += 64) sum += expf(xr[i] - m);
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        const bool live = (m0 + row) < n;
+        float* ar = attn + (((int64_t)blockIdx.y * n) + m0 + row) * n;
+        for (int i = lane; i < n; i += 64) {
+            const float pv = expf(xr[i] - m) * inv;
+            xr[i] = pv;
+            if (live) ar[i] = pv;
+        }
+    }
+    __syncthreads();
+    // ---- O = P V, 128 head-dimension columns at a time; the A tile comes from the scores in LDS ----
+    for (int j = grp; j < (((d + 127) / 128 + 1) & ~1); j += 2) {
+        TileLoader<128, M_KM, 0, true, false> lv;
+        lv.init(op, 128 * j, d, 0, 1.f);
+        lv.seek(op, 0);
+        v16f acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        auto stage_p = [&](int k0) {          // P[32 rows][k0 .. k0 + 32) -> the three bf16 planes (TileLoader's K-contiguous image)
+            const int row = t >> 3, kk = k0 + 4 * (t & 7);
+            v4f x = *(const v4f*)&Ss[row * ATT_SP + kk];          // (columns past n hold zeros)
+            unsigned pl[3][2];
+            split3v(x, pl);
+            unsigned* S = (unsigned*)Ap;
+            const int off = row * 20 + 2 * (t & 7);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *(uint2*)&S[q * A_PL + off] = make_uint2(pl[q][0], pl[q][1]);
+        };
+        lv.issue(lv.sa, op, V, 0, n, 0);
+        if (BK < n) lv.issue(lv.sb, op, V, BK, n, 0);
+        stage_p(0);
+        lv.finish(lv.sa);
+        lv.template store<3>(lv.sa, Bp);
+        __syncthreads();
+        auto step = [&](int k0, auto& fv, auto& nv) {
+            if (k0 + 2 * BK < n) lv.issue(fv, op, V, k0 + 2 * BK, n, 0);
+            mma(acc, false);
+            __syncthreads();
+            if (k0 + BK < n) {
+                stage_p(k0 + BK);
+                lv.finish(nv);
+                lv.template store<3>(nv, Bp);
+                __syncthreads();
+            }
+        };
+        for (int k0 = 0; k0 < n; k0 += 2 * BK) {
+            step(k0, lv.sa, lv.sb);
+            if (k0 + BK < n) step(k0 + BK, lv.sb, lv.sa);
+        }
+        const int col = 128 * j + 32 * w + r;
+        if (col < d) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (row < n) out[((int64_t)b * n + row) * ((int64_t)h * d) + (int64_t)head * d + col] = acc[e];
+            }
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+// returns KOAF_OK when the fused kernel took the call, 1 when the shape is outside it (the caller runs the three-launch path)
+int koaf_attention_fwd_fused(const float* qkv, float* attn, float* out, int32_t B, int32_t n, int32_t h, int32_t d, float scale,
+                             void* stream) {
+    if (n > ATT_NMAX || (d & 3) || !aligned16(qkv) || (int64_t)B * h > 65535) return 1;
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3((unsigned)((n + ATT_BM - 1) / ATT_BM), (unsigned)(B * h)), dim3(256, 2), 0,
+                       (hipStream_t)stream, qkv, attn, out, n, h, d, scale);
+    return koaf_check_launch("koaf_attention_fwd");
+}
+
+// ================================================================================================
 // weight plane images (the M_PS operand): cut once per optimizer step for every convolution weight of the model
 // ================================================================================================
 namespace {

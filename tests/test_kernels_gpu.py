@@ -287,7 +287,9 @@ def test_layernorm(dev, rows, D):
     assert rel_err(dg, g.grad) < 1e-5 and rel_err(db, b.grad) < 1e-5
 
 
-@pytest.mark.parametrize("B,n,h,d", [(2, 92, 8, 256), (2, 25, 8, 256), (3, 64, 8, 256), (1, 161, 4, 16)])
+@pytest.mark.parametrize("B,n,h,d", [(2, 92, 8, 256), (2, 25, 8, 256), (3, 64, 8, 256), (1, 161, 4, 16),
+                                     (2, 483, 8, 256), (1, 512, 2, 64), (1, 31, 3, 36),          # one launch (n <= 512)
+                                     (1, 520, 2, 32)])                                           # past it: three launches
 def test_attention(dev, B, n, h, d):
     from oaprogressionmmf_amd import ops
     dim = h * d
