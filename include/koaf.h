@@ -74,7 +74,8 @@ typedef struct KoafOperand {
                          BatchNorm-backward apply formed on load, see koaf_bn_bwd_finalize; 3 (A operand, dense K-contiguous,
                          fmt 1 with a pre-split B) y = relu(sc[c]*x + sh[c] + x2): the BOTTLENECK TAIL relu(bn3(c3) + identity)
                          (_torchvision.py:132-136) formed in the loader of the next block's conv1 -- koaf_bn_add_relu's
-                         arithmetic bit for bit -- with y written once to `side` by the blocks of the first column tile */
+                         arithmetic bit for bit -- with y written once to `side` by the blocks of the first column tile; with
+                         sc2 / sh2 the identity is sc2[c]*x2 + sh2[c] (a downsample branch's raw conv output and BatchNorm) */
     int32_t tf_bs;    /* channel offset of sc/sh per batch index z1 (grouped-conv slabs) */
     const float* sc;
     const float* sh;
@@ -105,6 +106,7 @@ typedef struct KoafOperand {
        (B: column = tap*C + c, k = output pixel -> source pixel by H/W/PH/PW/KH/KW/stride/pad; C % 8 == 0).  Rows % 8 == 0. */
     const uint16_t* zeros;
     float* side;        /* tf 3: where the loader stores y (same layout as ptr; nullable: y is then not kept) */
+    const float* sh2;   /* tf 3 with sc2 != NULL: the identity is sc2[c]*x2 + sh2[c] (the BatchNorm of a downsample branch) */
 } KoafOperand;
 
 typedef struct KoafGemm {
@@ -259,10 +261,13 @@ typedef struct KoafBnApply {
  * last convolution, in_sc / in_sh its BatchNorm's coefficients, tail->idt that block's identity: the convolution's input
  * y = relu(in_sc*x + in_sh + idt) -- the bottleneck tail, _torchvision.py:132-136 -- is formed on load (KoafOperand.tf 3) and
  * written once to tail->y_out [N,H,W,Cin] (nullable), so the element-wise tail pass (koaf_bn_add_relu: 12 B per element) and
- * this convolution's own read of y (4 B) become one read of c3 + idt and one write of y. */
+ * this convolution's own read of y (4 B) become one read of c3 + idt and one write of y.  idt_sc / idt_sh (nullable pair): the
+ * block had a downsample branch -- idt is that branch's raw convolution output and these its BatchNorm coefficients. */
 typedef struct KoafTail {
     const float* idt;
     float* y_out;
+    const float* idt_sc;   /* nullable pair: the identity is idt_sc[c]*idt + idt_sh[c] -- the raw output of a downsample */
+    const float* idt_sh;   /* convolution and its BatchNorm coefficients (koaf_bn_add_relu's idsc / idsh)             */
 } KoafTail;
 int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W,
                     int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,

@@ -49,6 +49,7 @@ class KoafOperand(ctypes.Structure):
         ("sc2", ctypes.c_void_p),
         ("zeros", ctypes.c_void_p),
         ("side", ctypes.c_void_p),
+        ("sh2", ctypes.c_void_p),
     ]
 
 
@@ -145,7 +146,7 @@ class KoafWImg(ctypes.Structure):
 
 
 class KoafTail(ctypes.Structure):
-    _fields_ = [("idt", ctypes.c_void_p), ("y_out", ctypes.c_void_p)]
+    _fields_ = [("idt", ctypes.c_void_p), ("y_out", ctypes.c_void_p), ("idt_sc", ctypes.c_void_p), ("idt_sh", ctypes.c_void_p)]
 
 
 class KoafBnApply(ctypes.Structure):

@@ -255,7 +255,7 @@ extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t
     KOAF_REQUIRE((x || x_planes) && w && y && N > 0 && Cin % 32 == 0 && Cout % 4 == 0, "koaf_conv2d_fwd: bad args (Cin=%d Cout=%d)",
                  Cin, Cout);
     KOAF_REQUIRE(!tail || (tail->idt && x && in_sc && in_sh && !x_planes && KH == 1 && KW == 1 && stride == 1 && pad == 0 && wimg &&
-                           wimg->amax && wimg->f),
+                           wimg->amax && wimg->f && (tail->idt_sc == nullptr) == (tail->idt_sh == nullptr)),
                  "koaf_conv2d_fwd: the fused bottleneck tail serves 1x1 / stride-1 convolutions with weight plane images, from x / in_sc / in_sh");
     KOAF_REQUIRE((in_sc == nullptr) == (in_sh == nullptr), "koaf_conv2d_fwd: in_sc/in_sh come together");
     const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
@@ -275,7 +275,7 @@ extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t
         g.A.KH = KH; g.A.KW = KW; g.A.stride = stride; g.A.pad = pad; g.A.pad_w = pad;
     }
     if (in_sc) { g.A.tf = 1; g.A.sc = in_sc; g.A.sh = in_sh; }
-    if (tail) { g.A.tf = 3; g.A.ptr2 = tail->idt; g.A.side = tail->y_out; }
+    if (tail) { g.A.tf = 3; g.A.ptr2 = tail->idt; g.A.side = tail->y_out; g.A.sc2 = tail->idt_sc; g.A.sh2 = tail->idt_sc ? tail->idt_sh : nullptr; }
     g.B.ptr = w;
     g.B.kind = 0;
     g.B.ld = (int64_t)KH * KW * Cin;

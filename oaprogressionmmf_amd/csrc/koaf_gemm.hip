@@ -178,8 +178,10 @@ struct TileLoader {
         v4f r2[NU2];   // TF 2: the second source
         unsigned vm;   // validity bits: VEC 1 bit / unit, else 4 bits / unit
         v4f ts4, th4, tk4;  // transform coefficients of the tile (KC operands: they depend on k)
+        v4f tq4;            // TF 3 with the identity's own affine (a downsample branch): its shift (tk4 = its scale)
     };
     Slot sa, sb;
+    bool tail2 = false;      // TF 3: the identity is sc2[c] * x2 + sh2[c] (KoafOperand.sc2 / sh2 given)
     v4f kts4, kth4, ktk4;    // transform coefficients of this thread's columns (KM operands: fixed)
     float fsc;               // F16: operand scale (a power of two)
     unsigned satmax;         // F16, TF 1: packed maximum of the fp16 hi pieces stored so far (0x7bff = clamped at 65504)
@@ -209,7 +211,8 @@ struct TileLoader {
         fsc = scale;
         satmax = 0u;
         sa.vm = sb.vm = 0;
-        sa.ts4 = sa.th4 = sb.ts4 = sb.th4 = kts4 = kth4 = sa.tk4 = sb.tk4 = ktk4 = (v4f){0.f, 0.f, 0.f, 0.f};
+        sa.ts4 = sa.th4 = sb.ts4 = sb.th4 = kts4 = kth4 = sa.tk4 = sb.tk4 = ktk4 = sa.tq4 = sb.tq4 = (v4f){0.f, 0.f, 0.f, 0.f};
+        if constexpr (TF == 3) tail2 = op.sc2 != nullptr;
         rvm = cvm = 0;
         base = (v4l){0, 0, 0, 0};
         iy0 = ix0 = toff = (v4i){0, 0, 0, 0};
@@ -376,6 +379,9 @@ struct TileLoader {
                     s.ts4 = *(const v4f*)(sc + c);
                     s.th4 = *(const v4f*)(sh + c);
                     if constexpr (TF == 2) s.tk4 = *(const v4f*)(op.sc2 + z1 * op.tf_bs + c);
+                    if constexpr (TF == 3) {
+                        if (tail2) { s.tk4 = *(const v4f*)(op.sc2 + c); s.tq4 = *(const v4f*)(op.sh2 + c); }
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -470,7 +476,7 @@ struct TileLoader {
     // block owns the column range (side != nullptr: the first column tile), at element offset base[i] + k0s.
     float* side = nullptr;
     int k0s = 0;
-    __device__ __forceinline__ void finish_unit(Slot& s, int i, v4f a, v4f b, v4f k) {
+    __device__ __forceinline__ void finish_unit(Slot& s, int i, v4f a, v4f b, v4f k, v4f q = (v4f){0.f, 0.f, 0.f, 0.f}) {
         constexpr float HMAX = 65504.f;
         if constexpr (S16) s.r[i] = widen_bf16x4(__float_as_uint(s.r[i][0]), __float_as_uint(s.r[i][1]));
         if constexpr (S2_16 && (TF == 2 || TF == 3)) s.r2[i < NU2 ? i : 0] = widen_bf16x4(__float_as_uint(s.r2[i < NU2 ? i : 0][0]), __float_as_uint(s.r2[i < NU2 ? i : 0][1]));
@@ -485,7 +491,9 @@ struct TileLoader {
                 x = fmaf(a[j], x, fmaf(-k[j], s.r2[i < NU2 ? i : 0][j], b[j]));
                 if constexpr (F16) x = __builtin_amdgcn_fmed3f(x, -HMAX, HMAX);
             } else if constexpr (TF == 3) {
-                x = fmaxf(fmaf(x, a[j], b[j]) + s.r2[i < NU2 ? i : 0][j], 0.f);      // (a, b unscaled here: y is stored as it is)
+                float idv = s.r2[i < NU2 ? i : 0][j];
+                if (tail2) idv = fmaf(idv, k[j], q[j]);                  // (a downsample branch: its BatchNorm, as koaf_bn_add_relu's idsc / idsh)
+                x = fmaxf(fmaf(x, a[j], b[j]) + idv, 0.f);      // (a, b unscaled here: y is stored as it is)
                 if constexpr (S16) x = widen_bf16x4(round_bf16x4((v4f){x, 0.f, 0.f, 0.f}).x, 0u)[0];   // bf16 storage: everyone reads the ROUNDED y
                 s.r2[i < NU2 ? i : 0][j] = x;
                 x = fminf(x * fsc, HMAX);
@@ -505,7 +513,7 @@ struct TileLoader {
         v4f a = KC ? s.ts4 : kts4, b = KC ? s.th4 : kth4, k = KC ? s.tk4 : ktk4;
         if constexpr (F16 && KC && TF != 0 && TF != 3) { a *= fsc; b *= fsc; k *= fsc; }     // (KM coefficients were scaled once in init)
 #pragma unroll
-        for (int i = 0; i < NU; ++i) finish_unit(s, i, a, b, k);
+        for (int i = 0; i < NU; ++i) finish_unit(s, i, a, b, k, s.tq4);
     }
     // LDS dword offset (within a plane) of unit i of this thread
     __device__ __forceinline__ int plane_off(int i) const {
@@ -1970,7 +1978,8 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     KOAF_REQUIRE(g.fmt == 0 || g.fmt == 1, "koaf_gemm: fmt must be 0 (bf16 x 3) or 1 (fp16 x 2)");
     KOAF_REQUIRE(g.A.tf >= 0 && g.A.tf <= 3 && g.B.tf >= 0 && g.B.tf <= 1, "koaf_gemm: tf is 0 | 1 (A, B) | 2 | 3 (A)");
     KOAF_REQUIRE(g.A.tf != 3 || (g.A.kind == 0 && g.A.gather == 0 && g.A.ptr2 && g.A.sc && g.A.sh && g.fmt == 1 && g.B.kind == 2 &&
-                                 g.nb0 * g.nb1 == 1 && g.splitk == 1 && aligned16(g.A.ptr2) && (!g.A.side || aligned16(g.A.side))),
+                                 g.nb0 * g.nb1 == 1 && g.splitk == 1 && aligned16(g.A.ptr2) && (!g.A.side || aligned16(g.A.side)) &&
+                                 (!g.A.sc2 || (g.A.sh2 && aligned16(g.A.sc2) && aligned16(g.A.sh2)))),
                  "koaf_gemm: the bottleneck-tail prologue (tf 3) needs a dense K-contiguous A, ptr2 / sc / sh, the fp16 scheme with a pre-split B");
     KOAF_REQUIRE(g.A.tf != 2 || (g.A.ptr2 && g.A.sc && g.A.sh && g.A.sc2 && g.fmt == 1),
                  "koaf_gemm: the two-source prologue needs ptr2 / sc / sh / sc2 and the fp16 scheme");

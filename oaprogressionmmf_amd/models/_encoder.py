@@ -43,10 +43,11 @@ def _stat_shift(bn, train):
     return bn.running_mean if (train and bn is not None and bn.running_mean is not None) else None
 
 
-# The bottleneck tail y = relu(bn3(c3) + identity) of a block whose identity is a plain tensor is not run as an element-wise
-# pass: the NEXT block's conv1 forms it while it loads its operand and writes y once (ops.conv2d_fwd tail_idt; koaf.h
+# The bottleneck tail y = relu(bn3(c3) + identity) of a block (identity = the block input, or BatchNorm(downsample conv)) is not
+# run as an element-wise pass: the NEXT block's conv1 forms it while it loads its operand and writes y once (ops.conv2d_fwd tail_idt; koaf.h
 # KoafOperand.tf 3) -- 12 B per element of c3 / identity / y traffic instead of 12 + 4.  KOAF_FUSE_TAIL=0 keeps the pass.
 FUSE_TAIL = os.environ.get("KOAF_FUSE_TAIL", "1") != "0"
+FUSE_TAIL_DS = os.environ.get("KOAF_FUSE_TAIL_DS", "1") != "0"      # ... also behind blocks with a downsample branch
 
 
 def _can_take_tail(blk):
@@ -61,7 +62,7 @@ def _can_take_tail(blk):
     return img is not None and img[0] is not None
 
 
-def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None, tail_idt=None, tail_out=None):
+def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None, tail_idt=None, tail_out=None, tail_idsaved=None):
     """bn: the BatchNorm that consumes this conv's output statistics; tail_idt: x / in_saved are the previous block's last
     conv output and BatchNorm, tail_idt its identity -- the input is their bottleneck tail, formed on load (then the sixth
     return value is that input, written by the convolution)"""
@@ -73,7 +74,8 @@ def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None, tail_idt=None, tail_ou
     shift = _stat_shift(bn, train)
     if tail_idt is not None:
         y, part, yin = ops.conv2d_fwd(x, w, N, H, W, cin, cout, k, k, s, p, sc, sh, stats=train, shift=shift,
-                                      wimg=weight_planes(conv.weight), tail_idt=tail_idt, tail_out=tail_out)
+                                      wimg=weight_planes(conv.weight), tail_idt=tail_idt, tail_out=tail_out,
+                                      tail_idsaved=tail_idsaved)
         return y, part, ops.conv_out(H, k, s, p), ops.conv_out(W, k, s, p), wexp, yin
     if g == 1:
         y, part = ops.conv2d_fwd(x, w, N, H, W, cin, cout, k, k, s, p, sc, sh, stats=train, shift=shift,
@@ -282,9 +284,9 @@ def _block_fwd(blk, y, N, Hc, Wc, train, given, tail=None, defer=False):
     """Forward of one residual block.  given = None: statistics are collected by the conv epilogues and
     finalised (normal forward).  given = (s1, s2, s3, sd): activation RECOMPUTE in backward -- the saved
     BatchNorm statistics are reused, nothing is reduced and no running statistic is touched.
-    tail = (c_last, s_last, identity) of the PREVIOUS block whose tail was deferred (y is None then): this block's conv1 forms
+    tail = (c_last, s_last, identity, y buffer, identity's BatchNorm record or None) of the PREVIOUS block whose tail was deferred (y is None then): this block's conv1 forms
     its own input on load and writes it (r.yin).  defer: leave THIS block's tail to the next block (r.y stays None, r.tail
-    holds what the next call needs) -- only for a plain identity; the caller checks _can_take_tail(next block)."""
+    holds what the next call needs); the caller checks _can_take_tail(next block)."""
     r = _Rec()
     r.blk, r.yin = blk, y
     want = train and given is None
@@ -294,7 +296,8 @@ def _block_fwd(blk, y, N, Hc, Wc, train, given, tail=None, defer=False):
     if isinstance(blk, Bottleneck):
         r.kind = "bottleneck"
         if tail is not None:
-            r.c1, part, _, _, _, y = _conv_fwd(tail[0], blk.conv1, N, Hc, Wc, tail[1], want, blk.bn1, tail_idt=tail[2], tail_out=tail[3])
+            r.c1, part, _, _, _, y = _conv_fwd(tail[0], blk.conv1, N, Hc, Wc, tail[1], want, blk.bn1, tail_idt=tail[2], tail_out=tail[3],
+                                               tail_idsaved=tail[4])
             r.yin = y
         else:
             r.c1, part, _, _, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, want, blk.bn1)
@@ -317,12 +320,15 @@ def _block_fwd(blk, y, N, Hc, Wc, train, given, tail=None, defer=False):
     if blk.downsample is not None:
         r.cd, part, _, _, _ = _conv_fwd(y, blk.downsample[0], N, Hc, Wc, None, want, blk.downsample[1])
         r.sd = fin(blk.downsample[1], part, rows_o, 3)
-        r.y = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=r.cd, idsaved=r.sd)
+        if defer and FUSE_TAIL_DS:
+            r.tail = (last_c, last_s, r.cd, torch.empty_like(last_c), r.sd)     # (identity = bn_d(cd), formed on load as well)
+        else:
+            r.y = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=r.cd, idsaved=r.sd)
     elif defer:
         # y = relu(bn(last_c) + identity) is formed (and written) by the next block's conv1.  Its buffer is allocated HERE, where
         # the element-wise pass would have allocated its output: the caching allocator then sees the same request order as
         # without the fusion (allocating it at the next conv1 instead cost 17 GB of reserved memory on the headline step)
-        r.tail = (last_c, last_s, y, torch.empty_like(last_c))
+        r.tail = (last_c, last_s, y, torch.empty_like(last_c), None)
     else:
         r.y = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=y)
     r.dims = (N, Hc, Wc, OH, OW)

@@ -192,14 +192,15 @@ def use_aplanes(wimg, KH, KW, C):
 
 
 def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, stats=False, shift=None, wimg=None,
-               aplanes=None, tail_idt=None, tail_out=None):
+               aplanes=None, tail_idt=None, tail_out=None, tail_idsaved=None):
     """x [N,H,W,Cin] (any view with that memory), w packed [Cout,KH,KW,Cin] -> y [N,OH,OW,Cout],
     (part, rows) per-tile column statistics if stats, summed about `shift` [Cout] (hand the same tensor to bn_finalize).
     wimg = (F, D, amax) plane images of w (arena.weight_planes) or None: with them the contraction runs on the fp16
     scheme (KoafGemm.fmt 1: half the matrix instructions, same accuracy), the weight tiles DMA'd from F.
     tail_idt (1x1 / stride 1 with wimg): x is the PREVIOUS block's raw last conv output c3, in_sc / in_sh its BatchNorm
     coefficients and tail_idt that block's identity: the input y = relu(in_sc*x + in_sh + tail_idt) (the bottleneck tail) is
-    formed on load and written to tail_out (allocated here when None); returns (y, part, tail_out)."""
+    formed on load and written to tail_out (allocated here when None); returns (y, part, tail_out).  tail_idsaved: the block had a
+    downsample branch -- tail_idt is that branch's raw conv output and tail_idsaved its BatchNorm record (mean, invstd, sc, sh)."""
     L = lib()
     OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
     if tail_idt is not None and tail_out is None:
@@ -217,7 +218,9 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     xpl = None
     tail = None
     if tail_idt is not None:
-        tail = ctypes.byref(KoafTail(idt=_ptr(tail_idt), y_out=_ptr(tail_out)))
+        tail = ctypes.byref(KoafTail(idt=_ptr(tail_idt), y_out=_ptr(tail_out),
+                                     idt_sc=_ptr(tail_idsaved[2]) if tail_idsaved is not None else None,
+                                     idt_sh=_ptr(tail_idsaved[3]) if tail_idsaved is not None else None))
         aplanes = False
     if torch.is_tensor(aplanes):
         xpl = aplanes                   # images cut by the caller (act_planes with this call's transform and ACT_SCALE)

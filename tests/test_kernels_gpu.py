@@ -748,30 +748,36 @@ def test_numerics_status_words_saturation_and_nonfinite(dev):
     assert torch.equal(y2, y_ok) and ops.numerics_status() == {"saturated": 0, "nonfinite": 0}
 
 
+@pytest.mark.parametrize("ds", [False, True])
 @pytest.mark.parametrize("C,Cout,bf16", [(256, 64, False), (1024, 256, False), (512, 512, False), (256, 64, True), (1024, 256, True)])
-def test_bottleneck_tail_formed_in_the_conv1_loader(dev, C, Cout, bf16):
+def test_bottleneck_tail_formed_in_the_conv1_loader(dev, C, Cout, bf16, ds):
     """y = relu(bn3(c3) + identity) (_torchvision.py:132-136) formed by the NEXT block's conv1 while it loads its operand
     (koaf.h KoafOperand.tf 3) and written once by the first column tile: the side-stored y and the convolution's output and
     statistics equal, bit for bit, the element-wise tail pass followed by the plain convolution -- also with several column
-    tiles (Cout 256 / 512), ragged row tiles and, in the bf16 storage mode, with y rounded before it is multiplied"""
+    tiles (Cout 256 / 512), ragged row tiles and, in the bf16 storage mode, with y rounded before it is multiplied.
+    ds: the block had a downsample branch -- the identity is BatchNorm(raw downsample conv output) (_torchvision.py:129-130),
+    formed on load as well"""
     from oaprogressionmmf_amd import ops
     N, H, W = 3, 21, 19
     rows = N * H * W
-    c3, idt = rnd(N, H, W, C).to(dev), torch.relu(rnd(N, H, W, C)).to(dev)
+    c3, idt = rnd(N, H, W, C).to(dev), (rnd(N, H, W, C) if ds else torch.relu(rnd(N, H, W, C))).to(dev)
     if bf16:
         c3, idt = c3.bfloat16(), idt.bfloat16()
     saved = torch.stack([0.1 * rnd(C), 1.0 + 0.1 * rnd(C), 1.0 + 0.1 * rnd(C), 0.1 * rnd(C)]).to(dev)
+    idsaved = torch.stack([0.1 * rnd(C), 1.0 + 0.1 * rnd(C), 1.0 + 0.3 * rnd(C), 0.2 * rnd(C)]).to(dev) if ds else None
     w = rnd(Cout, 1, 1, C, scale=C ** -0.5).to(dev)
     img = ops.build_weight_planes(w, Cout, 1, C)
-    y_ref = ops.bn_add_relu(c3, saved, rows, C, idt=idt)
+    y_ref = ops.bn_add_relu(c3, saved, rows, C, idt=idt, idsaved=idsaved)
     o_ref, p_ref = ops.conv2d_fwd(y_ref, w, N, H, W, C, Cout, 1, 1, 1, 0, None, None, stats=True, wimg=img)
     ops.numerics_status(reset=True)
-    o, p, y = ops.conv2d_fwd(c3, w, N, H, W, C, Cout, 1, 1, 1, 0, saved[2], saved[3], stats=True, wimg=img, tail_idt=idt)
+    o, p, y = ops.conv2d_fwd(c3, w, N, H, W, C, Cout, 1, 1, 1, 0, saved[2], saved[3], stats=True, wimg=img, tail_idt=idt,
+                             tail_idsaved=idsaved)
     assert y.dtype == y_ref.dtype and torch.equal(y, y_ref)
     assert torch.equal(o, o_ref) and torch.equal(p, p_ref)
     assert ops.numerics_status() == {"saturated": 0, "nonfinite": 0}
     # against float64: the usual forward bar
-    yd = torch.relu(c3.double() * saved[2].double() + saved[3].double() + idt.double())
+    idd = idt.double() * idsaved[2].double() + idsaved[3].double() if ds else idt.double()
+    yd = torch.relu(c3.double() * saved[2].double() + saved[3].double() + idd)
     if bf16:
         yd = yd.float().bfloat16().double()
     od = (yd.reshape(rows, C) @ w.reshape(Cout, C).double().t()).reshape(N, H, W, Cout)
@@ -779,7 +785,7 @@ def test_bottleneck_tail_formed_in_the_conv1_loader(dev, C, Cout, bf16):
     # the saturation watch covers the fused loader too
     big = saved.clone()
     big[2] = 5000.0
-    ops.conv2d_fwd(c3, w, N, H, W, C, Cout, 1, 1, 1, 0, big[2], big[3], wimg=img, tail_idt=idt)
+    ops.conv2d_fwd(c3, w, N, H, W, C, Cout, 1, 1, 1, 0, big[2], big[3], wimg=img, tail_idt=idt, tail_idsaved=idsaved)
     assert ops.numerics_status(reset=True)["saturated"] > 0
 
 
