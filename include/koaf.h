@@ -342,8 +342,10 @@ int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp, int32_t N
 int koaf_stem_fwd(const float* x, const float* w1t, float* y, int32_t N, int32_t H, int32_t W,
                   int32_t act16, void* stream);
 int64_t koaf_stem_wgrad_ws(int32_t N, int32_t H, int32_t W);
+/* dy_apply (nullable; dy may then be NULL): dy is formed on load from (dz, c, coef) as coef0*dz + coef3 - coef2*c -- the
+ * BatchNorm-backward apply of the stem's BatchNorm (koaf_bn_bwd_finalize with mean) -- and never written; act16: c is bf16 */
 int koaf_stem_wgrad(const float* dy, const float* x, float* dw1t, int32_t N, int32_t H, int32_t W,
-                    float* slabs, void* stream);
+                    float* slabs, const KoafBnApply* dy_apply, int32_t act16, void* stream);
 /* w [64,7,7,3] packed -> w1t [49][64] (sum over the 3 channels); gradient un-fold (copy x3) */
 int koaf_stem_fold_w(const float* w, float* w1t, void* stream);
 int koaf_stem_unfold_dw(const float* dw1t, float* dw, void* stream);
@@ -385,6 +387,14 @@ int koaf_bn_bwd_reduce(const float* g, const float* c, const float* ymask, const
                        const float* sh, const float* mean, const float* invstd, int32_t mask_mode,
                        float* dz_out, float* part, int32_t* part_rows, int64_t rows, int32_t C,
                        float* dz_amax, int32_t act16, void* stream);
+/* the same reduction for a BatchNorm(+ReLU) that is followed by the 3x3 / stride-2 / pad-1 max-pool (the stem,
+ * _torchvision.py:172-174): the upstream gradient is gathered from the POOL's gradient pool_g [N,OH,OW,C] and the window
+ * positions pool_argmax of koaf_maxpool_fwd (the arithmetic of koaf_maxpool_bwd), masked by sc*c+sh > 0 and written to dz_out
+ * [N,H,W,C] -- the pool's input gradient is never written and read back */
+int koaf_bn_bwd_reduce_pool(const float* pool_g, const uint8_t* pool_argmax, const float* c, const float* sc,
+                            const float* sh, const float* mean, const float* invstd, float* dz_out, float* part,
+                            int32_t* part_rows, int32_t N, int32_t H, int32_t W, int32_t C, float* dz_amax,
+                            int32_t act16, void* stream);
 /* part [rows][nsum][C] -> dgamma (= sum index i1), dbeta (= sum index 0), and apply coefficients
  * coef [3][C] = {sc, dbeta/M, sc*invstd*dgamma/M}.  (nsum, i1) = (2, 1) for the plain layout.
  * With mean: coef is [4][C], the fourth row = coef2*mean - coef0*coef1, so that dc = coef0*dz + coef3 - coef2*c -- the form

@@ -137,9 +137,12 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
     }
 }
 
+// APPLY: dy is formed on load from (dz = dy, c, coef [4][64]) as coef0*dz + coef3 - coef2*c -- the BatchNorm-backward apply
+// (KoafBnApply, the arithmetic of the GEMM loaders' tf 2) -- so the stem's dc is never written; C16: c is stored as bf16
+template <bool APPLY, bool C16>
 __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          float* __restrict__ slabs, int N, int H, int W, int OH,
-                                                         int OW) {
+                                                         int OW, const float* __restrict__ cc, const float* __restrict__ coef) {
     __shared__ __attribute__((aligned(16))) float patch[ST_PH][ST_PW];
     __shared__ float red[3][64][49 + 1];
     const int co = threadIdx.x & 63, pg = threadIdx.x >> 6;
@@ -148,6 +151,18 @@ __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict
     float acc[49];
 #pragma unroll
     for (int k = 0; k < 49; ++k) acc[k] = 0.f;
+    float k0 = 1.f, k2 = 0.f, k3 = 0.f;
+    if constexpr (APPLY) { k0 = coef[co]; k2 = coef[128 + co]; k3 = coef[192 + co]; }
+    auto grad = [&](int64_t o) {
+        float gv = dy[o];
+        if constexpr (APPLY) {
+            float cv;
+            if constexpr (C16) cv = __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(cc)[o] << 16);
+            else cv = cc[o];
+            gv = fmaf(k0, gv, fmaf(-k2, cv, k3));
+        }
+        return gv;
+    };
     for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         int b = tile;
         const int bx = b % tx; b /= tx;
@@ -163,8 +178,8 @@ __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict
             const int ox = ox0 + 2 * q;
             float g0 = 0.f, g1 = 0.f;
             if (oy < OH) {
-                if (ox < OW) g0 = dy[(((int64_t)n * OH + oy) * OW + ox) * 64 + co];
-                if (ox + 1 < OW) g1 = dy[(((int64_t)n * OH + oy) * OW + ox + 1) * 64 + co];
+                if (ox < OW) g0 = grad((((int64_t)n * OH + oy) * OW + ox) * 64 + co);
+                if (ox + 1 < OW) g1 = grad((((int64_t)n * OH + oy) * OW + ox + 1) * 64 + co);
             }
 #pragma unroll
             for (int kh = 0; kh < 7; ++kh) {
@@ -445,11 +460,25 @@ extern "C" int koaf_conv2d_dgrad(const float* dy, const float* w, float* dx, int
                                  nullptr, wimg, dy_amax, dy_apply, dy_planes, act16, stream);
 }
 
+// koaf_wgrad3.hip: 3x3 / stride 1 / pad 1 over plane images, both tensors walked once in padded raster order
+bool koaf_wgrad3_ring_ok(int N, int H, int W, int Cin, int Cout);
+int64_t koaf_wgrad3_ring_ws(int N, int H, int W, int Cin, int Cout);
+int koaf_wgrad3_ring(const uint16_t* dy_planes, const uint16_t* x_planes, float* dw, float* slabs, const float* dy_amax,
+                     float x_scale, int N, int H, int W, int Cin, int Cout, void* stream);
+static inline bool wgrad3_ring_shape(int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    return KH == 3 && KW == 3 && stride == 1 && pad == 1 && koaf_wgrad3_ring_ok(N, H, W, Cin, Cout);
+}
+
 extern "C" int64_t koaf_conv2d_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH,
                                         int32_t KW, int32_t stride, int32_t pad) {
     const int OH = conv_out(H, KH, stride, pad), OW = conv_out(W, KW, stride, pad);
     WgradPlan p = wgrad_plan(Cout, KH * KW * Cin, (int64_t)N * OH * OW, Cin, 1);
-    return p.splitk > 1 ? (int64_t)(p.splitk + 16) * Cout * KH * KW * Cin : 0;   // +16: koaf_slab_reduce level-1 partials
+    int64_t ws = p.splitk > 1 ? (int64_t)(p.splitk + 16) * Cout * KH * KW * Cin : 0;   // +16: koaf_slab_reduce level-1 partials
+    if (wgrad3_ring_shape(N, H, W, Cin, Cout, KH, KW, stride, pad)) {
+        const int64_t w3 = koaf_wgrad3_ring_ws(N, H, W, Cin, Cout);
+        if (w3 > ws) ws = w3;
+    }
+    return ws;
 }
 
 extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int32_t N, int32_t H, int32_t W,
@@ -468,6 +497,8 @@ extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int
     const int64_t P = (int64_t)N * OH * OW;
     KOAF_REQUIRE(P < (1ll << 31), "koaf_conv2d_wgrad: too many pixels");
     const int Ntot = KH * KW * Cin;
+    if (dy_planes && slabs && wgrad3_ring_shape(N, H, W, Cin, Cout, KH, KW, stride, pad))
+        return koaf_wgrad3_ring(dy_planes, x_planes, dw, slabs, dy_amax, KOAF_ACT_SCALE, N, H, W, Cin, Cout, stream);
     WgradPlan p = wgrad_plan(Cout, Ntot, P, Cin, 1);
     KOAF_REQUIRE(p.splitk == 1 || slabs, "koaf_conv2d_wgrad: workspace required");
     KoafGemm g;
@@ -633,11 +664,18 @@ extern "C" int64_t koaf_stem_wgrad_ws(int32_t N, int32_t H, int32_t W) {
     return (int64_t)(stem_wgrad_blocks(N, H, W) + 16) * 49 * 64;
 }
 extern "C" int koaf_stem_wgrad(const float* dy, const float* x, float* dw1t, int32_t N, int32_t H, int32_t W,
-                               float* slabs, void* stream) {
-    KOAF_REQUIRE(dy && x && dw1t && slabs && N > 0, "koaf_stem_wgrad: bad args");
+                               float* slabs, const KoafBnApply* dy_apply, int32_t act16, void* stream) {
+    KOAF_REQUIRE((dy || dy_apply) && x && dw1t && slabs && N > 0, "koaf_stem_wgrad: bad args");
+    KOAF_REQUIRE(!dy_apply || (dy_apply->dz && dy_apply->c && dy_apply->coef), "koaf_stem_wgrad: dy_apply needs dz / c / coef");
     const int OH = conv_out(H, 7, 2, 3), OW = conv_out(W, 7, 2, 3);
     const int nb = stem_wgrad_blocks(N, H, W);
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb), dim3(256), 0, STREAM, dy, x, slabs, N, H, W, OH, OW);
+    if (dy_apply) {
+        if (act16) hipLaunchKernelGGL((stem_wgrad_kernel<true, true>), dim3(nb), dim3(256), 0, STREAM, dy_apply->dz, x, slabs, N, H, W, OH, OW,
+                                      dy_apply->c, dy_apply->coef);
+        else hipLaunchKernelGGL((stem_wgrad_kernel<true, false>), dim3(nb), dim3(256), 0, STREAM, dy_apply->dz, x, slabs, N, H, W, OH, OW,
+                                dy_apply->c, dy_apply->coef);
+    } else
+        hipLaunchKernelGGL((stem_wgrad_kernel<false, false>), dim3(nb), dim3(256), 0, STREAM, dy, x, slabs, N, H, W, OH, OW, nullptr, nullptr);
     int rc = koaf_check_launch("koaf_stem_wgrad");
     if (rc != KOAF_OK) return rc;
     return koaf_slab_reduce(slabs, nb, 49 * 64, dw1t, stream);

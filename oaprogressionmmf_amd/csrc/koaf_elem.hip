@@ -269,14 +269,18 @@ __global__ void __launch_bounds__(256) bn_add_relu_kernel(const float* __restric
 }
 
 // BN backward pass 1: masked gradient + column partials of dz and dz*xhat   (H: c and ymask are bf16 activations)
-template <bool H>
+// POOL: g is not a tensor of `rows` rows but the gradient of the 3x3 / stride-2 / pad-1 max-pool that follows this BatchNorm
+// (+ReLU): pool_g [N][OH][OW][C] with the window positions pool_am recorded (koaf_maxpool_fwd); the gradient of input pixel
+// (n, iy, ix) is gathered here -- the arithmetic of maxpool_bwd_kernel -- instead of being written by it and read back
+struct PoolGeom { const float* g; const uint8_t* am; int H, W, OH, OW; };
+template <bool H, bool POOL>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ c,
                                                             const float* __restrict__ ymask,
                                                             const float* __restrict__ sc, const float* __restrict__ sh,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, int mask_mode,
                                                             float* __restrict__ dz_out, int64_t rows, int C,
-                                                            ColGeom geo, float* __restrict__ part, float* dz_amax) {
+                                                            ColGeom geo, float* __restrict__ part, float* dz_amax, PoolGeom pg) {
     const int t = threadIdx.x, cvx = t % geo.CV, ry = t / geo.CV;
     unsigned am = 0u;       // largest |dz| as magnitude bits (a NaN / Inf wins: koaf_common.h)
     const int c0 = blockIdx.y * geo.CW + 4 * cvx;
@@ -288,7 +292,33 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* __restr
     v4f s[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     for (int64_t r = rbeg + ry; r < rend; r += geo.RP) {
         const int64_t o = r * C + c0;
-        v4f gv = *(const v4f*)&g[o];
+        v4f gv;
+        if constexpr (POOL) {
+            int64_t pp = r;
+            const int ix = (int)(pp % pg.W);
+            pp /= pg.W;
+            const int iy = (int)(pp % pg.H);
+            const int n = (int)(pp / pg.H);
+            gv = (v4f){0.f, 0.f, 0.f, 0.f};
+            // output windows covering (iy, ix): oy*2-1 <= iy <= oy*2+1
+            for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+                if (oy >= pg.OH) continue;
+                const int kh = iy - (oy * 2 - 1);
+                for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+                    if (ox >= pg.OW) continue;
+                    const int kw = ix - (ox * 2 - 1);
+                    const int64_t po = ((int64_t)(n * pg.OH + oy) * pg.OW + ox) * C + c0;
+                    const uint32_t a4 = *(const uint32_t*)&pg.am[po];
+                    const v4f gg = *(const v4f*)&pg.g[po];
+                    const uint32_t want = (uint32_t)(kh * 3 + kw);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (((a4 >> (8 * j)) & 0xffu) == want) gv[j] += gg[j];
+                }
+            }
+        } else {
+            gv = *(const v4f*)&g[o];
+        }
         v4f cvv = load4<H>(c, o);
         if (mask_mode == 1) {
             v4f yv = load4<H>(ymask, o);
@@ -1086,12 +1116,35 @@ extern "C" int koaf_bn_bwd_reduce(const float* g, const float* c, const float* y
         koaf_set_error("koaf_bn_bwd_reduce: memset failed");
         return KOAF_ELAUNCH;
     }
-    if (act16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(geo.nblk, geo.nchunk), dim3(256), 0, STREAM, g, c, ymask, sc, sh,
-                                  mean, invstd, mask_mode, dz_out, rows, C, geo, part, dz_amax);
-    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(geo.nblk, geo.nchunk), dim3(256), 0, STREAM, g, c, ymask, sc, sh,
-                            mean, invstd, mask_mode, dz_out, rows, C, geo, part, dz_amax);
+    const PoolGeom nopool{nullptr, nullptr, 0, 0, 0, 0};
+    if (act16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, false>), dim3(geo.nblk, geo.nchunk), dim3(256), 0, STREAM, g, c, ymask, sc, sh,
+                                  mean, invstd, mask_mode, dz_out, rows, C, geo, part, dz_amax, nopool);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, false>), dim3(geo.nblk, geo.nchunk), dim3(256), 0, STREAM, g, c, ymask, sc, sh,
+                            mean, invstd, mask_mode, dz_out, rows, C, geo, part, dz_amax, nopool);
     *part_rows = geo.nblk;
     return koaf_check_launch("koaf_bn_bwd_reduce");
+}
+
+extern "C" int koaf_bn_bwd_reduce_pool(const float* pool_g, const uint8_t* pool_argmax, const float* c, const float* sc,
+                                       const float* sh, const float* mean, const float* invstd, float* dz_out, float* part,
+                                       int32_t* part_rows, int32_t N, int32_t H, int32_t W, int32_t C, float* dz_amax,
+                                       int32_t act16, void* stream) {
+    ColGeom geo;
+    KOAF_REQUIRE(pool_g && pool_argmax && c && sc && sh && mean && invstd && dz_out && part && part_rows && N > 0 && H > 0 && W > 0,
+                 "koaf_bn_bwd_reduce_pool: bad args");
+    const int64_t rows = (int64_t)N * H * W;
+    KOAF_REQUIRE(col_geom(rows, C, 1024, &geo), "koaf_bn_bwd_reduce_pool: unsupported C=%d", C);
+    if (dz_amax && hipMemsetAsync(dz_amax, 0, sizeof(float), STREAM) != hipSuccess) {
+        koaf_set_error("koaf_bn_bwd_reduce_pool: memset failed");
+        return KOAF_ELAUNCH;
+    }
+    const PoolGeom pg{pool_g, pool_argmax, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1};
+    if (act16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true>), dim3(geo.nblk, geo.nchunk), dim3(256), 0, STREAM, nullptr, c, nullptr,
+                                  sc, sh, mean, invstd, 2, dz_out, rows, C, geo, part, dz_amax, pg);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<false, true>), dim3(geo.nblk, geo.nchunk), dim3(256), 0, STREAM, nullptr, c, nullptr,
+                            sc, sh, mean, invstd, 2, dz_out, rows, C, geo, part, dz_amax, pg);
+    *part_rows = geo.nblk;
+    return koaf_check_launch("koaf_bn_bwd_reduce_pool");
 }
 extern "C" int koaf_bn_bwd_finalize(const float* part, int32_t part_rows, int32_t C, int64_t count, const float* sc,
                                     const float* invstd, float* dgamma, float* dbeta, float* coef, int32_t nsum,

@@ -111,9 +111,13 @@ __device__ __forceinline__ void split2h(const v4f x, unsigned out[2][2]) {
     for (int d = 0; d < 2; ++d) {
         const float a = x[2 * d], b = x[2 * d + 1];
         const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector((v2f){a, b}, h16x2));
-        const h16x2 hv = __builtin_bit_cast(h16x2, hb);
         out[0][d] = hb;
-        out[1][d] = __builtin_bit_cast(unsigned, __builtin_convertvector((v2f){a - (float)hv[0], b - (float)hv[1]}, h16x2));
+        // residuals x - float(hi) in ONE instruction each (v_fma_mix_f32 reads the fp16 half of hb directly: the exact difference,
+        // rounded once -- the bits of v_cvt_f32_f16 + v_sub_f32, which hipcc emits for the C++ form, at half the vector issue)
+        float ra, rb;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hb), "v"(a));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hb), "v"(b));
+        out[1][d] = __builtin_bit_cast(unsigned, __builtin_convertvector((v2f){ra, rb}, h16x2));
     }
 }
 

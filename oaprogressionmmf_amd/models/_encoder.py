@@ -233,7 +233,7 @@ def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True,
     return dx
 
 
-def _bn_bwd(bn, g, c, saved, rows, mask_mode, ymask=None, dz_out=None, dc_out=None, fused=None):
+def _bn_bwd(bn, g, c, saved, rows, mask_mode, ymask=None, dz_out=None, dc_out=None, fused=None, pool=None):
     """-> dc of a BatchNorm(+ReLU mask): an ops.BnApply when the consumers can form it on load (fused), else the tensor"""
     C = bn.num_features
     gg, ag = grad_target(bn.weight)
@@ -245,7 +245,7 @@ def _bn_bwd(bn, g, c, saved, rows, mask_mode, ymask=None, dz_out=None, dc_out=No
             dc = dc.materialize(out=dc_out, want_amax=True)      # (A/B switch: dc written out, with its exact max |dc|)
     else:
         dc = ops.bn_bwd(g, c, saved, rows, C, rows, gg, gb, mask_mode, ymask=ymask, dz_out=dz_out,
-                        dc_out=None if fused else dc_out, fused=fused)
+                        dc_out=None if fused else dc_out, fused=fused, pool=pool)
     deliver_grad(bn.weight, gg, ag)
     deliver_grad(bn.bias, gb, ab)
     return dc
@@ -267,6 +267,7 @@ def _bn_bwd_part(bn, part, nsum, i1, dz, c, saved, rows, dc_out=None, dzmax=None
 
 
 FUSE_BNB = os.environ.get("KOAF_FUSE_BNB", "1") != "0"
+FUSE_STEM_BWD = os.environ.get("KOAF_FUSE_STEM_BWD", "1") != "0"
 
 
 def _tail_bnb(prev):
@@ -591,11 +592,16 @@ class EncoderFn(torch.autograd.Function):
             del recs, y
         # stem: max-pool, BN0, conv1 weight gradient (no data gradient: the input is a leaf)
         conv1, bn1 = st["conv1"], st["bn1"]
-        da0 = ops.maxpool_bwd(dy, S["am"], N, H1, W1, 64)
         c0 = S["c0"]
         if c0 is None:
             c0 = ops.stem_fwd(S["x"], ops.stem_fold_w(packed_weight(conv1.weight)), N, H, W, dtype=S["adt"])
-        dc0 = _bn_bwd(bn1, da0, c0, S["s0"], N * H1 * W1, 2, dc_out=da0, fused=False)    # (the stem's wgrad is not a GEMM)
+        if FUSE_STEM_BWD:
+            # the max-pool's input gradient is gathered inside the BatchNorm reduction and dc0 is formed by the weight gradient
+            # while it loads (dz, c0): neither tensor is written (two of the four passes over the largest activation of the trunk)
+            dc0 = _bn_bwd(bn1, None, c0, S["s0"], N * H1 * W1, 2, fused=True, pool=(dy, S["am"], N, H1, W1))
+        else:
+            da0 = ops.maxpool_bwd(dy, S["am"], N, H1, W1, 64)
+            dc0 = _bn_bwd(bn1, da0, c0, S["s0"], N * H1 * W1, 2, dc_out=da0, fused=False)
         gw, acc = grad_target(conv1.weight)
         ops.stem_wgrad(dc0, S["x"], gw, N, H, W)
         deliver_grad(conv1.weight, gw, acc)

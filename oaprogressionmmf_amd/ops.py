@@ -398,11 +398,13 @@ def stem_fwd(x, w1t, N, H, W, dtype=torch.float32):
 
 
 def stem_wgrad(dy, x, dw, N, H, W):
-    """writes dw (packed [64,7,7,3] memory)"""
+    """writes dw (packed [64,7,7,3] memory); dy may be a BnApply (the stem BatchNorm's backward, formed on load)"""
     L = lib()
-    slabs = _empty((L.koaf_stem_wgrad_ws(N, H, W),), dy)
-    dw1t = _empty((49, 64), dy)
-    check(L.koaf_stem_wgrad(_ptr(dy), _ptr(x), _ptr(dw1t), N, H, W, _ptr(slabs), _stream()), "stem_wgrad")
+    dyp, _, app, like = _dy_args(dy, None)
+    slabs = _empty((L.koaf_stem_wgrad_ws(N, H, W),), like)
+    dw1t = _empty((49, 64), like)
+    check(L.koaf_stem_wgrad(dyp, _ptr(x), _ptr(dw1t), N, H, W, _ptr(slabs), app, _a16(dy.c) if app is not None else 0, _stream()),
+          "stem_wgrad")
     check(L.koaf_stem_unfold_dw(_ptr(dw1t), _ptr(dw), _stream()), "stem_unfold_dw")
     return dw
 
@@ -446,11 +448,24 @@ def bn_add_relu(c, saved, rows, C, idt=None, idsaved=None, out=None):
     return y
 
 
-def bn_bwd(g, c, saved, rows, C, count, dgamma, dbeta, mask_mode, ymask=None, dz_out=None, dc_out=None, fused=False):
+def bn_bwd(g, c, saved, rows, C, count, dgamma, dbeta, mask_mode, ymask=None, dz_out=None, dc_out=None, fused=False, pool=None):
     """Full BatchNorm(+ReLU mask) backward: reduce -> finalize -> dc.  g is the upstream gradient; with a mask the masked
     gradient dz is written to dz_out (default: in place over g).  fused=False: dc is written out (koaf_bn_bwd_apply) and
     returned; fused=True: returns a BnApply -- the recipe of dc for the GEMM loaders -- and nothing is written."""
     L = lib()
+    if pool is not None:
+        # g is the gradient of the max-pool behind this BatchNorm(+ReLU): pool = (pool_g [N,OH,OW,C], argmax, N, H, W); the pool's
+        # input gradient is gathered by the reduction itself (koaf_bn_bwd_reduce_pool) and only the masked dz is written
+        pg, am, pN, pH, pW = pool
+        assert g is None and mask_mode == 2 and rows == pN * pH * pW
+        dz = dz_out if dz_out is not None else _empty((pN, pH, pW, C), pg)
+        part = _empty((L.koaf_colpart_rows(rows, C), 2, C), pg)
+        r = _i32(0)
+        dzmax = _empty((1,), pg) if fused else None
+        check(L.koaf_bn_bwd_reduce_pool(_ptr(pg), _ptr(am), _ptr(c), _ptr(saved[2]), _ptr(saved[3]), _ptr(saved[0]), _ptr(saved[1]),
+                                        _ptr(dz), _ptr(part), ctypes.addressof(r), pN, pH, pW, C, _ptr(dzmax), _a16(c), _stream()),
+              "bn_bwd_reduce_pool")
+        return _bn_bwd_tail(part[:r.value], 2, 1, dz, c, saved, rows, C, count, dgamma, dbeta, dc_out, fused, dzmax)
     if mask_mode != 0 and dz_out is None:
         dz_out = g  # mask in place
     part = _empty((L.koaf_colpart_rows(rows, C), 2, C), g)
