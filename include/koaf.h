@@ -339,8 +339,11 @@ int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp, int32_t N
 /* ---- Stem: 7x7 s2 p3 conv on the 1->3 channel-repeated image (_torchvision.py:170; the
  * `repeat "b ch r c -> b (k ch) r c", k=3` of _xrNmrMcP.py:211-213 is folded: w1t = sum_c w[:,c]).
  * x [N,H,W] (single channel), w1t [49][64], y [N,OH,OW,64].  */
+/* stats (nullable): koaf_stem_stats_rows(N, H) rows of [2][64] -- column sums and sums of squares of y about stats_shift[64]
+ * (nullable = 0), the partials koaf_bn_finalize takes for the BatchNorm behind the stem (as koaf_conv2d_fwd's stats) */
+int32_t koaf_stem_stats_rows(int32_t N, int32_t H);
 int koaf_stem_fwd(const float* x, const float* w1t, float* y, int32_t N, int32_t H, int32_t W,
-                  int32_t act16, void* stream);
+                  float* stats, const float* stats_shift, int32_t act16, void* stream);
 int64_t koaf_stem_wgrad_ws(int32_t N, int32_t H, int32_t W);
 /* dy_apply (nullable; dy may then be NULL): dy is formed on load from (dz, c, coef) as coef0*dz + coef3 - coef2*c -- the
  * BatchNorm-backward apply of the stem's BatchNorm (koaf_bn_bwd_finalize with mean) -- and never written; act16: c is bf16 */

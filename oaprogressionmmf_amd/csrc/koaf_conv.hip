@@ -88,13 +88,20 @@ __device__ __forceinline__ void stem_load_patch(float (*patch)[ST_PW], const flo
     }
 }
 
-// Y16: the output is stored as bf16 (activation storage mode)
-template <bool Y16>
+// Y16: the output is stored as bf16 (activation storage mode); ST: per-block column sums and sums of squares of the (stored)
+// output about `shift` go to part [block][2][64] -- the statistics of the BatchNorm behind the stem, without a pass over y
+template <bool Y16, bool ST>
 __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1t,
-                                                       float* __restrict__ y, int N, int H, int W, int OH, int OW) {
+                                                       float* __restrict__ y, int N, int H, int W, int OH, int OW,
+                                                       float* __restrict__ part, const float* __restrict__ shift) {
+    float s1 = 0.f, s2 = 0.f, kshift = 0.f;
     auto put = [&](int64_t idx, float v) {
-        if constexpr (Y16) reinterpret_cast<__bf16*>(y)[idx] = (__bf16)v;
-        else y[idx] = v;
+        if constexpr (Y16) {
+            const __bf16 r = (__bf16)v;
+            reinterpret_cast<__bf16*>(y)[idx] = r;
+            v = (float)r;
+        } else y[idx] = v;
+        if constexpr (ST) { const float d = v - kshift; s1 += d; s2 += d * d; }
     };
     __shared__ __attribute__((aligned(16))) float patch[ST_PH][ST_PW];
     const int co = threadIdx.x & 63, pg = threadIdx.x >> 6;
@@ -106,6 +113,7 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
     float wr[49];
 #pragma unroll
     for (int k = 0; k < 49; ++k) wr[k] = w1t[k * 64 + co];
+    if constexpr (ST) kshift = shift ? shift[co] : 0.f;
     const int oy = oy0 + pg;
 #pragma unroll 1
     for (int bx = 0; bx < tx; ++bx) {
@@ -133,6 +141,18 @@ __global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__
                 if (ox < OW) put((((int64_t)n * OH + oy) * OW + ox) * 64 + co, a0);
                 if (ox + 1 < OW) put((((int64_t)n * OH + oy) * OW + ox + 1) * 64 + co, a1);
             }
+        }
+    }
+    if constexpr (ST) {
+        __shared__ float sred[2][ST_TH][64];
+        sred[0][pg][co] = s1;
+        sred[1][pg][co] = s2;
+        __syncthreads();
+        if (pg < 2) {
+            float a = 0.f;
+#pragma unroll
+            for (int g = 0; g < ST_TH; ++g) a += sred[pg][g][co];
+            part[((int64_t)blockIdx.x * 2 + pg) * 64 + co] = a;
         }
     }
 }
@@ -645,14 +665,21 @@ extern "C" int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp
 // ================================================================================================
 // stem
 // ================================================================================================
+extern "C" int32_t koaf_stem_stats_rows(int32_t N, int32_t H) { return (int32_t)((int64_t)N * cdiv64(conv_out(H, 7, 2, 3), ST_TH)); }
 extern "C" int koaf_stem_fwd(const float* x, const float* w1t, float* y, int32_t N, int32_t H, int32_t W,
-                             int32_t act16, void* stream) {
+                             float* stats, const float* stats_shift, int32_t act16, void* stream) {
     KOAF_REQUIRE(x && w1t && y && N > 0 && H > 0 && W > 0, "koaf_stem_fwd: bad args");
     const int OH = conv_out(H, 7, 2, 3), OW = conv_out(W, 7, 2, 3);
     const int64_t blocks = (int64_t)N * cdiv64(OH, ST_TH);          // one per (image, row band)
     KOAF_REQUIRE(blocks < (1ll << 31), "koaf_stem_fwd: grid too large");
-    if (act16) hipLaunchKernelGGL(stem_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, STREAM, x, w1t, y, N, H, W, OH, OW);
-    else hipLaunchKernelGGL(stem_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, STREAM, x, w1t, y, N, H, W, OH, OW);
+    const dim3 grid((unsigned)blocks);
+    if (stats) {
+        if (act16) hipLaunchKernelGGL((stem_fwd_kernel<true, true>), grid, dim3(256), 0, STREAM, x, w1t, y, N, H, W, OH, OW, stats, stats_shift);
+        else hipLaunchKernelGGL((stem_fwd_kernel<false, true>), grid, dim3(256), 0, STREAM, x, w1t, y, N, H, W, OH, OW, stats, stats_shift);
+    } else {
+        if (act16) hipLaunchKernelGGL((stem_fwd_kernel<true, false>), grid, dim3(256), 0, STREAM, x, w1t, y, N, H, W, OH, OW, nullptr, nullptr);
+        else hipLaunchKernelGGL((stem_fwd_kernel<false, false>), grid, dim3(256), 0, STREAM, x, w1t, y, N, H, W, OH, OW, nullptr, nullptr);
+    }
     return koaf_check_launch("koaf_stem_fwd");
 }
 static inline int stem_wgrad_blocks(int N, int H, int W) {

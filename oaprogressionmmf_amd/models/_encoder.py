@@ -62,7 +62,10 @@ def _can_take_tail(blk):
     return img is not None and img[0] is not None
 
 
-def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None, tail_idt=None, tail_out=None, tail_idsaved=None):
+KEEP_PLANES_RECOMPUTE = os.environ.get("KOAF_KEEP_PLANES_RECOMPUTE", "1") != "0"
+
+
+def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None, tail_idt=None, tail_out=None, tail_idsaved=None, keep_planes=False):
     """bn: the BatchNorm that consumes this conv's output statistics; tail_idt: x / in_saved are the previous block's last
     conv output and BatchNorm, tail_idt its identity -- the input is their bottleneck tail, formed on load (then the sixth
     return value is that input, written by the convolution)"""
@@ -79,7 +82,7 @@ def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None, tail_idt=None, tail_ou
         return y, part, ops.conv_out(H, k, s, p), ops.conv_out(W, k, s, p), wexp, yin
     if g == 1:
         y, part = ops.conv2d_fwd(x, w, N, H, W, cin, cout, k, k, s, p, sc, sh, stats=train, shift=shift,
-                                 wimg=weight_planes(conv.weight))
+                                 wimg=weight_planes(conv.weight), keep_planes=keep_planes)
     else:
         if k != 3 or p != 1 or cin != cout:
             raise NotImplementedError("grouped convolution other than the ResNeXt 3x3 is not built")
@@ -268,6 +271,7 @@ def _bn_bwd_part(bn, part, nsum, i1, dz, c, saved, rows, dc_out=None, dzmax=None
 
 FUSE_BNB = os.environ.get("KOAF_FUSE_BNB", "1") != "0"
 FUSE_STEM_BWD = os.environ.get("KOAF_FUSE_STEM_BWD", "1") != "0"
+REUSE_STAGE_INPUT = os.environ.get("KOAF_REUSE_STAGE_INPUT", "1") != "0"
 
 
 def _tail_bnb(prev):
@@ -281,13 +285,14 @@ def _tail_bnb(prev):
     return d
 
 
-def _block_fwd(blk, y, N, Hc, Wc, train, given, tail=None, defer=False):
+def _block_fwd(blk, y, N, Hc, Wc, train, given, tail=None, defer=False, skip_tail=False):
     """Forward of one residual block.  given = None: statistics are collected by the conv epilogues and
     finalised (normal forward).  given = (s1, s2, s3, sd): activation RECOMPUTE in backward -- the saved
     BatchNorm statistics are reused, nothing is reduced and no running statistic is touched.
     tail = (c_last, s_last, identity, y buffer, identity's BatchNorm record or None) of the PREVIOUS block whose tail was deferred (y is None then): this block's conv1 forms
     its own input on load and writes it (r.yin).  defer: leave THIS block's tail to the next block (r.y stays None, r.tail
-    holds what the next call needs); the caller checks _can_take_tail(next block)."""
+    holds what the next call needs); the caller checks _can_take_tail(next block).  skip_tail: the caller already holds this
+    block's output (r.y stays None, nothing is computed for it)."""
     r = _Rec()
     r.blk, r.yin = blk, y
     want = train and given is None
@@ -303,7 +308,10 @@ def _block_fwd(blk, y, N, Hc, Wc, train, given, tail=None, defer=False):
         else:
             r.c1, part, _, _, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, want, blk.bn1)
         r.s1 = fin(blk.bn1, part, N * Hc * Wc, 0)
-        r.c2, part, OH, OW, r.wexp = _conv_fwd(r.c1, blk.conv2, N, Hc, Wc, r.s1, want, blk.bn2)
+        # (rebuilt in backward: the plane images cut for conv2 live on until its weight gradient, a few kernels later, instead of
+        # being cut again -- in the forward pass proper they would have to survive the whole step)
+        r.c2, part, OH, OW, r.wexp = _conv_fwd(r.c1, blk.conv2, N, Hc, Wc, r.s1, want, blk.bn2,
+                                               keep_planes=given is not None and KEEP_PLANES_RECOMPUTE)
         r.s2 = fin(blk.bn2, part, N * OH * OW, 1)
         r.c3, part, _, _, _ = _conv_fwd(r.c2, blk.conv3, N, OH, OW, r.s2, want, blk.bn3)
         r.s3 = fin(blk.bn3, part, N * OH * OW, 2)
@@ -321,10 +329,14 @@ def _block_fwd(blk, y, N, Hc, Wc, train, given, tail=None, defer=False):
     if blk.downsample is not None:
         r.cd, part, _, _, _ = _conv_fwd(y, blk.downsample[0], N, Hc, Wc, None, want, blk.downsample[1])
         r.sd = fin(blk.downsample[1], part, rows_o, 3)
-        if defer and FUSE_TAIL_DS:
+        if skip_tail:
+            pass
+        elif defer and FUSE_TAIL_DS:
             r.tail = (last_c, last_s, r.cd, torch.empty_like(last_c), r.sd)     # (identity = bn_d(cd), formed on load as well)
         else:
             r.y = ops.bn_add_relu(last_c, last_s, rows_o, cout, idt=r.cd, idsaved=r.sd)
+    elif skip_tail:
+        pass
     elif defer:
         # y = relu(bn(last_c) + identity) is formed (and written) by the next block's conv1.  Its buffer is allocated HERE, where
         # the element-wise pass would have allocated its output: the caching allocator then sees the same request order as
@@ -336,16 +348,21 @@ def _block_fwd(blk, y, N, Hc, Wc, train, given, tail=None, defer=False):
     return r
 
 
-def _blocks_fwd(blocks, y, N, Hc, Wc, train, givens=None, tail=None, defer_last=False, slim=False):
+def _blocks_fwd(blocks, y, N, Hc, Wc, train, givens=None, tail=None, defer_last=False, slim=False, last_y=None):
     """forward of consecutive blocks with the bottleneck tails left to the following conv1 where possible; -> (records, y of the
     last block or None when its tail was deferred (records[-1].tail), H, W).  tail: a deferred tail entering the first block.
     slim: the records are not needed for backward (a stage that will be rebuilt, or no gradient at all): each one gives up its
-    conv outputs as soon as the following block has consumed them, so that only ~two blocks are alive at a time."""
+    conv outputs as soon as the following block has consumed them, so that only ~two blocks are alive at a time.
+    last_y: the output of the last block, when the caller still holds it (a stage rebuilt in backward: it is the saved input of
+    the following stage) -- its tail is then not computed again."""
     recs, yin0 = [], None
     for i, blk in enumerate(blocks):
         nxt = blocks[i + 1] if i + 1 < len(blocks) else None
         defer = (nxt is not None and _can_take_tail(nxt)) or (nxt is None and defer_last)
-        r = _block_fwd(blk, y, N, Hc, Wc, train, givens[i] if givens is not None else None, tail=tail, defer=defer)
+        have = nxt is None and last_y is not None
+        r = _block_fwd(blk, y, N, Hc, Wc, train, givens[i] if givens is not None else None, tail=tail, defer=defer, skip_tail=have)
+        if have:
+            r.y = last_y
         if i == 0:
             yin0 = r.yin                     # the input of the first block (written by its conv1 when a tail came in)
         if recs:
@@ -394,9 +411,11 @@ class EncoderFn(torch.autograd.Function):
         train = bn1.training
         w1t = ops.stem_fold_w(packed_weight(conv1.weight))
         adt = getattr(trunk, "act_dtype", torch.float32)       # storage type of the forward activations (KoafTrunk.act_dtype)
-        c0 = ops.stem_fwd(x, w1t, N, H, W, dtype=adt)
+        if train:       # (the statistics of bn1 come out of the stem kernel: no pass over its output, the largest tensor of the trunk)
+            c0, part = ops.stem_fwd(x, w1t, N, H, W, dtype=adt, stats=True, shift=_stat_shift(bn1, train))
+        else:
+            c0, part = ops.stem_fwd(x, w1t, N, H, W, dtype=adt), None
         H1, W1 = c0.shape[1], c0.shape[2]
-        part = ops.colstats(c0, N * H1 * W1, 64, shift=_stat_shift(bn1, train)) if train else None
         s0 = _bn_fin(bn1, part, N * H1 * W1)
         y, am = ops.maxpool_fwd(c0, s0, N, H1, W1, 64)
         Hc, Wc = y.shape[1], y.shape[2]
@@ -556,6 +575,7 @@ class EncoderFn(torch.autograd.Function):
         side = _SideStream(gout.device, side_stream, hold=S["any_recompute"]) if USE_SIDE_STREAM else None
         stages = st["stages"]
         run = []      # block records of consecutive kept stages: one list, so the fused tail reductions cross stage boundaries
+        next_in = None   # the input of the stage processed last = the output of the stage processed next (when still held)
         for si in range(len(stages) - 1, -1, -1):
             sv = S["stages"][si]
             if not sv["recompute"]:
@@ -563,13 +583,17 @@ class EncoderFn(torch.autograd.Function):
                 sv["recs"] = None
                 if si > 0 and not S["stages"][si - 1]["recompute"]:
                     continue
+                first_in = run[0].yin if REUSE_STAGE_INPUT else None
                 dy = EncoderFn._blocks_bwd(run, dy, side)
                 run = []
+                next_in = first_in
                 continue
             # activation recompute: only the stage input and the BatchNorm statistics were kept; the stage's conv
             # outputs are rebuilt (same kernels, saved statistics, no reductions) right before use
             y, Hc2, Wc2 = sv["yin"], sv["H"], sv["W"]
             sv["yin"] = None
+            stage_in, last_y = (y if REUSE_STAGE_INPUT else None), next_in
+            next_in = None
             if S["block_level"] and len(stages[si]) > 1:
                 # block-granular: pass 1 rebuilds only the block INPUTS of the stage, then every block is rebuilt
                 # alone (last first) and back-propagated -- one block's conv outputs live at a time instead of
@@ -585,12 +609,17 @@ class EncoderFn(torch.autograd.Function):
                     r = _block_fwd(stages[si][bi], yb, N, hb, wb, S["train"], sv["stats"][bi])
                     dy = EncoderFn._blocks_bwd([r], dy, side)
                     del r, yb
-                del y
+                del y, last_y
+                next_in = stage_in
                 continue
-            recs, y, Hc2, Wc2, _ = _blocks_fwd(stages[si], y, N, Hc2, Wc2, S["train"], givens=sv["stats"])
+            # (the stage's output is the input the following stage kept for its own backward: the last tail is not rebuilt)
+            recs, y, Hc2, Wc2, _ = _blocks_fwd(stages[si], y, N, Hc2, Wc2, S["train"], givens=sv["stats"], last_y=last_y)
+            del last_y
             dy = EncoderFn._blocks_bwd(recs, dy, side)
             del recs, y
+            next_in = stage_in
         # stem: max-pool, BN0, conv1 weight gradient (no data gradient: the input is a leaf)
+        next_in = None
         conv1, bn1 = st["conv1"], st["bn1"]
         c0 = S["c0"]
         if c0 is None:

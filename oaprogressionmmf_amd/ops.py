@@ -192,7 +192,7 @@ def use_aplanes(wimg, KH, KW, C):
 
 
 def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, stats=False, shift=None, wimg=None,
-               aplanes=None, tail_idt=None, tail_out=None, tail_idsaved=None):
+               aplanes=None, tail_idt=None, tail_out=None, tail_idsaved=None, keep_planes=False):
     """x [N,H,W,Cin] (any view with that memory), w packed [Cout,KH,KW,Cin] -> y [N,OH,OW,Cout],
     (part, rows) per-tile column statistics if stats, summed about `shift` [Cout] (hand the same tensor to bn_finalize).
     wimg = (F, D, amax) plane images of w (arena.weight_planes) or None: with them the contraction runs on the fp16
@@ -200,7 +200,8 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     tail_idt (1x1 / stride 1 with wimg): x is the PREVIOUS block's raw last conv output c3, in_sc / in_sh its BatchNorm
     coefficients and tail_idt that block's identity: the input y = relu(in_sc*x + in_sh + tail_idt) (the bottleneck tail) is
     formed on load and written to tail_out (allocated here when None); returns (y, part, tail_out).  tail_idsaved: the block had a
-    downsample branch -- tail_idt is that branch's raw conv output and tail_idsaved its BatchNorm record (mean, invstd, sc, sh)."""
+    downsample branch -- tail_idt is that branch's raw conv output and tail_idsaved its BatchNorm record (mean, invstd, sc, sh).
+    keep_planes: the activation plane images cut for this call stay attached to the output for its weight gradient."""
     L = lib()
     OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
     if tail_idt is not None and tail_out is None:
@@ -229,7 +230,7 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     check(L.koaf_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
                             _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _ptr(shift) if stats else None,
                             _img(wimg), xpl.data_ptr() if xpl is not None else None, tail, _a16(x), _stream()), "conv2d_fwd")
-    if xpl is not None and not torch.is_tensor(aplanes) and xpl.numel() <= KEEP_XPLANES_ELEMS:
+    if xpl is not None and not torch.is_tensor(aplanes) and (keep_planes or xpl.numel() <= KEEP_XPLANES_ELEMS):
         y._koaf_xplanes = xpl       # ride on the output: this conv's weight gradient reads them instead of cutting them again
     _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin,
               f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}" + (" +tail" if tail is not None else ""),
@@ -390,11 +391,14 @@ def stem_fold_w(w):
     return w1t
 
 
-def stem_fwd(x, w1t, N, H, W, dtype=torch.float32):
-    """dtype: storage type of the output activation (torch.float32, or torch.bfloat16: koaf.h "bf16 ACTIVATION STORAGE")"""
+def stem_fwd(x, w1t, N, H, W, dtype=torch.float32, stats=False, shift=None):
+    """dtype: storage type of the output activation (torch.float32, or torch.bfloat16: koaf.h "bf16 ACTIVATION STORAGE");
+    stats: -> (y, part): the column statistics of y about `shift`, collected by the kernel (what colstats(y) would reduce)"""
+    L = lib()
     y = _empty((N, conv_out(H, 7, 2, 3), conv_out(W, 7, 2, 3), 64), x, dtype=dtype)
-    check(lib().koaf_stem_fwd(_ptr(x), _ptr(w1t), _ptr(y), N, H, W, _a16(y), _stream()), "stem_fwd")
-    return y
+    part = _empty((L.koaf_stem_stats_rows(N, H), 2, 64), x) if stats else None
+    check(L.koaf_stem_fwd(_ptr(x), _ptr(w1t), _ptr(y), N, H, W, _ptr(part), _ptr(shift) if stats else None, _a16(y), _stream()), "stem_fwd")
+    return (y, part) if stats else y
 
 
 def stem_wgrad(dy, x, dw, N, H, W):

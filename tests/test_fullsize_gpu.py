@@ -209,7 +209,7 @@ def test_headline_syn3_batch8_train_step_and_eval(dev):
     under pytest: one train step with the headline policy "012,012,01" against the same step with bench.py's out-of-memory
     fallback policy (every stage rebuilt block by block) -- the loss bit-equal, every gradient finite and within 1e-4 relative
     (recomputed activations are the same bits; what differs is the summation order of a few BatchNorm reductions), peak
-    memory under 250 GiB reserved, the fallback needing at least 10 GiB less -- and eval-mode sample independence at batch 8.  A tile-count, 32-bit-offset or lane-ordering error that only shows at 3840 x 384^2 fails here,
+    memory under 256 GiB reserved, the fallback needing at least 10 GiB less -- and eval-mode sample independence at batch 8.  A tile-count, 32-bit-offset or lane-ordering error that only shows at 3840 x 384^2 fails here,
     not in a plausible `last_loss`."""
     import bench
     from oaprogressionmmf_amd.models import KoafTrunk
@@ -254,10 +254,11 @@ def test_headline_syn3_batch8_train_step_and_eval(dev):
             t.recompute = False
     assert l0 == l1 and np.isfinite(l0), (l0, l1)
     print(f"\n[syn3 batch 8] peak GiB (reserved, allocated): headline policy {mem0}, lean policy {mem1}")
-    # of the 288 GB = 268 GiB of HBM: the headline policy's first (cold-allocator) step stays under 250 GiB reserved, and the
-    # fallback policy needs less at its peak -- its reserved figure here includes what the first run left fragmented in the
-    # pool, so it is the allocated peaks that are compared
-    assert mem0[0] < 250.0, mem0
+    # of the 288 GB = 268 GiB of HBM: the headline policy's first (cold-allocator) step stays under 256 GiB reserved (245-248
+    # measured: the plane images a rebuilt stage keeps for its weight gradients and the stage inputs reused as the rebuilt
+    # stages' outputs trade 14 GiB for 47 ms per step), and the fallback policy needs less at its peak -- its reserved figure
+    # here includes what the first run left fragmented in the pool, so it is the allocated peaks that are compared
+    assert mem0[0] < 256.0, mem0
     assert mem1[1] < mem0[1] - 10.0, (mem0, mem1)
     assert len(g0) > 800 and sorted(g0) == sorted(g1)
     assert all(bool(torch.isfinite(g).all()) for g in g0.values())

@@ -180,6 +180,13 @@ def test_stem(dev, N, H, W):
     xd = x.reshape(N, H, W).contiguous().to(dev)
     y = ops.stem_fwd(xd, w1t, N, H, W)
     assert rel_err(nchw(y.cpu()), y_ref) < 2e-6
+    # the statistics epilogue: same output, partial sums of (y - shift) and (y - shift)^2 per block
+    shift = (rnd(64) * 0.1).to(dev)
+    for dt in (torch.float32, torch.bfloat16):
+        y2, part = ops.stem_fwd(xd, w1t, N, H, W, dtype=dt, stats=True, shift=shift)
+        assert torch.equal(y2, y if dt == torch.float32 else y.bfloat16())
+        d = y2.double().reshape(-1, 64) - shift.double()
+        assert rel_err(part[:, 0].double().sum(0), d.sum(0)) < 1e-5 and rel_err(part[:, 1].double().sum(0), (d * d).sum(0)) < 1e-5
     dw = torch.empty(64, 7, 7, 3, device=dev)
     ops.stem_wgrad(nhwc(dy).to(dev), xd, dw, N, H, W)
     # folded gradient: every one of the 3 input channels sees the same image, so dW[:,c] are identical
