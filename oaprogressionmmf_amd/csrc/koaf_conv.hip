@@ -665,6 +665,9 @@ extern "C" int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp
 // ================================================================================================
 // stem
 // ================================================================================================
+// koaf_stem.hip: the same convolution on the matrix pipe (three bf16 pieces per operand); 1 = not taken
+int koaf_stem_fwd_mma(const float* x, const float* w1t, float* y, int N, int H, int W, float* stats, const float* stats_shift,
+                      int act16, void* stream);
 extern "C" int32_t koaf_stem_stats_rows(int32_t N, int32_t H) { return (int32_t)((int64_t)N * cdiv64(conv_out(H, 7, 2, 3), ST_TH)); }
 extern "C" int koaf_stem_fwd(const float* x, const float* w1t, float* y, int32_t N, int32_t H, int32_t W,
                              float* stats, const float* stats_shift, int32_t act16, void* stream) {
@@ -672,6 +675,10 @@ extern "C" int koaf_stem_fwd(const float* x, const float* w1t, float* y, int32_t
     const int OH = conv_out(H, 7, 2, 3), OW = conv_out(W, 7, 2, 3);
     const int64_t blocks = (int64_t)N * cdiv64(OH, ST_TH);          // one per (image, row band)
     KOAF_REQUIRE(blocks < (1ll << 31), "koaf_stem_fwd: grid too large");
+    {
+        const int rc = koaf_stem_fwd_mma(x, w1t, y, N, H, W, stats, stats_shift, act16, stream);
+        if (rc <= 0) return rc;          // taken (or failed); 1: the vector kernel below (KOAF_STEM_MMA=0)
+    }
     const dim3 grid((unsigned)blocks);
     if (stats) {
         if (act16) hipLaunchKernelGGL((stem_fwd_kernel<true, true>), grid, dim3(256), 0, STREAM, x, w1t, y, N, H, W, OH, OW, stats, stats_shift);

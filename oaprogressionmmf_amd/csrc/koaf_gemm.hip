@@ -480,13 +480,15 @@ struct TileLoader {
     // block owns the column range (side != nullptr: the first column tile), at element offset base[i] + k0s.
     float* side = nullptr;
     int k0s = 0;
+    // FULL: every element of this wave's slot is valid (interior tiles of the dense operands: the usual case) -- no zero-fill selects
+    template <bool FULL>
     __device__ __forceinline__ void finish_unit(Slot& s, int i, v4f a, v4f b, v4f k, v4f q = (v4f){0.f, 0.f, 0.f, 0.f}) {
         constexpr float HMAX = 65504.f;
         if constexpr (S16) s.r[i] = widen_bf16x4(__float_as_uint(s.r[i][0]), __float_as_uint(s.r[i][1]));
         if constexpr (S2_16 && (TF == 2 || TF == 3)) s.r2[i < NU2 ? i : 0] = widen_bf16x4(__float_as_uint(s.r2[i < NU2 ? i : 0][0]), __float_as_uint(s.r2[i < NU2 ? i : 0][1]));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool ok = VEC ? ((s.vm >> i) & 1u) : ((s.vm >> (4 * i + j)) & 1u);
+            const bool ok = FULL || (VEC ? ((s.vm >> i) & 1u) : ((s.vm >> (4 * i + j)) & 1u));
             float x = s.r[i][j];
             if constexpr (TF == 1) {
                 x = fmaf(x, a[j], b[j]);
@@ -507,7 +509,7 @@ struct TileLoader {
             s.r[i][j] = ok ? x : 0.f;
         }
         if constexpr (TF == 3) {
-            if (side != nullptr && ((s.vm >> i) & 1u)) {
+            if (side != nullptr && (FULL || ((s.vm >> i) & 1u))) {
                 if constexpr (S16) store4<true>(side, base[i] + k0s, s.r2[i < NU2 ? i : 0]);
                 else *(v4f*)(side + base[i] + k0s) = s.r2[i < NU2 ? i : 0];
             }
@@ -516,8 +518,15 @@ struct TileLoader {
     __device__ __forceinline__ void finish(Slot& s) {
         v4f a = KC ? s.ts4 : kts4, b = KC ? s.th4 : kth4, k = KC ? s.tk4 : ktk4;
         if constexpr (F16 && KC && TF != 0 && TF != 3) { a *= fsc; b *= fsc; k *= fsc; }     // (KM coefficients were scaled once in init)
+        // (wave-uniform: one ballot per tile; the ragged last tiles and the padded taps of gathers take the selecting form)
+        constexpr unsigned ALLV = VEC ? ((NU >= 32) ? ~0u : ((1u << NU) - 1u)) : ((4 * NU >= 32) ? ~0u : ((1u << (4 * NU)) - 1u));
+        if (__builtin_amdgcn_ballot_w64(s.vm != ALLV) == 0ull) {
 #pragma unroll
-        for (int i = 0; i < NU; ++i) finish_unit(s, i, a, b, k, s.tq4);
+            for (int i = 0; i < NU; ++i) finish_unit<true>(s, i, a, b, k, s.tq4);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) finish_unit<false>(s, i, a, b, k, s.tq4);
+        }
     }
     // LDS dword offset (within a plane) of unit i of this thread
     __device__ __forceinline__ int plane_off(int i) const {

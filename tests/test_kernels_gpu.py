@@ -165,7 +165,7 @@ def test_gconv3x3(dev, C, groups, stride, H):
     assert rel_err(dw.cpu().permute(0, 3, 1, 2), wd.grad) < BWD
 
 
-@pytest.mark.parametrize("N,H,W", [(3, 40, 40), (2, 35, 31), (1, 70, 70)])
+@pytest.mark.parametrize("N,H,W", [(3, 40, 40), (2, 35, 31), (1, 70, 70), (2, 30, 401), (1, 9, 790)])     # (the last two: several column bands)
 def test_stem(dev, N, H, W):
     from oaprogressionmmf_amd import ops
     x = rnd(N, 1, H, W)
