@@ -668,6 +668,8 @@ extern "C" int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp
 // koaf_stem.hip: the same convolution on the matrix pipe (three bf16 pieces per operand); 1 = not taken
 int koaf_stem_fwd_mma(const float* x, const float* w1t, float* y, int N, int H, int W, float* stats, const float* stats_shift,
                       int act16, void* stream);
+int koaf_stem_wgrad_mma(const float* dy, const float* x, float* slabs, int nb, int N, int H, int W, const float* c,
+                        const float* coef, int act16, void* stream);
 extern "C" int32_t koaf_stem_stats_rows(int32_t N, int32_t H) { return (int32_t)((int64_t)N * cdiv64(conv_out(H, 7, 2, 3), ST_TH)); }
 extern "C" int koaf_stem_fwd(const float* x, const float* w1t, float* y, int32_t N, int32_t H, int32_t W,
                              float* stats, const float* stats_shift, int32_t act16, void* stream) {
@@ -703,6 +705,12 @@ extern "C" int koaf_stem_wgrad(const float* dy, const float* x, float* dw1t, int
     KOAF_REQUIRE(!dy_apply || (dy_apply->dz && dy_apply->c && dy_apply->coef), "koaf_stem_wgrad: dy_apply needs dz / c / coef");
     const int OH = conv_out(H, 7, 2, 3), OW = conv_out(W, 7, 2, 3);
     const int nb = stem_wgrad_blocks(N, H, W);
+    {
+        const int rc = koaf_stem_wgrad_mma(dy_apply ? dy_apply->dz : dy, x, slabs, nb, N, H, W, dy_apply ? dy_apply->c : nullptr,
+                                           dy_apply ? dy_apply->coef : nullptr, act16, stream);
+        if (rc < 0) return rc;
+        if (rc == 0) return koaf_slab_reduce(slabs, nb, 49 * 64, dw1t, stream);       // (1: the vector kernel below, KOAF_STEM_MMA=0)
+    }
     if (dy_apply) {
         if (act16) hipLaunchKernelGGL((stem_wgrad_kernel<true, true>), dim3(nb), dim3(256), 0, STREAM, dy_apply->dz, x, slabs, N, H, W, OH, OW,
                                       dy_apply->c, dy_apply->coef);
