@@ -708,9 +708,9 @@ def main(args):
             "rccl_ranks": rccl_ranks, "comm_exposed_ms": comm_exposed,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak_mix, 1),
                          "unit": "TFLOP/s", "frac": round(achieved / peak_mix, 4), "traffic": traffic,
-                         "traffic_unit": "bytes per koaf_gemm_kernel launch (average)", "traffic_source": traffic_src,
+                         "traffic_unit": "bytes per GEMM-family kernel launch (average)", "traffic_source": traffic_src,
                          "traffic_per_step": traffic_step,
-                         "kernel": "koaf_gemm_kernel (implicit GEMM: conv fwd/dgrad/wgrad, linear, attention; fp32 in/out/accumulate; "
+                         "kernel": "koaf_gemm_kernel + wgrad3x3_ring_kernel (implicit GEMM: conv fwd/dgrad/wgrad, linear, attention; fp32 in/out/accumulate; "
                                    "products on v_mfma_f32_32x32x16_f16 from two scaled fp16 pieces per operand (3 MFMAs per product: "
                                    "convolutions) or on v_mfma_f32_32x32x16_bf16 from three bf16 pieces (6 MFMAs: linear, attention, "
                                    "grouped conv))",

@@ -35,7 +35,7 @@ for tag, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         fh.write("dispatch,kernel,value_kb\n")
         for k, v in per.items():
             name = kn[k].replace("void ", "").replace("(anonymous namespace)::", "")
-            short = "koaf_gemm_kernel" if "koaf_gemm_kernel" in name else name.split("(")[0].split("<")[0][-60:]
+            short = "koaf_gemm_kernel" if "koaf_gemm_kernel" in name else name.split("(")[0].split("<")[0][-60:]     # (wgrad3x3_ring_kernel keeps its own name)
             fh.write(f"{k},{short},{v}\n")
 import os
 for tag in ("fetch", "write"):

@@ -14,14 +14,18 @@ d = json.loads([ln for ln in open(O / "bench.log", errors="ignore") if ln.starts
 workload = tag.split("_")[0]
 
 
+GEMM_KERNELS = ("koaf_gemm_kernel", "wgrad3x3_ring_kernel")      # what bench.py's GEMM-family brackets launch (koaf_gemm.hip, koaf_wgrad3.hip)
+
+
 def kernel_sum(f, name):
-    vals = [float(r["value_kb"]) for r in csv.DictReader(open(f)) if name in r["kernel"]]
+    names = name if isinstance(name, tuple) else (name,)
+    vals = [float(r["value_kb"]) for r in csv.DictReader(open(f)) if any(n in r["kernel"] for n in names)]
     return sum(vals), len(vals)
 
 
 PMC_STEPS = 4       # steps bench.py executes under the PMC passes: 1 warm-up + 1 timed + 1 allocator-settling + 1 instrumented
-fe, n = kernel_sum(O / "fetch_per_dispatch.csv", "koaf_gemm_kernel")
-wr, n2 = kernel_sum(O / "write_per_dispatch.csv", "koaf_gemm_kernel")
+fe, n = kernel_sum(O / "fetch_per_dispatch.csv", GEMM_KERNELS)
+wr, n2 = kernel_sum(O / "write_per_dispatch.csv", GEMM_KERNELS)
 assert n == n2 and n > 0
 fetch_b, write_b = fe * 1024 * 2, wr * 1024
 pfe, pn = kernel_sum(O / "fetch_per_dispatch.csv", "act_planes_kernel")
@@ -29,7 +33,7 @@ pwr, _ = kernel_sum(O / "write_per_dispatch.csv", "act_planes_kernel")
 planes_b = pfe * 1024 * 2 + pwr * 1024
 B = int(d["config"]["workload"].split("per-GPU batch ")[1].split(",")[0])
 out = {
-    "kernel": "koaf_gemm_kernel (all instantiations)", "workload": d["config"]["workload"], "batch": B,
+    "kernel": "koaf_gemm_kernel (all instantiations) + wgrad3x3_ring_kernel", "workload": d["config"]["workload"], "batch": B,
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (one counter per pass) --kernel-trace --output-format csv -- python3 "
                "bench.py --serial --steps 1 --warmup 1 --no-cpu-baseline --no-secondary (scripts/collect_profiles.sh)",
     "launches": n, "FETCH_SIZE_KB_sum": round(fe, 1), "WRITE_SIZE_KB_sum": round(wr, 1),
@@ -53,7 +57,7 @@ shutil.copy(O / "bench.log", ROOT / "profiles" / f"{RND}_bench_{tag}.log")
 shutil.copy(O / "breakdown.txt", ROOT / "profiles" / f"{RND}_gemm_breakdown_{tag}.txt")
 rows = list(csv.DictReader(open(O / "kernel_stats.csv")))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-g = [r for r in rows if "koaf_gemm_kernel" in r["Name"]]
+g = [r for r in rows if any(n in r["Name"] for n in GEMM_KERNELS)]
 gt, gc = sum(float(r["TotalDurationNs"]) for r in g), sum(int(r["Calls"]) for r in g)
 nsteps = 1 + 3 + 1 + 1      # warm-up + timed + allocator-settling + instrumented (bench.py under collect_profiles.sh)
 r = d["roofline"]
