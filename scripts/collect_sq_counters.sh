@@ -8,6 +8,7 @@ mkdir -p $OUT
 PROG=$GRAFT_REPO_ROOT/scripts/bench_gemm_pmc.py
 ARGS="20"
 if [ "$2" = "short" ]; then PROG=$GRAFT_REPO_ROOT/scripts/bench_gemm_pmc_short.py; ARGS="12 $OUT/plan.json"; fi
+if [ "$2" = "new" ]; then PROG=$GRAFT_REPO_ROOT/scripts/bench_new_kernels_pmc.py; ARGS="10 $OUT/plan.json"; fi      # (the round-3 ring / stem / attention kernels)
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/sq1 -o a -- python3 $PROG $ARGS > $OUT/pass1.log 2>&1 || exit 1

@@ -15,6 +15,7 @@ O = Path(sys.argv[1])
 RND = sys.argv[2] if len(sys.argv) > 2 else "r03"
 ROOT = Path(__file__).resolve().parent.parent
 PLAN = json.loads((O / "plan.json").read_text()) if (O / "plan.json").exists() else None
+BYNAME = PLAN is not None and "kernel" in PLAN[0]       # the `new` collection: plan entries name a kernel, not a GEMM template
 LABEL = {
     "128, 128, 0, 0, 0, 0, true, false, 256": "dense forward 4096^3, bf16 x 3 (6 MFMAs per product)",
     "128, 128, 1, 6, 1, 0, true, true, 256": "conv 3x3 256->256 forward, fp16 x 2 (3 MFMAs), fp32 activation loader: BN prologue + split in the k-loop, weight tiles by LDS-DMA",
@@ -33,6 +34,8 @@ def load(tag):
     with open(O / f"{tag}_counter_collection.csv") as fh:
         for r in csv.DictReader(fh):
             m = re.search(r"koaf_gemm_kernel<([^>]*)>", r["Kernel_Name"])
+            if not m and BYNAME:
+                m = re.search(r"(wgrad3x3_ring_kernel|stem_fwd_mma_kernel|stem_wgrad_mma_kernel|attention_fwd_kernel)", r["Kernel_Name"])
             if not m:
                 continue
             d = r["Dispatch_Id"]
@@ -59,8 +62,9 @@ def series(key, per, names, idx=None, count=None):
 if PLAN is not None:
     items, seen = [], collections.Counter()
     for e in PLAN:
-        items.append((e["template"], e["label"], seen[e["template"]], e["launches"]))
-        seen[e["template"]] += 1
+        key = e["kernel"] if BYNAME else e["template"]
+        items.append((key, e["label"], seen[key], e["launches"]))
+        seen[key] += 1
 else:
     items = [(k, lab, None, None) for k, lab in LABEL.items()]
 for key, label, idx, count in items:
@@ -76,7 +80,7 @@ for key, label, idx, count in items:
     mfma = avg(B, "SQ_INSTS_MFMA") if avg(B, "SQ_INSTS_MFMA") else (avg(B, "SQ_INSTS_VALU_MFMA_MOPS_F16") + avg(B, "SQ_INSTS_VALU_MFMA_MOPS_BF16")) / 512
     wave = avg(A, "SQ_WAVE_CYCLES")
     out.append({
-        "kernel": label, "template": f"koaf_gemm_kernel<{key}>", "us": round(t_us, 1), "clock_ghz": round(clock, 2),
+        "kernel": label, "template": key if BYNAME else f"koaf_gemm_kernel<{key}>", "us": round(t_us, 1), "clock_ghz": round(clock, 2),
         "mfma_busy_frac_at_clock": round(avg(A, "SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / (t_us * clock * 1e3), 3),
         "valu_per_mfma": round((avg(A, "SQ_INSTS_VALU") - mfma) / mfma, 2),
         "lds_per_mfma": round(avg(B, "SQ_INSTS_LDS") / mfma, 2), "vmem_rd_per_mfma": round(avg(B, "SQ_INSTS_VMEM_RD") / mfma, 3),
@@ -85,10 +89,11 @@ for key, label, idx, count in items:
         "active_inst_any": round(avg(A, "SQ_ACTIVE_INST_ANY") / wave, 3),
     })
 doc = {"command": "bash scripts/collect_sq_counters.sh <dir> [short] (two rocprofv3 --pmc passes, --kernel-trace --output-format csv, no other "
-                  "trace domain, over scripts/bench_gemm_pmc.py 20 | scripts/bench_gemm_pmc_short.py 12), reduced by scripts/sq_counters_summary.py",
+                  "trace domain, over scripts/bench_gemm_pmc.py 20 | scripts/bench_gemm_pmc_short.py 12 | scripts/bench_new_kernels_pmc.py 10), reduced by scripts/sq_counters_summary.py",
        "note": "averages over the launches of each kernel but its first two, on random operands; *_per_mfma are wave-instruction counts per matrix instruction; "
                "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (duration x clock); wait_* / active_* are shares of SQ_WAVE_CYCLES",
        "kernels": out}
-json.dump(doc, open(ROOT / "profiles" / (f"{RND}_gemm_sq_counters_short.json" if PLAN is not None else f"{RND}_gemm_sq_counters.json"), "w"), indent=1)
+fname = f"{RND}_sq_counters_new_kernels.json" if BYNAME else (f"{RND}_gemm_sq_counters_short.json" if PLAN is not None else f"{RND}_gemm_sq_counters.json")
+json.dump(doc, open(ROOT / "profiles" / fname, "w"), indent=1)
 for k in out:
     print(k)
