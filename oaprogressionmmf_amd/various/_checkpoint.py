@@ -66,18 +66,12 @@ class CheckpointHandler(object):
     def _listing(self):
         """checkpoint files of the directory, oldest first.  Age = the order this handler saved them in (the reference
         appends to its list, so the file just written is always the newest: `epoch_1000` sorts before `epoch_999` by
-        name, and a directory may hold several models / folds), files it did not write itself ordered before those by
-        (modification time, name)."""
+        name, and a directory may hold several models / folds); files it did not write itself come before those, ordered
+        by NAME exactly as the reference's `sorted(glob('*' + ext))` (:29) -- never by modification time, which a copy,
+        an artifact download or a checkout does not preserve."""
         files = [p for p in self.path_root.iterdir() if p.is_file() and p.suffix == self._suffix]
         mine = {p: i for i, p in enumerate(self._saved)}
-        def age(p):
-            if p in mine:
-                return (1, mine[p], p.name)
-            try:
-                return (0, p.stat().st_mtime_ns, p.name)
-            except OSError:
-                return (0, 0, p.name)
-        return sorted(files, key=age)
+        return sorted(files, key=lambda p: (1, mine[p], p.name) if p in mine else (0, 0, p.name))
 
     def _trim(self):
         files = self._listing()

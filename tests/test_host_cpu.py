@@ -200,6 +200,24 @@ def test_checkpoint_newest_save_is_never_the_victim(tmp_path):
     assert sorted(p.name for p in tmp_path.glob("*.pth")) == sorted([c.name, d.name]) and h2.get_last_ckpt() == d
 
 
+def test_checkpoint_resume_orders_foreign_files_by_name_not_mtime(tmp_path):
+    """a FRESH handler (resume / eval, koafusion/run/eval_prog_fus.py:161) over a directory whose modification times were
+    not preserved: the reference's sorted(glob) order decides (koafusion/various/_checkpoint.py:29,44-46) -- the newest
+    epoch by name is the last checkpoint and the older one is trimmed, whatever the mtimes say"""
+    import os
+    from oaprogressionmmf_amd.various import CheckpointHandler
+    old = tmp_path / "M__fold_0__epoch_003.pth"
+    new = tmp_path / "M__fold_0__epoch_007.pth"
+    new.write_bytes(b"n")
+    old.write_bytes(b"o")
+    os.utime(new, ns=(1_000_000_000, 1_000_000_000))          # the newer epoch carries the OLDER mtime (cp without -p, checkout)
+    os.utime(old, ns=(2_000_000_000, 2_000_000_000))
+    h = CheckpointHandler(tmp_path, num_saved=2)
+    assert h.get_last_ckpt() == new
+    h1 = CheckpointHandler(tmp_path)                            # num_saved = 1 trims from the oldest end = by name
+    assert h1.get_last_ckpt() == new and new.exists() and not old.exists()
+
+
 def test_adamw_takes_capturable():
     from oaprogressionmmf_amd.various import dict_optimizers
     p = torch.nn.Parameter(torch.zeros(3))
