@@ -10,8 +10,12 @@
 They are built from the reference's own blocks only (trunks, FeaT, FeatC1) and follow its naming scheme
 (`_fe{i}` / `_fe{i}_drop` by input position, `_agg_{i}` per MRI, `_agg_final`), so XR1MR2C1CnnTrf state dicts
 load into the first 2 MRI slots of XR1MR3C1CnnTrf except `_fe3` (clinical there, MRI here) and `_agg_final`
-(position embedding length).  Parity: against the CPU test oracle's statement of the same definitions (tests/test_ext_gpu.py); the
-shared blocks are pinned by fixtures F2-F8, the compositions themselves have no reference to pin against."""
+(position embedding length).  Parity: the shared blocks are pinned by fixtures F2-F8; the hierarchical COMPOSITION
+(`_HierFusionC1`: lane / token order, per-MRI aggregators without cls token, `_agg_final` sizing) is pinned to the reference
+by running the generic class at its default (n_xr, n_mr) = (1, 2) on the reference's XR1MR2C1CnnTrf config against fixture F6
+(tests/test_models_gpu.py::test_generic_hierarchy_reproduces_the_reference_class; the oracle's generic statement likewise,
+tests/test_oracle_golden.py) -- XR1MR3C1CnnTrf / MR1C1CnnTrf are the same loop with another MRI count, checked against the
+oracle's statement (tests/test_ext_gpu.py).  XR1C1Cnn's concatenation has no reference class to pin against."""
 import math
 
 import torch

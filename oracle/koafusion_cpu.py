@@ -162,7 +162,7 @@ def model_spec(cfg):
         spec = trunk_spec("_fe0", fe["arch"]) + trunk_spec("_fe1", fe["arch"])
         spec += feat_spec("_agg", vs["agg_in_len"], vs["agg_in_depth"], a["depth"], a["mlp_dim"], ncls, True)
         return spec, vs
-    if name in EXT_MODELS:
+    if name in EXT_MODELS or cfg.get("ext_pattern"):
         return _ext_spec(cfg)
     # XR + MRI families: _xr1mrN.py:11-103,160-300 ; _xrNmrMcP.py:32-182
     fe = cfg["fe"]
@@ -206,7 +206,11 @@ def model_spec(cfg):
 
 
 # Extensions (no reference class; oaprogressionmmf_amd/models/_ext.py states the definitions): built from the
-# reference's blocks only, so every sub-block is pinned -- the compositions are not.  (n_xr, n_mr); XR1C1Cnn apart.
+# reference's blocks only, so every sub-block is pinned.  The hierarchical COMPOSITION is pinned too: a config carrying
+# `ext_pattern: (n_xr, n_mr)` runs this generic statement whatever its name, and at (1, 2) under the reference's
+# XR1MR2C1CnnTrf config it must reproduce fixture F6 (koafusion/models/_xrNmrMcP.py:33-264) key for key and value for
+# value (tests/test_oracle_golden.py::test_oracle_generic_hierarchy_reproduces_the_reference_class); the 3-MRI headline
+# model is the same loop run once more.  (n_xr, n_mr); XR1C1Cnn apart.
 EXT_MODELS = {"XR1C1Cnn": None, "MR1C1CnnTrf": (0, 1), "XR1MR3C1CnnTrf": (1, 3)}
 
 
@@ -220,7 +224,7 @@ def _ext_spec(cfg):
         spec = trunk_spec("_fe", arch) + _lin_spec("_fe_clin._fe.0", fe["clin"]["dim_out"], fe["clin"]["dim_in"])
         spec += _lin_spec("_agg.1", a["hidden_size"], n) + _lin_spec("_final", ncls, a["hidden_size"])
         return spec, vs
-    nx, nm = EXT_MODELS[name]
+    nx, nm = cfg.get("ext_pattern") or EXT_MODELS[name]
     n_in = nx + nm + 1
     d = OUT_CH[fe["mr"]["arch"]]
     spec = []
@@ -257,7 +261,7 @@ def _ext_forward(cfg, sd, inputs, train):
         c = F.gelu(F.linear(inputs[1], sd["_fe_clin._fe.0.weight"], sd["_fe_clin._fe.0.bias"])).flatten(1)
         h = torch.relu(F.linear(torch.cat([f, c], 1), sd["_agg.1.weight"], sd["_agg.1.bias"]))
         return F.linear(h, sd["_final.weight"], sd["_final.bias"])
-    nx, nm = EXT_MODELS[name]
+    nx, nm = cfg.get("ext_pattern") or EXT_MODELS[name]
     gap = bool((nx and fe["xr"]["with_gap"]) or fe["mr"]["with_gap"])
     toks = [_tok(trunk(inputs[i], sd, f"_fe{i}", fe["xr"]["arch"], train, gap), b) for i in range(nx)]
     for i in range(nx, nx + nm):
@@ -427,7 +431,7 @@ def forward(cfg, sd, inputs, train):
         f1 = _tok(trunk(_fold(inputs[1]), sd, "_fe1", fe["arch"], train, fe["with_gap"]), b)
         out, _, _ = feat(torch.cat([f0, f1], 1), sd, "_agg", a["depth"], a["heads"], True)
         return out.reshape(b, -1)
-    if name in EXT_MODELS:
+    if name in EXT_MODELS or cfg.get("ext_pattern"):
         return _ext_forward(cfg, sd, inputs, train)
     fe = cfg["fe"]
     gap = bool(fe["xr"]["with_gap"] or fe["mr"]["with_gap"])       # Q7

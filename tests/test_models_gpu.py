@@ -23,10 +23,10 @@ def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
-def build(cfg, dev):
+def build(cfg, dev, cls=None):
     from oaprogressionmmf_amd.config import ConfigDict
     from oaprogressionmmf_amd.models import dict_models
-    m = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None)
+    m = (cls or dict_models[cfg["name"]])(config=ConfigDict(cfg), path_weights=None)
     P.fill_state_dict(m.state_dict())
     return m.to(dev)
 
@@ -43,11 +43,11 @@ def grads_and_buffers(m):
     return out, none
 
 
-def run_case(fname, dev, adam_steps=0):
+def run_case(fname, dev, adam_steps=0, cls=None):
     from oaprogressionmmf_amd.various import dict_losses, dict_optimizers
     gold = load(fname)
     cfg, B, seed = cfg_of(gold), int(gold["B"]), int(gold["seed"])
-    m = build(cfg, dev)
+    m = build(cfg, dev, cls)
     xs = [t(a).to(dev) for a in P.model_inputs(cfg, B, seed)]
     y = t(P.make_target("target", B, seed)).to(dev)
     loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
@@ -120,6 +120,29 @@ def test_models_vs_reference(dev, fname):
 def test_full_fusion_vs_reference(dev):
     """XR1MR2C1CnnTrf (BASELINE configs 4/5 model) B=2 native shapes: eval + train step + 3 Adam steps"""
     run_case("f6_full_native_b2.npz", dev, adam_steps=3)
+
+
+def test_generic_hierarchy_reproduces_the_reference_class(dev):
+    """The class the HEADLINE model is an instance of (models/_ext.py::_HierFusionC1; XR1MR3C1CnnTrf = n_mr 3) at its default
+    (n_xr, n_mr) = (1, 2), built from the reference's XR1MR2C1CnnTrf config, against fixture F6 of the imported reference
+    (koafusion/models/_xrNmrMcP.py:33-264): identical state-dict keys / shapes / `vs`, then everything run_case holds the
+    registry class to -- eval / train logits, loss, gradient-less set, BatchNorm buffers, the gradient bars.  The generic
+    composition (lane order, token order, aggregator sizing) is thereby pinned to the reference, not to the oracle."""
+    from oaprogressionmmf_amd.config import ConfigDict
+    from oaprogressionmmf_amd.models import dict_models
+    from oaprogressionmmf_amd.models._ext import _HierFusionC1
+    assert (_HierFusionC1.n_xr, _HierFusionC1.n_mr) == (1, 2)
+    gold = load("f6_full_native_b2.npz")
+    cfg = cfg_of(gold)
+    ref = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None)
+    gen = _HierFusionC1(config=ConfigDict(cfg), path_weights=None)
+    assert [(k, tuple(v.shape), v.dtype) for k, v in gen.state_dict().items()] == \
+           [(k, tuple(v.shape), v.dtype) for k, v in ref.state_dict().items()]
+    # (`vs` names: the reference writes ONE `fe12_out_ch` for its two MRI trunks, the generic class one per trunk)
+    assert {k: v for k, v in gen.vs.items() if k in ref.vs} == {k: v for k, v in ref.vs.items() if k in gen.vs}
+    assert set(ref.vs) - set(gen.vs) == {"fe12_out_ch"} and gen.vs["fe1_out_ch"] == gen.vs["fe2_out_ch"] == ref.vs["fe12_out_ch"]
+    del ref, gen
+    run_case("f6_full_native_b2.npz", dev, cls=_HierFusionC1)
 
 
 def test_trunks_vs_reference(dev):

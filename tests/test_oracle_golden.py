@@ -18,8 +18,10 @@ def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
-def run_oracle_case(gold, adam_steps=0):
+def run_oracle_case(gold, adam_steps=0, cfg_extra=None):
     cfg = cfg_of(gold)
+    if cfg_extra:
+        cfg = dict(cfg, **cfg_extra)
     B = int(gold["B"])
     seed = int(gold["seed"])
     m = O.OracleModel(cfg, fill=P.fill_value)
@@ -97,6 +99,24 @@ def test_oracle_full_fusion():
     if steps:
         assert np.allclose(out["adam_losses"], gold["adam_losses"], rtol=1e-4)
         check_summary(out, gold, "adam:", 1e-5, "params after 3 Adam steps")
+
+
+@pytest.mark.skipif(not (GOLDEN / "f6_full_native_b2.npz").exists(), reason="fixture missing")
+def test_oracle_generic_hierarchy_reproduces_the_reference_class():
+    """The generic hierarchical statement the headline model (XR1MR3C1CnnTrf) runs, at (n_xr, n_mr) = (1, 2) under the
+    reference's own XR1MR2C1CnnTrf config, against fixture F6 from the imported reference
+    (koafusion/models/_xrNmrMcP.py:33-264): same state-dict keys and shapes, same `vs` bookkeeping, eval / train logits,
+    loss, gradient-less parameter set, gradients and BatchNorm buffers.  This pins the COMPOSITION (token order, per-MRI
+    aggregators without cls token, `_agg_final` sizing); three MRI are one more iteration of the same loop."""
+    gold = load("f6_full_native_b2.npz")
+    cfg = cfg_of(gold)
+    spec_ref, vs_ref = O.model_spec(cfg)
+    spec_gen, vs_gen = O.model_spec(dict(cfg, ext_pattern=(1, 2)))
+    assert [(k, tuple(s), d) for k, s, d in spec_gen] == [(k, tuple(s), d) for k, s, d in spec_ref]
+    # (`vs` names: the reference writes ONE `fe12_out_ch` for its two MRI trunks, the generic class one per trunk)
+    assert {k: v for k, v in vs_gen.items() if k in vs_ref} == {k: v for k, v in vs_ref.items() if k in vs_gen}
+    assert set(vs_ref) - set(vs_gen) == {"fe12_out_ch"} and vs_gen["fe1_out_ch"] == vs_gen["fe2_out_ch"] == vs_ref["fe12_out_ch"]
+    compare_case(run_oracle_case(gold, cfg_extra=dict(ext_pattern=(1, 2))), gold)
 
 
 def test_oracle_attention_feat():
