@@ -74,6 +74,10 @@ def parse_args(argv=None):
                     help="1 GPU: capture the train step into a HIP graph after 2 eager steps and replay it (run.GraphedTrainStep): "
                          "for the launch-bound small configurations (xr1cnn, xr1c1)")
     ap.add_argument("--breakdown", default="", help="write a per-shape table of the instrumented step to this file")
+    ap.add_argument("--inproc", action="store_true",
+                    help="1 GPU: run the measurement in THIS process instead of a fresh child of a GPU-free supervisor (profiler runs: "
+                         "rocprofv3 must see the measuring process itself, and a process whose GPU the profiler has initialised must "
+                         "not start children)")
     ap.add_argument("--serial", action="store_true",
                     help="one HIP stream only (no encoder lanes / wgrad side stream): kernel durations seen by a profiler "
                          "are then not inflated by co-running kernels -- the mode the roofline step always uses")
@@ -115,8 +119,11 @@ def launch_workers(n, argv, program=None, timeout_s=None):
     with tempfile.TemporaryFile(mode="w+") as out0:          # rank 0's stdout goes to a file: no pipe to fill up and block on
         for r in range(n):
             procs.append(subprocess.Popen(cmd, env=worker_env(r, n, port), stdout=out0 if r == 0 else subprocess.DEVNULL))
-        t0, bad, timed_out = time.time(), [], False
+        t0, bad, timed_out, beat = time.time(), [], False, time.time()
         while True:
+            if time.time() - beat > 60:         # (a heartbeat: the supervisor relays rank 0's line only at the end)
+                print(f"bench.py: {n} rank(s) running, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+                beat = time.time()
             rcs = [p.poll() for p in procs]
             bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
             if bad or all(rc is not None for rc in rcs):
@@ -175,6 +182,13 @@ def workload_cfg(name):
         # later (their kept activations would sit under the other encoders' layer1 rebuilds: 102 GB each).  Measured:
         # "012,01,01" peaks at 265 GB allocated / 285 reserved of the 288 -- too close; this policy leaves ~50 GB.
         return cfg, 8, "012,012,01"
+    if name == "syn3_rcs":
+        # the same model and values with the volumes in the REFERENCE's layout (B, 1, R, C, S) (koafusion/models/_xrNmrMcP.py:209-210):
+        # the slice fold is then a real strided transpose (koaf_slice_fold) inside the timed step
+        cfg, b, pol = workload_cfg("syn3")
+        cfg["fe"]["mr"]["volume_layout"] = "rcs"
+        cfg["_tensor_shapes"] = [[310, 310], [384, 384, 160], [384, 384, 160], [384, 384, 160], [16]]
+        return cfg, b, pol
     if name == "xr1c1":
         return P.cfg_xr1c1(size=350, dropout=0.5), 32, "none"
     if name == "mr1c1":
@@ -194,6 +208,8 @@ WORKLOAD_TEXT = {
                "reference's native sizes; 3-MRI registry extension of XR1MR2C1CnnTrf); random-init weights",
     "syn3": "BASELINE config 4 on BASELINE's synthetic tensors: XR 1x310x310 + 3 x MRI 1x160x384x384 (slice-major) + 9 "
             "clinical; random-init weights",
+    "syn3_rcs": "BASELINE config 4 on BASELINE's synthetic tensors with the MRI volumes in the reference's layout (B, 1, 384, 384, 160): "
+                "the slice fold of koafusion/models/_xrNmrMcP.py:209-210 is a strided transpose inside the step; random-init weights",
     "eval3": "INFERENCE pass (forward + softmax, eval mode) on the native3 shapes; random-init weights",
     "xr1c1": "BASELINE config 2: XR 1x350x350 + 9 clinical, early-fusion MLP head; random-init weights",
     "mr1c1": "BASELINE config 3: SAG-3D-DESS 1x160x384x384 + 9 clinical; random-init weights",
@@ -210,8 +226,21 @@ def algorithmic_train_gflop_per_sample(name):
             "eval3": (1280.0 + 11.3) / 3 + (32 * 4.1705 + 64 * 0.2097),
             "syn": 3 * (16.84 + 320 * 24.02 + 641 * 0.2097),
             "syn3": 3 * (16.84 + 480 * 24.02 + 963 * 0.2097),
+            "syn3_rcs": 3 * (16.84 + 480 * 24.02 + 963 * 0.2097),
             "xr1c1": 62.1 + 3 * 2 * (9 * 2048 + 2048 * 512) / 1e9,
             "mr1c1": 3 * (160 * 24.02 + 322 * 0.2097)}[name]
+
+
+def survey_ideal_bytes_per_sample(name):
+    """a perfectly fused train step moves 7 x sum(conv elements) x sizeof(fp32) per image -- forward (in + out),
+    backward (dY read twice, X read, dX write) and the BatchNorm-recompute read -- with sum(conv elements) = the mean of the
+    measured conv-input and conv-output element counts: ResNet-50 5.555 M per 160^2 slice (x 5.76 at 384^2), ResNeXt-50 34.95 M
+    at 350^2 (scaled by area).  None where the survey gives no figure."""
+    r50_160, rx_350 = 0.5 * (5.44e6 + 5.67e6), 0.5 * (34.4e6 + 35.5e6)
+    per = {"syn3": 480 * r50_160 * 5.76 + rx_350 * (310 / 350.0) ** 2, "syn": 320 * r50_160 * 5.76 + rx_350 * (310 / 350.0) ** 2,
+           "native": 89 * r50_160 + rx_350, "native3": 121 * r50_160 + rx_350, "xr1cnn": rx_350, "xr1c1": rx_350,
+           "mr1": 64 * r50_160, "mr1c1": 160 * r50_160 * 5.76}.get(name)
+    return None if per is None else 7.0 * 4.0 * per
 
 
 def apply_recompute(model, policy):
@@ -394,6 +423,7 @@ def main(args):
 
     comm_ms = []
     jobs_ddp = []
+    rank_dt = []          # wall time of the last timed() region on every rank (N > 1)
 
     job_state = {}
 
@@ -416,7 +446,13 @@ def main(args):
         jobs_ddp.append(ddp)
         loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
         opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=bool(args.graph))
-        xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(dict(cfg, input_size=shapes) if shapes else cfg, B, seed=1234 + rank)]
+        if name == "syn3_rcs":
+            # the SAME values as syn3's slice-major volumes, laid out as the reference's (B, 1, R, C, S) tensors
+            ncd = [[310, 310]] + [[160, 384, 384]] * 3 + [[16]]
+            xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(dict(cfg, input_size=ncd), B, seed=1234 + rank)]
+            xs = [x.permute(0, 1, 3, 4, 2).contiguous() if x.dim() == 5 else x for x in xs]
+        else:
+            xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(dict(cfg, input_size=shapes) if shapes else cfg, B, seed=1234 + rank)]
         y = torch.from_numpy(P.make_target("target", B, seed=1234 + rank)).to(dev)
         job_state.update(xs=xs, y=y, loss_fn=loss_fn)
         model.train()
@@ -467,9 +503,11 @@ def main(args):
         dt = time.perf_counter() - t0
         per = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
         if dist_on:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            dt = float(tt.item())
+            mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(allr, mine)
+            rank_dt[:] = [float(t.item()) for t in allr]
+            dt = max(rank_dt)               # the job's time is the slowest rank's
         return dt, lv, per
 
     def free(*objs):
@@ -487,12 +525,16 @@ def main(args):
     cfg, B, policy, step = make_job(args.workload, args.batch, args.recompute)
     torch.cuda.reset_peak_memory_stats()
     dt, lv, per = timed(step, args.warmup, args.steps)
+    per_rank_ms = [round(t / args.steps * 1e3, 2) for t in rank_dt] if rank_dt else None
     hbm_gb = (round(torch.cuda.max_memory_allocated() / 2**30, 1), round(torch.cuda.max_memory_reserved() / 2**30, 1))
-    comm_exposed = None
+    comm_exposed, comm_exposed_ranks = None, None
     if dist_on:
         comm_ms = jobs_ddp[0].exposed_ms()
-        if comm_ms:
-            comm_exposed = round(statistics.mean(comm_ms), 3)
+        mine = torch.tensor([statistics.mean(comm_ms) if comm_ms else 0.0], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        comm_exposed_ranks = [round(float(t.item()), 3) for t in allr]
+        comm_exposed = max(comm_exposed_ranks)           # (the slowest rank's: what the step pays)
 
     if args.graph:
         if rank == 0:
@@ -519,7 +561,11 @@ def main(args):
     gemm_flop = sum(p[1] for p in prof)
     gemm_bytes = sum(p[4] for p in prof)
     n_launch = len(prof)
-    achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    achieved_exec = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    # ALGORITHMIC work of the step (per-sample figure x the samples one step processes) over the measured duration of
+    # the dominant kernel family: recomputed forward stages are time spent, not work done
+    algo_flop = algorithmic_train_gflop_per_sample(args.workload) * 1e9 * B
+    achieved = algo_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
 
     def call_peak(mpp):
         return BF16_MFMA_PEAK_TFLOPS / mpp
@@ -560,6 +606,16 @@ def main(args):
                 break
         except (ValueError, KeyError):
             pass
+
+    traffic_vs_ideal = None
+    ideal_b = survey_ideal_bytes_per_sample(args.workload)
+    if traffic_step and ideal_b:
+        moved = traffic_step.get("bytes_per_step", 0) + traffic_step.get("act_planes_bytes_per_step", 0)
+        traffic_vs_ideal = {"ratio": round(moved / (ideal_b * B), 3), "survey_ideal_bytes_per_step": int(ideal_b * B),
+                            "pmc_bytes_per_step": int(moved),
+                            "ideal_is": "SURVEY 8(d): 7 x sum(conv elements) x 4 B per image (every tensor of a perfectly fused step once: "
+                                        "forward in + out, backward dY twice, X, dX, one BatchNorm-recompute read), x the images of the "
+                                        "batch; pmc = GEMM-family launches + plane-image pre-passes of the committed PMC summary"}
 
     def one_step_outputs(perturb=False):
         """eval logits, train logits / loss and the flat gradient arena of ONE forward + backward of the current job's model on
@@ -660,6 +716,34 @@ def main(args):
             job_state.clear()
             free()
         try:
+            # the reference's tensor layout (B, 1, R, C, S): the slice-fold kernel inside the timed step (5 steps)
+            cfgr, Br, polr, stepr = make_job("syn3_rcs", 0)
+            dtr, lvr, perr = timed(stepr, 2, 5)
+            xv = job_state["xs"][1]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ops.slice_fold(xv, Br, 384, 384, 160)
+            e0.record()
+            for _ in range(5):
+                ops.slice_fold(xv, Br, 384, 384, 160)
+            e1.record()
+            torch.cuda.synchronize()
+            fold_ms = e0.elapsed_time(e1) / 5
+            secondary["syn3_rcs"] = {"model": cfgr["name"], "value": round(world * Br * 5 / dtr, 3), "unit": "knees/s",
+                                     "ms_per_step": round(dtr / 5 * 1e3, 2), "ms_per_step_median": round(statistics.median(perr), 2),
+                                     "steps": 5, "warmup": 2, "per_gpu_batch": Br, "activation_recompute": polr, "last_loss": round(lvr, 6),
+                                     "slice_fold": {"ms_per_volume_batch": round(fold_ms, 3), "calls_per_step": 3,
+                                                    "tb_per_s": round(2 * xv.numel() * 4 / (fold_ms * 1e-3) / 1e12, 2),
+                                                    "what": "koaf_slice_fold of one (8, 1, 384, 384, 160) fp32 volume batch: read + write "
+                                                            "755 MB each (koafusion/models/_xrNmrMcP.py:209-210)"},
+                                     "workload": WORKLOAD_TEXT["syn3_rcs"]}
+            del stepr, xv
+            job_state.clear()
+            free()
+        except Exception as e:  # noqa: BLE001
+            secondary["syn3_rcs"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            job_state.clear()
+            free()
+        try:
             pr = storage_pair("xr1c1", 20, 5, None)
             secondary["xr1c1"] = dict(pr["fp32"], per_gpu_batch=32, workload=WORKLOAD_TEXT["xr1c1"] + " (fp32 mode)")
             secondary["xr1c1_bf16"] = dict(pr["bf16"], workload=WORKLOAD_TEXT["xr1c1"] + "; bf16 activation storage = the configuration "
@@ -706,8 +790,11 @@ def main(args):
                                                          "retried once in a fresh process)" if os.environ.get("KOAF_BENCH_OOM_RETRY") else ""),
                        "hbm_peak_gib": {"allocated": hbm_gb[0], "reserved": hbm_gb[1]}},
             "rccl_ranks": rccl_ranks, "comm_exposed_ms": comm_exposed,
+            "per_rank": {"ms_per_step": per_rank_ms, "comm_exposed_ms": comm_exposed_ranks} if dist_on else None,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak_mix, 1),
-                         "unit": "TFLOP/s", "frac": round(achieved / peak_mix, 4), "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak_mix, 4),
+                         "achieved_executed": round(achieved_exec, 2), "frac_executed": round(achieved_exec / peak_mix, 4),
+                         "traffic": traffic,
                          "traffic_unit": "bytes per GEMM-family kernel launch (average)", "traffic_source": traffic_src,
                          "traffic_per_step": traffic_step,
                          "kernel": "koaf_gemm_kernel + wgrad3x3_ring_kernel (implicit GEMM: conv fwd/dgrad/wgrad, linear, attention; fp32 in/out/accumulate; "
@@ -717,10 +804,13 @@ def main(args):
                          "peak_is": "2.5 PFLOP/s dense 16-bit MFMA / MFMAs per product, FLOP-weighted harmonic mean over the step's calls "
                                     f"({100 * f16_share:.0f} % of the executed FLOPs on the 3-MFMA scheme at 833.3, the rest at 416.7 TFLOP/s "
                                     "fp32-equivalent)",
-                         "achieved_is": "algorithmic FLOPs the step's GEMM-family calls execute (recomputed forward stages included) / "
-                                        "their event-timed durations on the launch stream (one instrumented single-stream step)",
+                         "achieved_is": "ALGORITHMIC FLOPs of the step (SURVEY 8(d): step_gflop_per_sample_survey x the per-GPU batch) / the "
+                                        "event-timed durations of the step's GEMM-family calls on the launch stream (one instrumented "
+                                        "single-stream step); achieved_executed / frac_executed count what the calls execute instead "
+                                        "(recomputed forward stages included)",
                          "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
                          "achieved_over_fp32_mfma_peak": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                         "traffic_vs_survey_ideal": traffic_vs_ideal,
                          "floor_ms_per_step": round(floor_ms, 2), "frac_of_floor": round(floor_ms / gemm_ms, 4) if gemm_ms > 0 else None,
                          "hbm_bound_share_of_kernel_ms": round(hbm_ms / gemm_ms, 4) if gemm_ms > 0 else None,
                          "floor_is": "sum over the step's calls of max(FLOP / matrix-pipe bound of the call, algorithmic bytes / 8 TB/s): "
@@ -786,7 +876,11 @@ def launch_with_fallback(args, argv, program=None):
 
 if __name__ == "__main__":
     _args = parse_args()
-    if _args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if "WORLD_SIZE" not in os.environ and not _args.inproc:
+        # No launcher: this process is a GPU-free SUPERVISOR for every N, 1 included -- it starts the N measuring ranks as fresh
+        # children, relays rank 0's line, and on an out-of-memory exit of the headline's default policy starts ONE more set with
+        # the leaner policy only after the first set has exited (nothing of the failed run is left on the device, so the
+        # retry's headroom and its reported hbm_peak_gib are those of a clean run).
         sys.exit(launch_with_fallback(_args, sys.argv[1:]))
     try:
         main(_args)
@@ -795,14 +889,4 @@ if __name__ == "__main__":
         if not is_oom(_e):
             raise
         print(f"bench.py: out of memory: {str(_e)[:300]}", file=sys.stderr)
-        if "WORLD_SIZE" in os.environ or not fallback_allowed(_args):
-            sys.exit(OOM_EXIT)          # (a rank of a launcher: the parent decides; its peers are torn down)
-    # 1 GPU, default policy: ONE retry with the leaner policy in a FRESH child process (this process only frees what it holds
-    # and waits; it is never re-executed), named in config.activation_recompute of the child's line
-    import gc
-    import torch
-    gc.collect()
-    torch.cuda.empty_cache()
-    print(f"bench.py: retrying once with --recompute {FALLBACK_POLICY} in a fresh process", file=sys.stderr)
-    _env = dict(os.environ, KOAF_BENCH_OOM_RETRY="1")
-    sys.exit(subprocess.call([sys.executable, str(Path(__file__).resolve())] + fallback_argv(sys.argv[1:]), env=_env))
+        sys.exit(OOM_EXIT)              # (a rank: the supervisor / launcher decides; with --inproc there is no retry)

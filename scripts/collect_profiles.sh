@@ -10,14 +10,14 @@ cd /tmp
 if [ -z "$ONLY_PMC" ]; then      # (ONLY_PMC=1: just the two counter passes, into a directory that already holds the rest)
 python3 $GRAFT_REPO_ROOT/bench.py "$@" --breakdown $OUT/breakdown.txt > $OUT/bench.log 2> $OUT/bench.err || exit 1
 echo "bench done" > $OUT/progress
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -o s -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --serial --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/serial.log 2>&1 || exit 2
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s -o s -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --inproc --serial --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/serial.log 2>&1 || exit 2
 find /tmp/prof_s -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 echo "trace done" >> $OUT/progress
 fi
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_f -o f -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --serial --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/pmc_fetch.log 2>&1 || exit 3
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_f -o f -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --inproc --serial --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/pmc_fetch.log 2>&1 || exit 3
 find /tmp/prof_f -name "*counter_collection.csv" -exec cp {} $OUT/fetch_counter_collection.csv \;
 echo "fetch done" >> $OUT/progress
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_w -o w -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --serial --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/pmc_write.log 2>&1 || exit 4
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_w -o w -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --inproc --serial --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/pmc_write.log 2>&1 || exit 4
 find /tmp/prof_w -name "*counter_collection.csv" -exec cp {} $OUT/write_counter_collection.csv \;
 echo "write done" >> $OUT/progress
 # keep only the per-dispatch counter rows of the GEMM kernel (the merged-back directory is capped at 64 MiB)

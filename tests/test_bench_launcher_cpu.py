@@ -92,3 +92,28 @@ def test_worker_env_and_defaults():
     assert a.gpus == 1 and a.workload == "syn3" and a.steps >= 20 and a.warmup >= 5
     cfg, B, pol = bench.workload_cfg("syn3")
     assert B == 8 and cfg["_tensor_shapes"][1] == [160, 384, 384] and cfg["fe"]["mr"]["volume_layout"] == "ncdhw"
+
+
+OOM1 = """
+import json, os, sys
+assert os.environ["WORLD_SIZE"] == "1" and os.environ["RANK"] == "0"
+if "--recompute" not in sys.argv:
+    sys.exit(42)                                   # the single rank runs out of memory on the default policy
+assert os.environ.get("KOAF_BENCH_OOM_RETRY") == "1"
+print(json.dumps({"argv": sys.argv[1:]}))
+"""
+
+
+def test_one_gpu_runs_under_the_gpu_free_supervisor_too(tmp_path, capfd):
+    """N = 1 takes the same path as N > 1: the measuring process is a fresh child, and the out-of-memory retry starts only
+    after that child has exited (nothing of the failed run stays on the device)"""
+    import bench
+    stub = tmp_path / "oom1.py"
+    stub.write_text(OOM1)
+    args = bench.parse_args([])
+    assert args.gpus == 1 and not args.inproc
+    rc = bench.launch_with_fallback(args, [], program=str(stub))
+    cap = capfd.readouterr()
+    assert rc == 0 and json.loads(cap.out.strip().splitlines()[-1])["argv"] == ["--recompute", bench.FALLBACK_POLICY]
+    src = (ROOT / "bench.py").read_text()
+    assert 'if "WORLD_SIZE" not in os.environ and not _args.inproc:' in src
