@@ -98,33 +98,65 @@ class ResNet(nn.Module):
         raise RuntimeError("koaf ResNet is a parameter container; build a KoafTrunk from its children")
 
 
-def _no_pretrained(pretrained, name):
-    if pretrained:
-        raise RuntimeError(
-            f"{name}(pretrained=True) needs a download (koafusion/models/_torchvision.py:258-261); there is no "
-            f"network here -- construct with pretrained=False and load a state_dict")
+# the ImageNet checkpoints the reference downloads (koafusion/models/_torchvision.py:12-20; torchvision's own resnet18/34/50 with
+# `pretrained=True`, which the MRI trunks go through, fetch the same files)
+model_urls = {
+    "resnet18": "https://download.pytorch.org/models/resnet18-f37072fd.pth",
+    "resnet34": "https://download.pytorch.org/models/resnet34-b627a593.pth",
+    "resnet50": "https://download.pytorch.org/models/resnet50-0676ba61.pth",
+    "resnext50_32x4d": "https://download.pytorch.org/models/resnext50_32x4d-7cdf4587.pth",
+}
+
+
+def pretrained_candidates(arch):
+    """where `pretrained=True` looks for the checkpoint of `arch`, in order: $KOAF_PRETRAINED_DIR/<file>, then the file
+    torch.hub would have cached for the reference's `load_state_dict_from_url(model_urls[arch])`
+    (<torch.hub.get_dir()>/checkpoints/<file>, i.e. $TORCH_HOME/hub/checkpoints)"""
+    import os
+    from pathlib import Path
+    fname = model_urls[arch].rsplit("/", 1)[-1]
+    out = []
+    if os.environ.get("KOAF_PRETRAINED_DIR"):
+        out.append(Path(os.environ["KOAF_PRETRAINED_DIR"]) / fname)
+    out.append(Path(torch.hub.get_dir()) / "checkpoints" / fname)
+    return out
+
+
+def _load_pretrained(model, arch):
+    """`pretrained=True` (koafusion/models/_torchvision.py:249-261: load_state_dict_from_url + load_state_dict) without a network:
+    the checkpoint file is taken from the local torch-hub cache or $KOAF_PRETRAINED_DIR; the keys (fc included) are the
+    reference's, so it loads strictly.  Absent file: RuntimeError naming the paths -- nothing is downloaded."""
+    for path in pretrained_candidates(arch):
+        if path.is_file():
+            model.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+            return model
+    raise RuntimeError(
+        f"{arch}(pretrained=True): the reference downloads {model_urls[arch]} (koafusion/models/_torchvision.py:258-261); there is "
+        f"no network here and none of {[str(p) for p in pretrained_candidates(arch)]} exists -- place the file there (torch-hub cache "
+        f"or $KOAF_PRETRAINED_DIR), or construct with pretrained=False and load a state_dict")
+
+
+def _resnet(arch, block, layers, pretrained, **kw):
+    model = ResNet(block, layers, **kw)
+    return _load_pretrained(model, arch) if pretrained else model
 
 
 def resnet18(pretrained=False, progress=True, **kw):
-    _no_pretrained(pretrained, "resnet18")
-    return ResNet(BasicBlock, [2, 2, 2, 2], **kw)
+    return _resnet("resnet18", BasicBlock, [2, 2, 2, 2], pretrained, **kw)
 
 
 def resnet34(pretrained=False, progress=True, **kw):
-    _no_pretrained(pretrained, "resnet34")
-    return ResNet(BasicBlock, [3, 4, 6, 3], **kw)
+    return _resnet("resnet34", BasicBlock, [3, 4, 6, 3], pretrained, **kw)
 
 
 def resnet50(pretrained=False, progress=True, **kw):
-    _no_pretrained(pretrained, "resnet50")
-    return ResNet(Bottleneck, [3, 4, 6, 3], **kw)
+    return _resnet("resnet50", Bottleneck, [3, 4, 6, 3], pretrained, **kw)
 
 
 def resnext50_32x4d(pretrained=False, progress=True, **kw):
-    _no_pretrained(pretrained, "resnext50_32x4d")
     kw["groups"] = 32
     kw["width_per_group"] = 4
-    return ResNet(Bottleneck, [3, 4, 6, 3], **kw)
+    return _resnet("resnext50_32x4d", Bottleneck, [3, 4, 6, 3], pretrained, **kw)
 
 
 def _unsupported(name):

@@ -337,6 +337,44 @@ def test_bench_workloads_are_constructible():
         bench.workload_cfg("nope")
 
 
+def test_pretrained_encoders_load_from_the_local_hub_cache(tmp_path, monkeypatch):
+    """`fe.*.pretrained: true` -- what every shipped reference recipe sets (runner.sh:94,116,..., conf/model/*.yaml) -- resolves
+    the file the reference's load_state_dict_from_url would have cached (koafusion/models/_torchvision.py:249-261) instead of a
+    download: $KOAF_PRETRAINED_DIR or <TORCH_HOME>/hub/checkpoints; strict load (the keys incl. `fc` are the reference's);
+    absent file = RuntimeError, never a silent random init"""
+    from oaprogressionmmf_amd.config import load_model_config
+    from oaprogressionmmf_amd.models import dict_models
+    from oaprogressionmmf_amd.models._core_fes import dict_fes, model_urls, pretrained_candidates
+    monkeypatch.delenv("KOAF_PRETRAINED_DIR", raising=False)
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "th"))
+    with pytest.raises(RuntimeError, match="resnet18-f37072fd.pth"):
+        dict_fes["resnet18"](pretrained=True)
+    # a stand-in "ImageNet" checkpoint with the reference's key set (values by key name)
+    def ckpt(arch):
+        sd = dict_fes[arch](pretrained=False).state_dict()
+        return {k: torch.from_numpy(P.fill_value(k, tuple(v.shape), v.dtype == torch.int64)).to(v.dtype).reshape(v.shape) for k, v in sd.items()}
+    hub = tmp_path / "th" / "hub" / "checkpoints"
+    hub.mkdir(parents=True)
+    sd18 = ckpt("resnet18")
+    torch.save(sd18, hub / "resnet18-f37072fd.pth")
+    assert pretrained_candidates("resnet18")[-1] == hub / "resnet18-f37072fd.pth"
+    m = dict_fes["resnet18"](pretrained=True)
+    assert all(torch.equal(v, sd18[k]) for k, v in m.state_dict().items()) and "fc.weight" in sd18
+    # $KOAF_PRETRAINED_DIR wins over the hub cache; a whole registry model built from a config with pretrained: true
+    other = tmp_path / "ckpts"
+    other.mkdir()
+    sd18b = {k: (v + 1 if v.dtype.is_floating_point else v) for k, v in sd18.items()}
+    torch.save(sd18b, other / "resnet18-f37072fd.pth")
+    monkeypatch.setenv("KOAF_PRETRAINED_DIR", str(other))
+    cfg = load_model_config("xr1_cnn", **{"fe.arch": "resnet18", "fe.pretrained": True})
+    model = dict_models["XR1Cnn"](config=cfg, path_weights=None)
+    got = model.state_dict()
+    assert torch.equal(got["_fe.0.weight"], sd18b["conv1.weight"]) and torch.equal(got["_fe.4.0.bn1.running_var"], sd18b["layer1.0.bn1.running_var"])
+    assert set(model_urls) == {"resnet18", "resnet34", "resnet50", "resnext50_32x4d"}
+    with pytest.raises(RuntimeError, match="resnet50-0676ba61.pth"):        # the MRI trunks' file is still absent
+        dict_fes["resnet50"](pretrained=True)
+
+
 def test_model_config_groups_load():
     """every conf/model/*.yaml names a registry model and carries the keys its constructor reads"""
     from oaprogressionmmf_amd.config import CONF_DIR, load_model_config
