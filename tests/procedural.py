@@ -52,11 +52,42 @@ def _fill_value(key, shape, is_int=False):
     return r.uniform(-a, a, size=shape).astype(np.float32)
 
 
-def fill_state_dict(sd):
-    """In-place fill of a torch state_dict (values must be tensors) -- returns sd."""
+def imagenet_like_fill(key, shape, is_int=False):
+    """Deterministic "ImageNet-checkpoint-like" value for state_dict entry `key`: the parameter DISTRIBUTION of a trained
+    torchvision ResNet rather than a fresh init -- the real files cannot travel (no network), and the fixtures' gentle fill
+    (BatchNorm scale 1 +- 0.1, variance 0.5 .. 1.5) says nothing about the fp16-piece scheme's fixed activation scale on such
+    weights.  BatchNorm scale log-uniform over 1e-3 .. 3 with a few exact zeros and a few negative entries (trained nets prune
+    channels this way), bias N(0, 0.3), running variance log-uniform over 1e-4 .. 10, running mean N(0, 0.5) * sqrt(var);
+    convolution weights heavy-tailed (Student-t, 4 degrees of freedom) with a per-layer gain spread over two decades."""
+    shape = tuple(shape)
+    if is_int or key.endswith("num_batches_tracked"):
+        return np.zeros(shape, dtype=np.int64)
+    r = _rng("imagenet:" + key)
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "running_var":
+        return np.exp(r.uniform(np.log(1e-4), np.log(10.0), size=shape)).astype(np.float32)
+    if leaf == "running_mean":
+        var = np.exp(_rng("imagenet:" + key[:-len("running_mean")] + "running_var").uniform(np.log(1e-4), np.log(10.0), size=shape))
+        return (r.standard_normal(size=shape) * 0.5 * np.sqrt(var)).astype(np.float32)
+    if len(shape) == 1:
+        if leaf == "weight":
+            g = np.exp(r.uniform(np.log(1e-3), np.log(3.0), size=shape))
+            u = r.uniform(size=shape)
+            g = np.where(u < 0.04, 0.0, np.where(u < 0.09, -g, g))
+            return g.astype(np.float32)
+        return (0.3 * r.standard_normal(size=shape)).astype(np.float32)
+    fan_in = int(np.prod(shape[1:]))
+    gain = 10.0 ** r.uniform(-1.5, 0.5)
+    w = r.standard_t(4, size=shape) / np.sqrt(2.0)          # (variance of t_4 is 2)
+    return (gain * np.sqrt(2.0 / fan_in) * w).astype(np.float32)
+
+
+def fill_state_dict(sd, fill=None):
+    """In-place fill of a torch state_dict (values must be tensors) -- returns sd.  fill: fill_value (default) or another
+    `(key, shape, is_int) -> ndarray` law, e.g. imagenet_like_fill"""
     import torch
     for k, v in sd.items():
-        arr = fill_value(k, v.shape, is_int=not v.dtype.is_floating_point)
+        arr = (fill or fill_value)(k, v.shape, is_int=not v.dtype.is_floating_point)
         v.copy_(torch.from_numpy(arr).to(v.dtype).reshape(v.shape))
     return sd
 
