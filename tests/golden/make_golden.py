@@ -297,6 +297,97 @@ def case_f2_bottleneck(tv, **_):
     print(f"  wrote f2_bottleneck.npz ({(HERE / 'f2_bottleneck.npz').stat().st_size / 1024:.0f} KiB)")
 
 
+F2B_SIZES = (("small", (2, 8, 8)), ("large", (4, 48, 48)))
+
+
+def case_f2b_stage(tv, **_):
+    """F2b: ResNet-50 `layer1` of the reference (three Bottlenecks, the first with its downsample branch: _torchvision.py:83-138,
+    192-215) in train mode, forward + backward -- the rung between F2 (one block, element-wise) and F3 / F14 (whole trunks, at
+    branch-noise level).  Two sizes:
+      small (2, 64, 8, 8): EVERY tensor in full (output, dx, every parameter gradient, BatchNorm buffers), with an input seed
+        such that no ReLU input of the float64 run lies within 1e-5 of zero -- element-wise bars are meaningful only where no
+        mask can flip at fp32 rounding level, and the nine ReLU layers see 1152 values per pixel: 147 k values here (a
+        (4, 64, 48, 48) input has 10.6 M of them, ~170 of which sit within 2e-5 of zero whatever the seed);
+      large (4, 64, 48, 48): the forward output (every 29th element: flips move it by <= 1e-6), BatchNorm buffers in full, and
+        per-tensor gradient norms + samples with the reference's own float32-vs-float64 noise beside them (e32), for the
+        multi-tile paths of the same kernels."""
+    out = {"torch_version": np.array(torch.__version__)}
+
+    def build(dt=torch.float32):
+        torch.manual_seed(0)
+        layer = tv.resnet50().layer1
+        P.fill_state_dict(layer.state_dict())
+        return layer.to(dt)
+
+    def margin_of(layer, x):
+        m = float("inf")
+        for blk in layer:
+            a1 = blk.bn1(blk.conv1(x))
+            a2 = blk.bn2(blk.conv2(torch.relu(a1)))
+            a3 = blk.bn3(blk.conv3(torch.relu(a2))) + (blk.downsample(x) if blk.downsample is not None else x)
+            m = min(m, float(a1.abs().min()), float(a2.abs().min()), float(a3.abs().min()))
+            x = torch.relu(a3)
+        return m
+    for tag, (N, H, W) in F2B_SIZES:
+        seed, margin = 0, None
+        if tag == "small":
+            seed = None
+            for cand in range(400):
+                x64 = torch.relu(t(P.make_input("f2bx_" + tag, (N, 64, H, W), seed=cand))).double()
+                with torch.no_grad():
+                    margin = margin_of(build(torch.float64).train(), x64)
+                if margin > 1e-5:
+                    seed = cand
+                    break
+            assert seed is not None
+        x = torch.relu(t(P.make_input("f2bx_" + tag, (N, 64, H, W), seed=seed)))
+        res = {}
+        for dt in (torch.float32, torch.float64):
+            layer = build(dt).train()
+            xi = x.to(dt).clone().requires_grad_(True)
+            y = layer(xi + 0)
+            g = t(P.make_input("f2bg_" + tag, tuple(y.shape), seed=seed)).to(dt)
+            (y * g).sum().backward()
+            res[dt] = (y.detach(), xi.grad.detach(), {k: p.grad.detach() for k, p in layer.named_parameters()},
+                       {k: v.detach().clone() for k, v in layer.named_buffers()})
+        y32, dx32, g32, buf32 = res[torch.float32]
+        y64, dx64, g64, _ = res[torch.float64]
+        out[tag + ":seed"] = np.int64(seed)
+        out[tag + ":shape"] = np.array([N, 64, H, W])
+        keys = sorted(g32)
+        out[tag + ":e32_keys"] = np.array(keys)
+        for k, v in buf32.items():
+            out[tag + ":buf:" + k] = v.numpy()
+        if tag == "small":
+            out[tag + ":relu_margin64"] = np.float64(margin)
+            out[tag + ":train"] = y32.numpy()
+            out[tag + ":dx"] = dx32.numpy()
+            for k, v in g32.items():
+                out[tag + ":grad:" + k] = v.numpy()
+            e32 = [float((g32[k].double() - g64[k]).abs().max() / g64[k].abs().max()) for k in keys]
+            out[tag + ":e32_vals"] = np.array(e32)
+            out[tag + ":e32_out_dx"] = np.array([float((y32.double() - y64).abs().max() / y64.abs().max()),
+                                                 float((dx32.double() - dx64).abs().max() / dx64.abs().max())])
+            print(f"  {tag}: seed {seed}, ReLU margin {margin:.2e}, reference fp32 vs fp64 (max-norm): out {out[tag + ':e32_out_dx'][0]:.1e} "
+                  f"dx {out[tag + ':e32_out_dx'][1]:.1e} worst grad {max(e32):.1e}")
+        else:
+            out[tag + ":train_s29"] = y32.numpy().reshape(-1)[::29].copy()
+            out[tag + ":train64_s29"] = y64.numpy().reshape(-1)[::29].copy()
+            named = {"dx": dx32.numpy()}
+            named.update({"grad:" + k: v.numpy() for k, v in g32.items()})
+            out.update({tag + ":" + k: v for k, v in P.summarize_tensors(named, k=32).items()})
+            named64 = {"dx": dx64.numpy()}
+            named64.update({"grad:" + k: v.numpy() for k, v in g64.items()})
+            out.update({tag + ":f64:" + k: v for k, v in P.summarize_tensors(named64, k=32).items()})
+            e32 = [_rel(g32[k], g64[k]) for k in keys]
+            out[tag + ":e32_vals"] = np.array(e32)           # relative L2 here
+            out[tag + ":e32_dx"] = np.float64(_rel(dx32, dx64))
+            print(f"  {tag}: reference fp32 vs fp64 (L2): out {_rel(y32, y64):.1e} dx {_rel(dx32, dx64):.1e} grads median "
+                  f"{np.median(e32):.1e} worst {max(e32):.1e}")
+    np.savez_compressed(HERE / "f2b_layer1.npz", **out)
+    print(f"  wrote f2b_layer1.npz ({(HERE / 'f2b_layer1.npz').stat().st_size / 1024:.0f} KiB)")
+
+
 def case_f3_trunk(tv, **_):
     out = {}
     for arch, shape in (("resnet50", (4, 1, 160, 160)), ("resnet50", (2, 1, 96, 112)), ("resnext50_32x4d", (2, 1, 130, 130)),
@@ -577,7 +668,7 @@ def case_f14_fullsize(km, tv, losses, **_):
 
 
 CASES = {
-    "f1": case_f1_attention_feat, "f2": case_f2_bottleneck, "f3": case_f3_trunk, "f4": case_f4_xr1cnn,
+    "f1": case_f1_attention_feat, "f2": case_f2_bottleneck, "f2b": case_f2b_stage, "f3": case_f3_trunk, "f4": case_f4_xr1cnn,
     "f5": case_f5_mr, "f5g": case_f5_nogap, "f6": case_f6_full, "f7": case_f7_focal, "f8": case_f8_interp, "f9": case_f9_sched,
     "f11": case_f11_bookkeeping, "f12": case_f12_augment, "f13": case_f13_modal_abl, "f14": case_f14_fullsize,
 }

@@ -71,3 +71,112 @@ def test_bottleneck_f2_elementwise(dev, case):
           f"reference fp32 vs its fp64: out/dx {g[tag + ':e32_out_dx'].tolist()}, worst gradient {float(g[tag + ':e32_vals'].max()):.1e}")
     bad = {k: v for k, v in errs.items() if not v < 1e-5}
     assert not bad, bad
+
+
+def _layer1(dev):
+    from oaprogressionmmf_amd.arena import get_arena
+    from oaprogressionmmf_amd.models._core_fes import dict_fes
+    layer = dict_fes["resnet50"](pretrained=False).layer1        # children named as the reference's: 0.conv1.weight, 0.downsample.0.weight, ...
+    P.fill_state_dict(layer.state_dict())
+    layer = layer.to(dev)
+    get_arena(layer)
+    return layer
+
+
+def _run_layer1(layer, xh, gy_of, N, H, W, rebuild):
+    """train-mode forward + backward of the stage through the product's own stage functions; rebuild: the activation-recompute
+    path (only the stage input and the BatchNorm statistics survive the forward; the stage is rebuilt before its backward)"""
+    from oaprogressionmmf_amd.models._encoder import EncoderFn, _blocks_fwd
+    blocks = list(layer.children())
+    recs, y, Ho, Wo, _ = _blocks_fwd(blocks, xh, N, H, W, True, slim=rebuild)
+    yout = y.clone()
+    if rebuild:
+        stats = [(r.s1, r.s2, r.s3, r.sd) for r in recs]
+        del recs
+        recs, y2, _, _, _ = _blocks_fwd(blocks, xh, N, H, W, True, givens=stats)
+        assert torch.equal(y2, yout), "rebuilt stage output"
+    dy = gy_of(yout)
+    dx = EncoderFn._blocks_bwd(recs, dy, None)
+    torch.cuda.synchronize()
+    return yout, dx
+
+
+@pytest.mark.parametrize("rebuild", [False, True], ids=["stored", "rebuilt"])
+def test_layer1_f2b_elementwise(dev, rebuild):
+    """fixture F2b, small: ResNet-50 layer1 of the imported reference (three Bottlenecks, the first with its downsample branch:
+    koafusion/models/_torchvision.py:83-138,192-215), train-mode forward + backward, EVERY tensor element-wise at 1e-5 of its
+    largest magnitude -- with the bottleneck tails formed in the next conv1's loader, the BatchNorm-backward reductions in the
+    dgrad epilogues, the applies in the loaders / plane-image cuts, the halo forward / data gradient, the ring weight gradient,
+    and (rebuilt) the activation-recompute path all active as in the full step.  The input seed keeps every ReLU input of the
+    float64 run 3.7e-5 from zero (recorded), so no mask flips at fp32 rounding level."""
+    g = load("f2b_layer1.npz")
+    N, C, H, W = (int(v) for v in g["small:shape"])
+    seed = int(g["small:seed"])
+    layer = _layer1(dev)
+    x = torch.relu(torch.from_numpy(P.make_input("f2bx_small", (N, C, H, W), seed=seed))).to(dev)
+    xh = x.permute(0, 2, 3, 1).contiguous()
+
+    def gy_of(y):
+        gy = torch.from_numpy(P.make_input("f2bg_small", (N, 256, H, W), seed=seed)).to(dev)
+        return gy.permute(0, 2, 3, 1).contiguous().view(y.shape)
+    with torch.no_grad():
+        y, dx = _run_layer1(layer, xh, gy_of, N, H, W, rebuild)
+    errs = {"out": mx(y.view(N, H, W, 256).permute(0, 3, 1, 2).cpu().numpy(), g["small:train"]),
+            "dx": mx(dx.view(N, H, W, C).permute(0, 3, 1, 2).cpu().numpy(), g["small:dx"])}
+    for k, p in layer.named_parameters():
+        assert p.grad is not None, k
+        errs["grad:" + k] = mx(p.grad.detach().cpu().numpy(), g["small:grad:" + k])
+    for k, b in layer.named_buffers():
+        if k.endswith("num_batches_tracked"):
+            assert int(b) == int(g["small:buf:" + k]) == 1
+        else:
+            errs["buf:" + k] = mx(b.detach().cpu().numpy(), g["small:buf:" + k])
+    worst = max(errs, key=errs.get)
+    print(f"\n[F2b small, {'rebuilt' if rebuild else 'stored'}] worst element-wise error {errs[worst]:.2e} ({worst}); out {errs['out']:.1e} "
+          f"dx {errs['dx']:.1e}; reference fp32 vs its fp64: out/dx {g['small:e32_out_dx'].tolist()}, worst gradient {float(g['small:e32_vals'].max()):.1e}")
+    bad = {k: v for k, v in errs.items() if not v < 1e-5}
+    assert not bad, bad
+
+
+def test_layer1_f2b_multi_tile(dev):
+    """fixture F2b, large: the same stage on (4, 64, 48, 48) -- 9216 pixel rows: many tiles of every kernel, the 48-wide rows
+    of the halo / ring kernels.  Forward output element-wise (every 29th element) at 1e-5 of the largest magnitude, BatchNorm
+    buffers in full at 1e-5; gradients per tensor against the reference's float64 run in relative L2 at 2e-5 (the reference's
+    own float32 run sits 6e-7 ... 1.3e-6 from it: at this size a ReLU mask that flips at rounding level moves a gradient
+    tensor's L2 by less than that), sampled elements at 1e-4 of the tensor's largest sample.  Stored and rebuilt stages give the
+    same bits."""
+    g = load("f2b_layer1.npz")
+    N, C, H, W = (int(v) for v in g["large:shape"])
+    layer = _layer1(dev)
+    x = torch.relu(torch.from_numpy(P.make_input("f2bx_large", (N, C, H, W), seed=0))).to(dev)
+    xh = x.permute(0, 2, 3, 1).contiguous()
+
+    def gy_of(y):
+        gy = torch.from_numpy(P.make_input("f2bg_large", (N, 256, H, W), seed=0)).to(dev)
+        return gy.permute(0, 2, 3, 1).contiguous().view(y.shape)
+    with torch.no_grad():
+        y, dx = _run_layer1(layer, xh, gy_of, N, H, W, False)
+    yf = y.view(N, H, W, 256).permute(0, 3, 1, 2).contiguous().view(-1)[::29].cpu().numpy()
+    assert mx(yf, g["large:train_s29"]) < 1e-5, "forward output"
+    for k, b in layer.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            assert mx(b.detach().cpu().numpy(), g["large:buf:" + k]) < 1e-5, k
+    named = {"dx": dx.view(N, H, W, C).permute(0, 3, 1, 2).cpu().numpy()}
+    named.update({"grad:" + k: p.grad.detach().cpu().numpy() for k, p in layer.named_parameters()})
+    got = P.summarize_tensors(named, k=32)
+    worst_n, worst_s = 0.0, 0.0
+    for k in named:
+        n64 = float(g[f"large:f64:{k}:norm"])
+        worst_n = max(worst_n, abs(float(got[k + ":norm"]) - n64) / n64)
+        s64 = np.asarray(g[f"large:f64:{k}:samples"], np.float64)
+        worst_s = max(worst_s, float(np.abs(np.asarray(got[k + ":samples"], np.float64) - s64).max() / np.abs(s64).max()))
+    print(f"\n[F2b large] gradient norms vs the reference's float64: worst {worst_n:.2e}; sampled elements: worst {worst_s:.2e} "
+          f"(reference float32 vs float64, L2: median {float(np.median(g['large:e32_vals'])):.1e})")
+    assert worst_n < 2e-5 and worst_s < 1e-4
+    grads = {k: p.grad.detach().clone() for k, p in layer.named_parameters()}
+    layer2 = _layer1(dev)
+    with torch.no_grad():
+        y2, dx2 = _run_layer1(layer2, xh, gy_of, N, H, W, True)
+    assert torch.equal(y2, y) and torch.equal(dx2, dx)
+    for k, p in layer2.named_parameters():
+        assert torch.equal(p.grad, grads[k]), k

@@ -119,6 +119,39 @@ def test_oracle_generic_hierarchy_reproduces_the_reference_class():
     compare_case(run_oracle_case(gold, cfg_extra=dict(ext_pattern=(1, 2))), gold)
 
 
+def test_oracle_layer1_f2b():
+    """fixture F2b (ResNet-50 layer1 of the imported reference, train-mode forward + backward): the oracle's three Bottlenecks
+    element-wise on the ReLU-safe small case (1e-5 of each tensor's largest magnitude: both sides are torch CPU fp32)"""
+    g = load("f2b_layer1.npz")
+    N, C, H, W = (int(v) for v in g["small:shape"])
+    seed = int(g["small:seed"])
+    spec = [k for k in g.files if k.startswith("small:grad:") or k.startswith("small:buf:")]
+    sd = {}
+    for k in spec:
+        name = k.split(":", 2)[2]
+        v = t(P.fill_value(name, g[k].shape, name.endswith("num_batches_tracked")))
+        sd["l." + name] = v.reshape(g[k].shape).clone()
+    for k in sd:
+        if O.is_param(k):
+            sd[k].requires_grad_(True)
+    x = torch.relu(t(P.make_input("f2bx_small", (N, C, H, W), seed=seed))).requires_grad_(True)
+    y = x + 0
+    for b in range(3):
+        y = O._bottleneck(y, sd, f"l.{b}", True, 1, 1)
+    (y * t(P.make_input("f2bg_small", tuple(y.shape), seed=seed))).sum().backward()
+
+    def mx(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.abs(a - b).max() / np.abs(b).max())
+    assert mx(y.detach().numpy(), g["small:train"]) < 1e-5 and mx(x.grad.numpy(), g["small:dx"]) < 1e-5
+    for k in spec:
+        name = k.split(":", 2)[2]
+        if k.startswith("small:grad:"):
+            assert mx(sd["l." + name].grad.numpy(), g[k]) < 1e-5, name
+        elif not name.endswith("num_batches_tracked"):
+            assert mx(sd["l." + name].detach().numpy(), g[k]) < 1e-5, name
+
+
 def test_oracle_attention_feat():
     g = load("f1_attention_feat.npz")
     for dim, heads, n in ((64, 4, 25), (2048, 8, 12)):
