@@ -427,10 +427,11 @@ def main(args):
 
     job_state = {}
 
-    def make_job(name, batch, recompute="auto"):
+    def make_job(name, batch, recompute="auto", graph=None):
         """model + optimizer + resident synthetic batch of one workload -> (cfg, B, policy, step).  A name ending in `_bf16`
         is the same workload in the bf16 activation-storage mode (config key `activation_storage`), with its own default
         recompute policy where the halved activations allow a lighter one."""
+        graph = bool(args.graph) if graph is None else graph
         bf16 = name.endswith("_bf16")
         cfg, bdef, rdef = workload_cfg(name[:-5] if bf16 else name)
         if bf16:
@@ -445,7 +446,7 @@ def main(args):
         ddp.time_exposed = dist_on
         jobs_ddp.append(ddp)
         loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
-        opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=bool(args.graph))
+        opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4, capturable=graph)
         if name == "syn3_rcs":
             # the SAME values as syn3's slice-major volumes, laid out as the reference's (B, 1, R, C, S) tensors
             ncd = [[310, 310]] + [[160, 384, 384]] * 3 + [[16]]
@@ -465,7 +466,7 @@ def main(args):
                 return float(proba[0, 0].item())       # the driver's per-batch host read (argmax / softmax go to the CPU)
             return cfg, B, policy, step_eval
 
-        if args.graph:
+        if graph:
             if dist_on:
                 raise SystemExit("--graph captures single-GPU steps")
             from oaprogressionmmf_amd.run import GraphedTrainStep
@@ -752,6 +753,25 @@ def main(args):
             secondary["xr1c1_bf16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             job_state.clear()
             free()
+        # the launch-bound small configurations (BASELINE configs 2 and 1) as ONE HIP graph per train step (run.GraphedTrainStep:
+        # same kernels on device-resident step state, bit-identical to the eager step -- tests/test_run_gpu.py)
+        if not dist_on:
+            for name in ("xr1c1", "xr1cnn"):
+                try:
+                    cfgg, Bg, polg, stepg = make_job(name, 0, graph=True)
+                    dtg, lvg, perg = timed(stepg, 5, 20)
+                    secondary[name + "_graph"] = {"model": cfgg["name"], "value": round(world * Bg * 20 / dtg, 3), "unit": "knees/s",
+                                                  "ms_per_step": round(dtg / 20 * 1e3, 3), "ms_per_step_median": round(statistics.median(perg), 3),
+                                                  "steps": 20, "warmup": 5, "per_gpu_batch": Bg, "last_loss": round(lvg, 6),
+                                                  "workload": WORKLOAD_TEXT.get(name, "BASELINE config 1: XR 1x350x350, XR1Cnn; random-init weights")
+                                                  + "; the whole train step replayed from one HIP graph"}
+                    del stepg
+                    job_state.clear()
+                    free()
+                except Exception as e:  # noqa: BLE001
+                    secondary[name + "_graph"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                    job_state.clear()
+                    free()
         for name in ("native3", "native"):
             try:
                 cfg2, B2, pol2, step2 = make_job(name, 0)

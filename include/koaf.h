@@ -168,6 +168,15 @@ typedef struct KoafGemm {
        and B.ptr.  Gradients, weights, statistics and all arithmetic stay fp32; needs the vector path. */
     int32_t act16;
     int32_t _pad5;
+    /* Epilogue side output (nullable; forward convolutions whose OUTPUT BatchNorm is already known -- eval mode, stages rebuilt in
+       backward): besides C, the epilogue writes the activation plane images of relu(out_sc[n] * C + out_sh[n]) at the scale
+       KOAF_ACT_SCALE -- exactly what koaf_act_planes (tf 1) would cut from C in a pass of its own: [2][M][N] fp16 pieces,
+       plane stride out_ps = M * N elements, the 16-B zero chunk behind them.  Needs the vector epilogue, ldc == N, no batch, no
+       split-K, no row map. */
+    uint16_t* out_planes;
+    const float* out_sc;
+    const float* out_sh;
+    int64_t out_ps;
 } KoafGemm;
 
 int koaf_gemm(const KoafGemm* g, void* stream);
@@ -269,11 +278,20 @@ typedef struct KoafTail {
     const float* idt_sc;   /* nullable pair: the identity is idt_sc[c]*idt + idt_sh[c] -- the raw output of a downsample */
     const float* idt_sh;   /* convolution and its BatchNorm coefficients (koaf_bn_add_relu's idsc / idsh)             */
 } KoafTail;
+/* emit (nullable): the BatchNorm behind THIS convolution is already known (eval mode; a stage rebuilt in backward from its saved
+ * statistics: _torchvision.py:118-138 with running / saved statistics): the epilogue also cuts the activation plane images of
+ * relu(sc * y + sh) -- what the following 3x3 convolution's koaf_act_planes pre-pass would read y back for -- into `planes`
+ * (koaf_act_planes_elems(N * OH * OW, Cout) elements, bit-identical to that pass). */
+typedef struct KoafEmit {
+    uint16_t* planes;
+    const float* sc;
+    const float* sh;
+} KoafEmit;
 int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W,
                     int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                     const float* in_sc, const float* in_sh, float* stats, int32_t* stats_rows,
                     const float* stats_shift, const KoafWImg* wimg, const uint16_t* x_planes, const KoafTail* tail,
-                    int32_t act16, void* stream);
+                    const KoafEmit* emit, int32_t act16, void* stream);
 /* rows of the stats buffer koaf_conv2d_fwd writes for M output pixels */
 int32_t koaf_conv2d_stats_rows(int64_t M, int32_t Cout);
 /* dx [N,H,W,Cin] = conv_transpose(dy [N,OH,OW,Cout], w) (+residual: the other branch's gradient);

@@ -106,6 +106,10 @@ class KoafGemm(ctypes.Structure):
         ("status", ctypes.c_void_p),
         ("act16", ctypes.c_int32),
         ("_pad5", ctypes.c_int32),
+        ("out_planes", ctypes.c_void_p),
+        ("out_sc", ctypes.c_void_p),
+        ("out_sh", ctypes.c_void_p),
+        ("out_ps", ctypes.c_int64),
     ]
 
 
@@ -149,6 +153,10 @@ class KoafTail(ctypes.Structure):
     _fields_ = [("idt", ctypes.c_void_p), ("y_out", ctypes.c_void_p), ("idt_sc", ctypes.c_void_p), ("idt_sh", ctypes.c_void_p)]
 
 
+class KoafEmit(ctypes.Structure):
+    _fields_ = [("planes", ctypes.c_void_p), ("sc", ctypes.c_void_p), ("sh", ctypes.c_void_p)]
+
+
 class KoafBnApply(ctypes.Structure):
     _fields_ = [("dz", ctypes.c_void_p), ("c", ctypes.c_void_p), ("coef", ctypes.c_void_p), ("amax", ctypes.c_void_p)]
 
@@ -178,6 +186,8 @@ def _ctype(decl: str):
             return ctypes.POINTER(KoafBnApply)
         if base == "KoafTail":
             return ctypes.POINTER(KoafTail)
+        if base == "KoafEmit":
+            return ctypes.POINTER(KoafEmit)
         if base == "char":
             return ctypes.c_char_p
         return ctypes.c_void_p

@@ -285,8 +285,8 @@ __global__ void __launch_bounds__(256) gconv_compress_kernel(const float* __rest
 extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t N, int32_t H, int32_t W, int32_t Cin,
                                int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, const float* in_sc,
                                const float* in_sh, float* stats, int32_t* stats_rows, const float* stats_shift,
-                               const KoafWImg* wimg, const uint16_t* x_planes, const KoafTail* tail, int32_t act16,
-                               void* stream) {
+                               const KoafWImg* wimg, const uint16_t* x_planes, const KoafTail* tail, const KoafEmit* emit,
+                               int32_t act16, void* stream) {
     KOAF_REQUIRE((x || x_planes) && w && y && N > 0 && Cin % 32 == 0 && Cout % 4 == 0, "koaf_conv2d_fwd: bad args (Cin=%d Cout=%d)",
                  Cin, Cout);
     KOAF_REQUIRE(!tail || (tail->idt && x && in_sc && in_sh && !x_planes && KH == 1 && KW == 1 && stride == 1 && pad == 0 && wimg &&
@@ -324,6 +324,10 @@ extern "C" int koaf_conv2d_fwd(const float* x, const float* w, float* y, int32_t
     g.stats = stats;
     g.stats_shift = stats ? stats_shift : nullptr;
     g.act16 = act16 ? 1 : 0;            // (x and y are bf16 activations)
+    if (emit) {
+        KOAF_REQUIRE(emit->planes && emit->sc && emit->sh && (Cout % 8) == 0, "koaf_conv2d_fwd: emit needs planes / sc / sh and Cout %% 8 == 0");
+        g.out_planes = emit->planes; g.out_sc = emit->sc; g.out_sh = emit->sh; g.out_ps = M * Cout;
+    }
     if (stats_rows) *stats_rows = koaf_gemm_part_rows(&g);
     return koaf_gemm(&g, stream);
 }

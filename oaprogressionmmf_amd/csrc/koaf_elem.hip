@@ -917,16 +917,25 @@ __global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ p, float 
 // weights [C] or NULL.  F.cross_entropy(reduction='none', weight=cw) per element: ce = -cw[t] * log_softmax(x)[t];
 //   focal (FocalLoss, _losses.py:101-108):  logpt = -ce, pt = exp(logpt), l = -(1 - pt)^gamma * logpt, plain mean | sum over elements
 //   else  (nn.CrossEntropyLoss(weight=cw), _losses.py:36,49):  sum ce / sum cw[t]   (weighted mean)
+// Targets outside [0, C): -100 is F.cross_entropy's default ignore_index -- such an element has zero loss and zero gradient, and
+// the (weighted) mean of the cross-entropy leaves it out of its denominator, while the focal loss, which takes the mean of the
+// per-element values itself (koafusion/various/_losses.py:101-108: reduction 'none', then .mean()), still divides by every
+// element, as the reference does.  Any other out-of-range label (torch raises a device assert there) is treated the same way
+// and counted in the numerics status word [1] instead of indexing out of bounds.
 __global__ void __launch_bounds__(256) focal_loss_kernel(const float* __restrict__ logits,
                                                          const int64_t* __restrict__ target, const float* __restrict__ cw,
                                                          float* loss, float* __restrict__ dlogits, int B, int C, int64_t S,
-                                                         float gamma, int mean, int focal) {
+                                                         float gamma, int mean, int focal, uint32_t* status) {
     __shared__ float red[256];
     const int64_t n = (int64_t)B * S;
     float wsum = (float)n;
-    if (!focal && cw) {       // the weighted mean's denominator first
+    unsigned nbad = 0;
+    if (!focal) {       // the (weighted) mean's denominator first: the elements that count
         float a = 0.f;
-        for (int64_t i = threadIdx.x; i < n; i += 256) a += cw[(int)target[i]];
+        for (int64_t i = threadIdx.x; i < n; i += 256) {
+            const int64_t tg = target[i];
+            if (tg >= 0 && tg < C) a += cw ? cw[(int)tg] : 1.f;
+        }
         red[threadIdx.x] = a;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {
@@ -941,12 +950,19 @@ __global__ void __launch_bounds__(256) focal_loss_kernel(const float* __restrict
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const int64_t b = i / S, sp = i - b * S;
         const float* x = logits + b * C * S + sp;        // class j at x[j * S]
+        float* d = dlogits + b * C * S + sp;
+        const int64_t tg64 = target[i];
+        if (tg64 < 0 || tg64 >= C) {
+            nbad += (tg64 != -100) ? 1u : 0u;
+            for (int j = 0; j < C; ++j) d[j * S] = 0.f;
+            continue;
+        }
         float m = -INFINITY;
         for (int j = 0; j < C; ++j) m = fmaxf(m, x[j * S]);
         float s = 0.f;
         for (int j = 0; j < C; ++j) s += expf(x[j * S] - m);
         const float lse = m + logf(s);
-        const int tg = (int)target[i];
+        const int tg = (int)tg64;
         const float w = cw ? cw[tg] : 1.f;
         const float logpt = w * (x[tg * S] - lse);
         const float pt = expf(logpt);
@@ -962,12 +978,12 @@ __global__ void __launch_bounds__(256) focal_loss_kernel(const float* __restrict
             dl = -1.f;
         }
         acc += li;
-        float* d = dlogits + b * C * S + sp;
         for (int j = 0; j < C; ++j) {
             const float pj = expf(x[j * S] - lse);
             d[j * S] = dl * w * ((j == tg ? 1.f : 0.f) - pj) * wgt;
         }
     }
+    koaf_status_add(status, 1, nbad);
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -1403,14 +1419,14 @@ extern "C" int koaf_focal_loss(const float* logits, const int64_t* target, const
                                void* stream) {
     KOAF_REQUIRE(logits && target && loss && dlogits && B > 0 && C > 0 && S > 0, "koaf_focal_loss: bad args");
     hipLaunchKernelGGL(focal_loss_kernel, dim3(1), dim3(256), 0, STREAM, logits, target, class_weight, loss, dlogits, B, C, S,
-                       gamma, reduction_mean, 1);
+                       gamma, reduction_mean, 1, koaf_status_ptr());
     return koaf_check_launch("koaf_focal_loss");
 }
 extern "C" int koaf_ce_loss(const float* logits, const int64_t* target, const float* class_weight, float* loss,
                             float* dlogits, int32_t B, int32_t C, int64_t S, void* stream) {
     KOAF_REQUIRE(logits && target && loss && dlogits && B > 0 && C > 0 && S > 0, "koaf_ce_loss: bad args");
     hipLaunchKernelGGL(focal_loss_kernel, dim3(1), dim3(256), 0, STREAM, logits, target, class_weight, loss, dlogits, B, C, S,
-                       0.f, 1, 0);
+                       0.f, 1, 0, koaf_status_ptr());
     return koaf_check_launch("koaf_ce_loss");
 }
 

@@ -38,6 +38,7 @@
 //       LDS-DMA writes are lane-linear, so rows cannot be padded, and the swizzle keeps the fragment reads conflict-free.
 //       Double-buffered: the DMA of k-tile t+1 lands while tile t is multiplied.
 #include "koaf_common.h"
+#include <stdlib.h>
 
 // In-kernel phase stamps (diagnostic builds only: make STAMPS=1 -> libkoaf_stamps.so, scripts/stamps_*.py): thread 0 of every
 // block adds the 100 MHz real-time counter differences between its phase boundaries to a device table.
@@ -150,7 +151,9 @@ enum { M_KC = 0,     // K-contiguous rows, dense
        M_PA2 = 8,    // the same, transposed-conv (dgrad) gather
        M_PH = 9,     // the same images, 3x3 / stride 1 / pad 1: the tile's pixel rows + halo stay in LDS for all nine taps
        M_PK = 10,    // activation plane images read K-major (weight gradient: k = pixel, rows = channels), dense
-       M_PKG = 11    // the same with the conv gather on the k index and the filter tap in the column (wgrad activations)
+       M_PKG = 11,   // the same with the conv gather on the k index and the filter tap in the column (wgrad activations)
+       M_PT = 12     // activation plane images, 3x3 / stride 1 / pad 1, 2-D pixel tiles (8 x 16) with a zero-filled halo in LDS (64 channels
+                     // at a time: one filter tap x 64 channels per barrier)
 };
 __host__ __device__ constexpr bool mode_is_kc(int m) { return m < 3; }
 __host__ __device__ constexpr bool mode_is_pa(int m) { return m == M_PA1 || m == M_PA2; }
@@ -892,23 +895,69 @@ __device__ __forceinline__ v4i frag_load_kmd(const unsigned* P, int row0, int g,
     return (v4i){l2[0], l2[1], h2[0], h2[1]};
 }
 
+// M_PT: LDS-DMA of the 10 x 18 pixel halo of 2-D tile `tm` (64 channels from channel 64 * chunk, both planes: 2880 granules of 16 B
+// = 45 pieces; wave w moves pieces w, w + 4, ...) into the image at LDS byte address halo0.  Granule c of halo pixel (y, x) lands at
+// ((18 y + x) * 8 + (c ^ (x / 2 % 8))) * 16; pixels outside the image fetch the operand's zero chunk.
+__device__ __forceinline__ void t2d_issue_halo(const KoafOperand& A, const unsigned short* Apl, int tm, int chunk, unsigned halo0) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int Wd = A.W, Hd = A.H, CSa = A.CS;
+    const int txn = Wd >> 4, tpi = (Hd >> 3) * txn;          // tiles per image row / per image
+    const int img = tm / tpi, trem = tm - img * tpi, tyi = trem / txn, txi = trem - tyi * txn;
+#pragma unroll 1
+    for (int pc = w; pc < 45; pc += 4) {
+        const int G = pc * 64 + lane, q = G >= 1440 ? 1 : 0, Gp = G - 1440 * q;
+        const int hp = Gp >> 3, cs = Gp & 7, y = hp / 18, x = hp - 18 * y;
+        const int c16 = cs ^ ((x >> 1) & 7);
+        const int iy = tyi * 8 - 1 + y, ix = txi * 16 - 1 + x;
+        const bool ok = (unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd;
+        const unsigned short* src = ok ? Apl + q * A.plane_stride + ((int64_t)(img * Hd + iy) * Wd + ix) * CSa + (chunk * 64 + c16 * 8) : A.zeros;
+        lds_dma16(src, halo0 + pc * 1024);
+    }
+}
+
 // Row loop of the vector epilogue for a FULL tile without row map, specialised on what is fused (residual, BatchNorm-
 // backward mode, second BatchNorm) so that it is branch-free: the loads of four rows go out together before the first
 // is consumed (the generic loop below tests every row and ends up with one load in flight at a time, which held the
 // HBM-bound 1x1-dgrad epilogues at 2-3 TB/s).
 // C16: the output tensor is stored as bf16; E16: the BatchNorm-backward operands (c / y / c2) are (KoafGemm.act16 1 / 2)
-template <int BM, int BN, int NT, bool HAS_R, int MODE, bool HAS_C2, bool C16, bool E16>
+// KoafGemm.out_planes: the activation plane images of relu(out_sc * v + out_sh) * KOAF_ACT_SCALE for the four output elements v at
+// element offset `off` -- koaf_act_planes' tf-1 arithmetic on the value as STORED (bf16 storage: the rounded one), bit for bit
+template <bool C16>
+__device__ __forceinline__ void epi_emit_planes(const KoafGemm& p, int64_t off, v4f v, v4f a, v4f b, unsigned& nsat) {
+    constexpr float HMAX = 65504.f;
+    if constexpr (C16) { const uint2 u = round_bf16x4(v); v = widen_bf16x4(u.x, u.y); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float u = fmaf(v[j], a[j], b[j]);
+        nsat += !(u <= HMAX) ? 1u : 0u;
+        v[j] = __builtin_amdgcn_fmed3f(u, 0.f, HMAX);
+    }
+    unsigned pl[2][2];
+    split2h(v, pl);
+    *(uint2*)(p.out_planes + off) = make_uint2(pl[0][0], pl[0][1]);
+    *(uint2*)(p.out_planes + p.out_ps + off) = make_uint2(pl[1][0], pl[1][1]);
+}
+
+// T2D: the tile's rows are an 8 x 16 pixel rectangle of one image (M_PT): row lr = pixel (lr / 16, lr % 16) of the tile whose first
+// pixel is m0, image rows w2d pixels apart
+template <int BM, int BN, int NT, bool HAS_R, int MODE, bool HAS_C2, bool C16, bool E16, bool T2D = false>
 __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs, int ldcs, float* Cp, int64_t ldc,
                                               const float* Rp, int m0, int col, int c4, int rr, v4f bv, v4f mu, v4f is,
-                                              v4f ms, v4f mh, v4f mu2, v4f is2, v4f& q1, v4f& q2, v4f& q3, v4f& qm) {
+                                              v4f ms, v4f mh, v4f mu2, v4f is2, v4f& q1, v4f& q2, v4f& q3, v4f& qm, int w2d = 0) {
     constexpr int C4 = BN / 4, RPP = NT / C4, U = 4;
     static_assert((BM / RPP) % U == 0, "rows per thread must be a multiple of the batch");
+    [[maybe_unused]] v4f ea = {0.f, 0.f, 0.f, 0.f}, eb = ea;      // KoafGemm.out_planes: this thread's columns of out_sc / out_sh, at the activation scale
+    [[maybe_unused]] unsigned nsat = 0;
+    if constexpr (MODE == 0 && !HAS_R) {
+        if (p.out_planes) { ea = *(const v4f*)(p.out_sc + col) * KOAF_ACT_SCALE; eb = *(const v4f*)(p.out_sh + col) * KOAF_ACT_SCALE; }
+    }
 #pragma unroll 1
     for (int row = rr; row < BM; row += RPP * U) {
         v4f rv[U], cv[U], yv[U], c2v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t orow = m0 + row + u * RPP;
+            const int lr_ = row + u * RPP;
+            const int64_t orow = T2D ? (int64_t)m0 + (lr_ >> 4) * w2d + (lr_ & 15) : (int64_t)m0 + lr_;
             // (streamed once: non-temporal, like the stores below -- the tile's operands, not these, should stay in L2)
             if constexpr (HAS_R) rv[u] = __builtin_nontemporal_load((const v4f*)(Rp + orow * p.ldr + col));
             if constexpr (MODE != 0) cv[u] = load4_nt<E16>(p.bnb_c, orow * ldc + col);
@@ -917,7 +966,8 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t orow = m0 + row + u * RPP;
+            const int lr_ = row + u * RPP;
+            const int64_t orow = T2D ? (int64_t)m0 + (lr_ >> 4) * w2d + (lr_ & 15) : (int64_t)m0 + lr_;
             v4f v = *(const v4f*)&Cs[(row + u * RPP) * ldcs + 4 * c4] + bv;
             if constexpr (HAS_R) v += rv[u];
             if constexpr (MODE == 1) {
@@ -935,8 +985,12 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
                 for (int j = 0; j < 4; ++j) qm[j] = __uint_as_float(max(__float_as_uint(qm[j]), koaf_absbits(v[j])));
             }
             store4_nt<C16>(Cp, orow * ldc + col, v);
+            if constexpr (MODE == 0 && !HAS_R) {
+                if (p.out_planes) epi_emit_planes<C16>(p, orow * ldc + col, v, ea, eb, nsat);
+            }
         }
     }
+    if constexpr (MODE == 0 && !HAS_R) koaf_status_add(p.status, 0, nsat);
 }
 
 
@@ -952,7 +1006,7 @@ __host__ __device__ constexpr bool persist_mode(int am, int bmd, bool f16, int t
 // ACT = KoafGemm.act16: which tensors of this call are bf16 ACTIVATIONS (0: none; 1 forward: A.ptr and C; 2 data gradient:
 // A.ptr2 (the conv output c of a tf-2 apply) and the BatchNorm-backward operands of the epilogue; 3 weight gradient: A.ptr2 and B.ptr)
 template <int BM, int BN, int AM, int BMD, int TFA, int TFB, bool VEC, bool F16, int NT = 256, int ACT = 0>
-__global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) koaf_gemm_kernel(const KoafGemm p) {
+__global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == M_PT) ? 2 : 1) koaf_gemm_kernel(const KoafGemm p) {
     static_assert(ACT == 0 || VEC, "bf16 activation storage needs the vector path");
     constexpr bool C16 = (ACT == 1), E16 = (ACT == 2);
     static_assert((TFA < 2 && TFB < 2) || VEC, "the two-source prologues need the vector path");
@@ -961,9 +1015,11 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
     constexpr int NW = NT / 64, WGM = NW / 2;                        // waves: WGM along M x 2 along N
     constexpr int WM = BM / WGM, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr bool AKC = mode_is_kc(AM), BKC = mode_is_kc(BMD), BPS = (BMD == M_PS), APS = mode_is_pa(AM), AH = (AM == M_PH);
+    constexpr bool AT = (AM == M_PT);                // 3x3 over plane images in 8 x 16 pixel tiles: halo in LDS, weight fragments in registers
+    static_assert(!AT || (BM == 128 && BN == 64 && NT == 256 && BMD == M_PS && TFA == 0 && F16 && VEC), "the 2-D tile kernel's one shape");
     constexpr bool WPS = (AM == M_PK);               // weight gradient from plane images: both operands K-major by LDS-DMA
     static_assert(WPS == (BMD == M_PKG || BMD == M_PK), "K-major plane images come in pairs");
-    static_assert(!(APS || AH) || (BPS && TFA == 0), "a pre-split A pairs with a pre-split B and carries its transform in the image");
+    static_assert(!(APS || AH || AT) || (BPS && TFA == 0), "a pre-split A pairs with a pre-split B and carries its transform in the image");
     static_assert(NT == 256 || AH, "only the halo kernel runs 512 threads (the fp32 loaders are laid out for 256)");
     static_assert(!AH || (BM == 256) == (NT == 512), "halo shapes: 256 rows x 512 threads, 128 rows x 256 threads");
     constexpr int HP_MAX = (BM + 2 * halo_max_w(BN, BM) + 2 + 15) / 16;  // 16-pixel (1 KiB) pieces of a halo plane
@@ -976,7 +1032,10 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
     constexpr int LDC_S = BN + 4;                                    // epilogue staging row (floats)
     constexpr int C_ELEMS = VEC ? BM * LDC_S : 0;
     constexpr int OPS = NBA * A_ELEMS + NBB * B_ELEMS;
-    constexpr int SMEM = (OPS > C_ELEMS) ? OPS : C_ELEMS;
+    // M_PT: the epilogue's staging tile (which the two weight-tile stages of the k-loop share) and the halo image (180 pixels x 64
+    // channels x two fp16 planes = 45 KiB) sit side by side: 80 960 B with the 64 B of block_amax_raise_bits -- two blocks per CU
+    constexpr int T2D_HALO_BYTES = 2 * 180 * 128;
+    constexpr int SMEM = AT ? (C_ELEMS + T2D_HALO_BYTES / 4) : ((OPS > C_ELEMS) ? OPS : C_ELEMS);
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
     KOAF_STAMP_DECL;
@@ -1033,13 +1092,13 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
 
     // (batch offsets count elements: a bf16 tensor behind a float-typed pointer advances by half the bytes)
     auto eoff = [](const float* q, int64_t elems, bool h16) { return h16 ? (const float*)((const unsigned short*)q + elems) : q + elems; };
-    const float* Ap = (APS || AH || WPS) ? nullptr : eoff(p.A.ptr, z0 * p.A.bs0 + z1 * p.A.bs1, ACT == 1);
-    const unsigned short* Apl = (APS || AH || WPS) ? p.A.planes + z0 * p.A.bs0 + z1 * p.A.bs1 : nullptr;
+    const float* Ap = (APS || AH || AT || WPS) ? nullptr : eoff(p.A.ptr, z0 * p.A.bs0 + z1 * p.A.bs1, ACT == 1);
+    const unsigned short* Apl = (APS || AH || AT || WPS) ? p.A.planes + z0 * p.A.bs0 + z1 * p.A.bs1 : nullptr;
     const float* Bp = (BPS || WPS) ? nullptr : eoff(p.B.ptr, z0 * p.B.bs0 + z1 * p.B.bs1, ACT == 3);
     const unsigned short* Bpl = (BPS || WPS) ? p.B.planes + z0 * p.B.bs0 + z1 * p.B.bs1 : nullptr;
 
     // (the unused ones of the loaders are dead code to the compiler)
-    TileLoader<(APS || AH) ? 128 : BM, (APS || AH || WPS) ? M_KC : AM, TFA, VEC, F16, ACT == 1,
+    TileLoader<(APS || AH || AT) ? 128 : BM, (APS || AH || AT || WPS) ? M_KC : AM, TFA, VEC, F16, ACT == 1,
                ((ACT == 2 || ACT == 3) && TFA == 2) || (ACT == 1 && TFA == 3)> la;
     TileLoader<BN, (BPS || WPS) ? M_KC : BMD, TFB, VEC, F16, ACT == 3> lb;
     PlaneKLoader<WPS ? BM : 128, false> wka;
@@ -1054,11 +1113,11 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
     } else if constexpr (APS) {
         lpa.init(p.A, m0, p.M);
         lpa.seek(p.A, kbeg);
-    } else if constexpr (!AH) {
+    } else if constexpr (!AH && !AT) {
         la.init(p.A, m0, p.M, z1, sca);
         la.seek(p.A, kbeg);
     }
-    if constexpr (AH || WPS) {
+    if constexpr (AH || AT || WPS) {
         // (the halo loop below addresses both operands itself; the K-major pair was set up above)
     } else if constexpr (BPS) {
         lp.init(p.B, n0, p.N);
@@ -1087,6 +1146,7 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
 
     float* const Bs0 = smem + NBA * A_ELEMS;
     const unsigned sm0 = KOAF_LDS_ADDR(smem), sb0 = sm0 + NBA * A_ELEMS * 4;     // LDS byte addresses of the A / B buffers
+    [[maybe_unused]] int t2d_base = 0, t2d_w = 0;                               // M_PT: first pixel of the tile's rectangle, image row pitch
     // the MFMAs of one k-tile whose plane images sit at Au / Bu
     auto mma = [&](const unsigned* Au, const unsigned* Bu) {
 #pragma unroll
@@ -1384,6 +1444,125 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the surplus fetches behind the last step)
         __syncthreads();       // the epilogue reuses the operand buffers
         }
+    } else if constexpr (AT) {
+        // 3x3 / stride 1 / pad 1 over activation plane images, 8 x 16 pixel tiles of ONE image (H % 8 == 0, W % 16 == 0).
+        //   * Halo: the 10 x 18 source pixels of the tile, 64 channels at a time, both fp16 planes, are fetched ONCE by LDS-DMA;
+        //     pixels outside the image fetch the zero chunk, so the k-loop needs no validity masks.  A raster tile of 128 pixels
+        //     (M_PH) needs 128 + 2 W + 2 halo pixels -- 2.5 tiles' worth at W = 96; the rectangle needs 1.4 -- and that is what
+        //     lets a 64-channel halo AND two blocks share a CU: one step = one filter tap over all 64 channels = 24 MFMAs per
+        //     wave (M_PH, 128 rows: 12 per barrier).
+        //   * LDS image: granule (16 B = 8 channels) c of halo pixel (y, x) at ((18 y + x) * 8 + (c ^ (x / 2 % 8))) * 16: the 16 lanes
+        //     of a ds_read_b128 group hold x = x0 + {0..3, 12..15} of one tile row and x0 + {4..11} of the next, i.e. every
+        //     residue mod 16 once -- (x % 2, x / 2 % 8) are 16 distinct (bank half, 16-B slot) pairs: conflict-free.  The DMA
+        //     writes lane-linear, so the permutation is applied to the per-lane SOURCE address.
+        //   * Weights: the 64 x 64 tile of one (tap, chunk) step by LDS-DMA, double-buffered INSIDE the epilogue's staging region
+        //     (the two never live at the same time), one barrier per step.  (Loading the fragments straight into registers --
+        //     no barrier at all -- was measured first: 64 KB per step and CU through the vector memory path in 32-B segments
+        //     was the limiter, 245 TFLOP/s.)
+        //   * k runs (chunk of 64 channels, tap, channel); C = 128 reloads the halo once (two barriers).
+        typedef const __attribute__((address_space(3))) v4i* lds_v4i;
+        typedef const __attribute__((address_space(3))) char* lds_c;
+        const int Wd = p.A.W, Hd = p.A.H, CSa = p.A.CS, Ca = p.A.C;
+        const bool flip = p.A.gather == 2;
+        const int txn = Wd >> 4, tpi = (Hd >> 3) * txn;          // tiles per image row / per image
+        const int img = tm / tpi, trem = tm - img * tpi, tyi = trem / txn, txi = trem - tyi * txn;
+        const int nchunk = Ca >> 6;
+        const unsigned halo0 = KOAF_LDS_ADDR(smem) + C_ELEMS * 4;
+        t2d_base = (img * Hd + tyi * 8) * Wd + txi * 16;
+        t2d_w = Wd;
+        // this lane's rows of the two M tiles: pixel (ly, lx) of the tile; halo pixel of tap (ky, kx) = (ly + ky, lx + kx)
+        const int lx = r & 15;
+        int hp0[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) hp0[i] = (4 * wm + 2 * i + (r >> 4)) * 18 + lx;
+        // weight tile of one step: 64 output channels x 64 k x two planes = 16 KiB = 16 DMA pieces, four per wave; granule c of row
+        // `row` at (row * 8 + (c ^ (row / 2 % 8))) * 16 (the halo image's conflict-free pattern); two stages in the staging region
+        const unsigned bst0 = KOAF_LDS_ADDR(smem);
+        int64_t bsrc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int G = (w + 4 * j) * 64 + lane, q = G >> 9, Gp = G & 511, row = Gp >> 3, cs = Gp & 7;
+            const int brow = min(n0 + row, p.N - 1);                // (rows past N: finite values, never stored)
+            bsrc[j] = (int64_t)q * p.B.plane_stride + (int64_t)brow * p.B.ld + 8 * (cs ^ ((row >> 1) & 7));
+        }
+        auto issue_b = [&](int tap, int chunk, int stage) {
+            const int koff = tap * Ca + chunk * 64;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lds_dma16(Bpl + bsrc[j] + koff, bst0 + stage * 16384 + (w + 4 * j) * 1024);
+        };
+        // fragments of k-group g of filter tap `tap`: A of both M tiles, B of this wave's 32 columns, both planes
+        struct FR { v4i a[TM][2]; v4i b[2]; };
+        const int browl = wn * WN + r, bsw = (browl >> 1) & 7;
+        auto read_f = [&](FR& f, int tap, int g, int stage) {
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const int ky = flip ? 2 - kh : kh, kx = flip ? 2 - kw : kw;
+            const int sw = ((lx + kx) >> 1) & 7;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const unsigned off = (unsigned)((hp0[i] + ky * 18 + kx) * 128 + (((2 * g + h) ^ sw) << 4));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) f.a[i][q] = *(lds_v4i)((lds_c)smem + (C_ELEMS * 4 + q * 23040) + off);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                f.b[q] = *(lds_v4i)((lds_c)smem + (stage * 16384 + q * 8192 + browl * 128 + (((2 * g + h) ^ bsw) << 4)));
+        };
+        auto mma_g = [&](const FR& f) {
+            constexpr int PAH[3] = {1, 0, 0}, PBH[3] = {0, 1, 0};
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, f.a[i][PAH[term]]),
+                                                                        __builtin_bit_cast(h16x8, f.b[PBH[term]]),
+                                                                        acc[i][0], 0, 0, 0);
+        };
+        static_assert(TM == 2 && TN == 1 && C_ELEMS * 4 >= 2 * 16384, "2 x 2 waves of 64 x 32; two weight stages inside the staging region");
+        FR R0, R1;
+        t2d_issue_halo(p.A, Apl, tm, 0, halo0);
+        issue_b(0, 0, 0);
+        const int nstep = 9 * nchunk;
+        int tap = 0, chunk = 0;
+        // One step = one filter tap over 64 channels = four k-groups of 6 MFMAs per wave, one barrier.  Pinned with scheduling
+        // barriers (left alone, hipcc sinks every LDS read to just in front of its first use): the fragments of k-group g + 1
+        // are read while group g is multiplied; the next step's weight tile lands under this step's MFMAs.
+#pragma unroll 1
+        for (int s_ = 0; s_ < nstep; ++s_) {
+            const int stage = s_ & 1;
+            int ntap = tap + 1, nch = chunk;
+            if (ntap == 9) { ntap = 0; ++nch; }
+            const bool has_next = s_ + 1 < nstep;
+            // this step's weight tile (and, at s = 0, the halo) has landed; every wave is done with the other stage
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (s_ == 0) KOAF_STAMP(1);
+            if (has_next && ntap != 0) issue_b(ntap, nch, stage ^ 1);
+            read_f(R0, tap, 0, stage);
+            __builtin_amdgcn_sched_barrier(0);
+            read_f(R1, tap, 1, stage);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_g(R0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_f(R0, tap, 2, stage);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_g(R1);
+            __builtin_amdgcn_sched_barrier(0);
+            read_f(R1, tap, 3, stage);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_g(R0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_g(R1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next && ntap == 0) {
+                // next 64 channels: every wave is done with this halo, then it is replaced together with the first weight tile
+                // (the CU's other block computes meanwhile)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                t2d_issue_halo(p.A, Apl, tm, nch, halo0);
+                issue_b(0, nch, stage ^ 1);
+            }
+            tap = ntap; chunk = nch;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();       // the epilogue's staging tile covers the weight stages
     } else if constexpr (WPS) {
         // weight gradient: both K-major operands by LDS-DMA, double-buffered, one barrier per k-tile (as below)
         if (kbeg < kend) {
@@ -1476,6 +1655,9 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
     // buffers, so the weight tile's DMA has to wait for the end of the epilogue)
     bool has_next = false;
     int tm2 = 0, tn2 = 0;
+    // (M_PT blocks are NOT persistent: requesting the next tile's halo under this tile's epilogue was measured -- the prologue
+    // fell from 3.9 to 0.7 us per tile and the k-loops grew by as much: with two blocks per CU one block's prologue already runs
+    // under the other's MFMAs)
     if constexpr (PERSIST) {
         has_next = (vt + gridDim.x) < ntx;
         if (has_next) {
@@ -1556,8 +1738,8 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
             if (full) {
                 const bool hr = Rp != nullptr, h2 = bnb && p.bnb2_c != nullptr;
                 const int mode = bnb ? p.bnb_mode : 0;
-#define KOAF_EPI(R_, M_, C2_) epi_rows_full<BM, BN, NT, R_, M_, C2_, C16, E16>(p, Cs, LDC_S, Cp, ldc, Rp, m0, col, c4, rr, bv, mu, is, \
-                                                                 ms, mh, mu2, is2, q1, q2, q3, qm)
+#define KOAF_EPI(R_, M_, C2_) epi_rows_full<BM, BN, NT, R_, M_, C2_, C16, E16, AT>(p, Cs, LDC_S, Cp, ldc, Rp, AT ? t2d_base : m0, col, c4, rr, bv, mu, is, \
+                                                                 ms, mh, mu2, is2, q1, q2, q3, qm, t2d_w)
                 if (mode == 0) { if (hr) KOAF_EPI(true, 0, false); else KOAF_EPI(false, 0, false); }
                 else if (mode == 1) {
                     if (hr) { if (h2) KOAF_EPI(true, 1, true); else KOAF_EPI(true, 1, false); }
@@ -1603,9 +1785,16 @@ __global__ void __launch_bounds__(NT, persist_mode(AM, BMD, F16, TFA) ? 2 : 1) k
                         }
                     }
                     store4_nt<C16>(Cp, orow * ldc + col, v);
+                    if (p.out_planes && !bnb && !Rp) {
+                        unsigned ns = 0;
+                        epi_emit_planes<C16>(p, orow * ldc + col, v, *(const v4f*)(p.out_sc + col) * KOAF_ACT_SCALE,
+                                             *(const v4f*)(p.out_sh + col) * KOAF_ACT_SCALE, ns);
+                        koaf_status_add(p.status, 0, ns);
+                    }
                 }
             }
         }
+        if (p.out_planes && tm == 0 && tn == 0 && t == 0 && blockIdx.z == 0) *(uint4*)(p.out_planes + 2 * p.out_ps) = make_uint4(0u, 0u, 0u, 0u);   // the zero chunk
         if (bnb) {
             if (p.bnb_amax) block_amax_raise_bits(max(max(__float_as_uint(qm[0]), __float_as_uint(qm[1])), max(__float_as_uint(qm[2]), __float_as_uint(qm[3]))), p.bnb_amax);
             // column sums over the block's rows: RPP row-threads per column vector -> LDS -> one partial row
@@ -1866,9 +2055,10 @@ extern "C" int koaf_gemm_pick_tile(const KoafGemm* g, int32_t* bm, int32_t* bn) 
 }
 
 namespace {
-struct TilePlan { int bm, bn; bool vec; int part_rows; bool halo; };
+struct TilePlan { int bm, bn; bool vec; int part_rows; bool halo; bool t2d; };
 
 int g_halo_mode = 1;        // koaf_set_conv3x3_halo: 0 off, 1 pick the shape per layer, 2 always 256 rows, 3 always 128 rows
+int g_t2d_mode = -1;        // the 2-D tile kernel (M_PT) for 64- / 128-channel layers whose image tiles evenly: -1 = read KOAF_CONV3_T2D once (default on)
 
 // 3x3 / stride 1 / pad 1 over activation plane images with the whole pixel range as rows: the halo kernel (M_PH)
 bool halo_ok(const KoafGemm& g) {
@@ -1895,7 +2085,17 @@ TilePlan plan_tiles(const KoafGemm& g) {
     t.vec = gemm_vec_ok(g);
     if (!t.vec) { t.bm = 64; t.bn = 64; }
     t.halo = t.vec && halo_ok(g);
-    if (t.halo) {
+    if (g_t2d_mode < 0) { const char* e = getenv("KOAF_CONV3_T2D"); g_t2d_mode = (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }
+    // 64 channels in (one halo chunk), 64 / 128 out, images of whole 8 x 16 tiles: the rectangle-tile kernel (halo_ok: 3x3 / stride 1 /
+    // pad 1 over plane images, one GEMM over all pixels, every pixel a row).  KOAF_CONV3_T2D=2 admits 128 input channels as well (two
+    // chunks, the halo fetched twice per 64-column tile: measured no faster than the 128-row raster kernel there, 2.59 vs 2.55 ms).
+    t.t2d = t.halo && g_t2d_mode >= 1 && g_halo_mode == 1 && (g.A.C == 64 || (g.A.C == 128 && g_t2d_mode == 2)) && (g.N == 64 || g.N == 128) &&
+            (g.A.W % 16) == 0 && (g.A.H % 8) == 0 && g.A.zeros != nullptr;
+    if (t.t2d) {
+        t.halo = false;
+        t.bm = 128;
+        t.bn = 64;
+    } else if (t.halo) {
         t.bn = g.N >= 128 ? 128 : 64;
         // 128 rows x two blocks per CU where the k-loop is short (few channel chunks) and the row fits its halo buffer
         const bool fits128 = g.A.W <= halo_max_w(t.bn, 128);
@@ -1922,6 +2122,22 @@ namespace {
 template <int ACT>
 int launch_act(const KoafGemm& g, const TilePlan& tp, dim3 grid, hipStream_t s) {
     const bool vec = tp.vec;
+    if (tp.t2d) {
+        if constexpr (ACT == 3) { koaf_set_error("koaf_gemm: 2-D tile kernel with act16 = 3"); return KOAF_EINVAL; }
+        else {
+            hipLaunchKernelGGL((koaf_gemm_kernel<128, 64, M_PT, M_PS, 0, 0, true, true, 256, ACT>), grid, dim3(256), 0, s, g);
+            return koaf_check_launch("koaf_gemm/t2d");
+        }
+    }
+#ifdef KOAF_DEV_T2D      // (development builds: only the kernels a 3x3 A/B needs are instantiated -- seconds instead of minutes)
+    if (!tp.halo || tp.bm != 128) { koaf_set_error("koaf_gemm: KOAF_DEV_T2D build"); return KOAF_EINVAL; }
+    if constexpr (ACT != 0) { koaf_set_error("koaf_gemm: KOAF_DEV_T2D build"); return KOAF_EINVAL; }
+    else {
+        if (tp.bn == 128) hipLaunchKernelGGL((koaf_gemm_kernel<128, 128, M_PH, M_PS, 0, 0, true, true, 256, 0>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((koaf_gemm_kernel<128, 64, M_PH, M_PS, 0, 0, true, true, 256, 0>), grid, dim3(256), 0, s, g);
+        return koaf_check_launch("koaf_gemm/halo128");
+    }
+#else
     if (tp.halo) {
         // (the halo kernels read plane images: only their epilogue sees the storage type -- forward: the output; data
         // gradient: the BatchNorm-backward operands)
@@ -1952,6 +2168,7 @@ int launch_act(const KoafGemm& g, const TilePlan& tp, dim3 grid, hipStream_t s) 
     if (tp.bm == 128 && tp.bn == 64) return launch_modes<128, 64, true, false, ACT>(g, grid, s);
     if (tp.bm == 64 && tp.bn == 128) return launch_modes<64, 128, true, false, ACT>(g, grid, s);
     return launch_modes<64, 64, true, false, ACT>(g, grid, s);
+#endif
 }
 }  // namespace
 
@@ -2002,7 +2219,12 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     }
     const TilePlan tp = plan_tiles(g);
     const bool vec = tp.vec;
-    KOAF_REQUIRE(((tp.bm == 64 || tp.bm == 128) && (tp.bn == 64 || tp.bn == 128)) || tp.halo, "koaf_gemm: tile must be 64|128");
+    KOAF_REQUIRE(!g.out_planes || (tp.vec && g.out_sc && g.out_sh && g.ldc == g.N && !(g.N & 7) && g.nb0 * g.nb1 == 1 && g.splitk == 1 && !g.cmap &&
+                                   !g.residual && !g.bnb_mode && g.out_ps == (int64_t)g.M * g.N && aligned16(g.out_planes) && aligned16(g.out_sc) &&
+                                   aligned16(g.out_sh)),
+                 "koaf_gemm: out_planes needs the vector epilogue of a plain forward call (ldc == N, N %% 8 == 0, no batch / split-K / row map / "
+                 "residual / BatchNorm-backward), out_ps == M * N and 16-B aligned out_planes / out_sc / out_sh");
+    KOAF_REQUIRE(((tp.bm == 64 || tp.bm == 128) && (tp.bn == 64 || tp.bn == 128)) || tp.halo || tp.t2d, "koaf_gemm: tile must be 64|128");
     if (g.A.gather || g.B.gather) KOAF_REQUIRE(vec, "koaf_gemm: gathered operands need aligned, C%%32==0 tensors");
     if (g.B.kind >= 2 || g.A.kind >= 2) KOAF_REQUIRE(vec, "koaf_gemm: pre-split operands need 16-B aligned images (and C %% 32 == 0 per tap)");
     if (g.B.kind == 1 && g.B.gather == 1)

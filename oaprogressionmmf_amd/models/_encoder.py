@@ -65,7 +65,23 @@ def _can_take_tail(blk):
 KEEP_PLANES_RECOMPUTE = os.environ.get("KOAF_KEEP_PLANES_RECOMPUTE", "1") != "0"
 
 
-def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None, tail_idt=None, tail_out=None, tail_idsaved=None, keep_planes=False):
+# The plane images a 3x3 convolution gathers from are cut by the epilogue of the convolution that PRODUCES its input whenever the
+# BatchNorm between the two is already known -- eval mode, and every stage rebuilt in backward from its saved statistics -- instead
+# of by a pass of their own over the stored tensor (ops.conv2d_fwd emit; koaf.h KoafEmit).  KOAF_EMIT_PLANES=0 keeps the pass.
+EMIT_PLANES = os.environ.get("KOAF_EMIT_PLANES", "1") != "0"
+
+
+def _takes_planes(conv):
+    """does this convolution gather its input from activation plane images (ops.conv2d_fwd's own rule)?"""
+    if not (EMIT_PLANES and ops.CONV_F16 and (ops.APLANES_MASK & 1)):
+        return False
+    if conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.groups != 1:
+        return False
+    img = weight_planes(conv.weight)
+    return img is not None and img[0] is not None and ops.use_aplanes(img, 3, 3, conv.in_channels)
+
+
+def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None, tail_idt=None, tail_out=None, tail_idsaved=None, keep_planes=False, emit=None):
     """bn: the BatchNorm that consumes this conv's output statistics; tail_idt: x / in_saved are the previous block's last
     conv output and BatchNorm, tail_idt its identity -- the input is their bottleneck tail, formed on load (then the sixth
     return value is that input, written by the convolution)"""
@@ -78,11 +94,11 @@ def _conv_fwd(x, conv, N, H, W, in_saved, train, bn=None, tail_idt=None, tail_ou
     if tail_idt is not None:
         y, part, yin = ops.conv2d_fwd(x, w, N, H, W, cin, cout, k, k, s, p, sc, sh, stats=train, shift=shift,
                                       wimg=weight_planes(conv.weight), tail_idt=tail_idt, tail_out=tail_out,
-                                      tail_idsaved=tail_idsaved)
+                                      tail_idsaved=tail_idsaved, emit=emit)
         return y, part, ops.conv_out(H, k, s, p), ops.conv_out(W, k, s, p), wexp, yin
     if g == 1:
         y, part = ops.conv2d_fwd(x, w, N, H, W, cin, cout, k, k, s, p, sc, sh, stats=train, shift=shift,
-                                 wimg=weight_planes(conv.weight), keep_planes=keep_planes)
+                                 wimg=weight_planes(conv.weight), keep_planes=keep_planes, emit=emit)
     else:
         if k != 3 or p != 1 or cin != cout:
             raise NotImplementedError("grouped convolution other than the ResNeXt 3x3 is not built")
@@ -301,13 +317,19 @@ def _block_fwd(blk, y, N, Hc, Wc, train, given, tail=None, defer=False, skip_tai
         return given[idx] if given is not None else _bn_fin(bn, part, count)
     if isinstance(blk, Bottleneck):
         r.kind = "bottleneck"
+        # bn1 known before conv1 runs (rebuild: saved statistics; eval: running statistics): conv1's epilogue cuts conv2's
+        # plane images (same kernels, same bits -- test_stage_recompute_matches_stored_activations)
+        s1_pre, emit = None, None
+        if not want and _takes_planes(blk.conv2) and blk.conv1.groups == 1 and weight_planes(blk.conv1.weight) is not None:
+            s1_pre = fin(blk.bn1, None, N * Hc * Wc, 0)
+            emit = (s1_pre[2], s1_pre[3])
         if tail is not None:
             r.c1, part, _, _, _, y = _conv_fwd(tail[0], blk.conv1, N, Hc, Wc, tail[1], want, blk.bn1, tail_idt=tail[2], tail_out=tail[3],
-                                               tail_idsaved=tail[4])
+                                               tail_idsaved=tail[4], emit=emit)
             r.yin = y
         else:
-            r.c1, part, _, _, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, want, blk.bn1)
-        r.s1 = fin(blk.bn1, part, N * Hc * Wc, 0)
+            r.c1, part, _, _, _ = _conv_fwd(y, blk.conv1, N, Hc, Wc, None, want, blk.bn1, emit=emit)
+        r.s1 = s1_pre if s1_pre is not None else fin(blk.bn1, part, N * Hc * Wc, 0)
         # (rebuilt in backward: the plane images cut for conv2 live on until its weight gradient, a few kernels later, instead of
         # being cut again -- in the forward pass proper they would have to survive the whole step)
         r.c2, part, OH, OW, r.wexp = _conv_fwd(r.c1, blk.conv2, N, Hc, Wc, r.s1, want, blk.bn2,

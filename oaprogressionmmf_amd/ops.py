@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from ._lib import KoafBnApply, KoafBnb, KoafGemm, KoafError, KoafTail, KoafWImg, check, lib
+from ._lib import KoafBnApply, KoafBnb, KoafEmit, KoafGemm, KoafError, KoafTail, KoafWImg, check, lib
 
 _i32 = ctypes.c_int32
 
@@ -63,6 +63,7 @@ def _ptr(t):
 
 
 _STATUS = None       # device int32[4]: the library's numerics status words (koaf.h koaf_set_status_buffer)
+_STATUS_DEV = None   # the device they live on: the library holds ONE pointer, the one of the device this process computes on
 
 
 def _a16(t):
@@ -71,16 +72,24 @@ def _a16(t):
 
 
 def _stream():
-    if _STATUS is None:
+    if _STATUS is None or _STATUS_DEV != torch.cuda.current_device():
         _status_buffer()
     return torch.cuda.current_stream().cuda_stream
 
 
+_STATUS_BY_DEV = {}
+
+
 def _status_buffer():
-    """register (once per process = per GPU) the status words every kernel launch may bump"""
-    global _STATUS
-    if _STATUS is None:
-        _STATUS = torch.zeros(4, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    """register the status words every kernel launch may bump: one buffer per device, the library pointing at the CURRENT
+    device's (one process = one GPU is the product's layout; a process that moves to another device re-registers there instead
+    of letting that device's kernels add into a peer's memory)"""
+    global _STATUS, _STATUS_DEV
+    d = torch.cuda.current_device()
+    if _STATUS is None or _STATUS_DEV != d:
+        if d not in _STATUS_BY_DEV:
+            _STATUS_BY_DEV[d] = torch.zeros(4, dtype=torch.int32, device=torch.device("cuda", d))
+        _STATUS, _STATUS_DEV = _STATUS_BY_DEV[d], d
         check(lib().koaf_set_status_buffer(_STATUS.data_ptr()), "set_status_buffer")
     return _STATUS
 
@@ -91,6 +100,7 @@ def numerics_status(reset=False):
     (|x| > 4094) and were clamped, or were not finite; nonfinite: NaN / Inf that reached an operand's scale scalar (the GEMM
     then returned NaN everywhere) or a BatchNorm's coefficients."""
     st = _status_buffer()
+    torch.cuda.synchronize(st.device)        # (encoder lanes / side streams add too: every stream of the device has landed)
     v = st.cpu().tolist()
     if reset:
         st.zero_()
@@ -192,7 +202,7 @@ def use_aplanes(wimg, KH, KW, C):
 
 
 def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=None, stats=False, shift=None, wimg=None,
-               aplanes=None, tail_idt=None, tail_out=None, tail_idsaved=None, keep_planes=False):
+               aplanes=None, tail_idt=None, tail_out=None, tail_idsaved=None, keep_planes=False, emit=None):
     """x [N,H,W,Cin] (any view with that memory), w packed [Cout,KH,KW,Cin] -> y [N,OH,OW,Cout],
     (part, rows) per-tile column statistics if stats, summed about `shift` [Cout] (hand the same tensor to bn_finalize).
     wimg = (F, D, amax) plane images of w (arena.weight_planes) or None: with them the contraction runs on the fp16
@@ -201,7 +211,11 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     coefficients and tail_idt that block's identity: the input y = relu(in_sc*x + in_sh + tail_idt) (the bottleneck tail) is
     formed on load and written to tail_out (allocated here when None); returns (y, part, tail_out).  tail_idsaved: the block had a
     downsample branch -- tail_idt is that branch's raw conv output and tail_idsaved its BatchNorm record (mean, invstd, sc, sh).
-    keep_planes: the activation plane images cut for this call stay attached to the output for its weight gradient."""
+    keep_planes: the activation plane images cut for this call stay attached to the output for its weight gradient.
+    emit = (sc, sh): the coefficients of the BatchNorm BEHIND this convolution are already known (eval mode, a stage rebuilt in
+    backward): the epilogue also cuts the plane images of relu(sc*y + sh) -- bit for bit what the following 3x3 convolution's
+    act_planes pre-pass would cut after reading y back -- and leaves them on the output (y._koaf_eplanes), where that convolution
+    finds them."""
     L = lib()
     OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
     if tail_idt is not None and tail_out is None:
@@ -226,15 +240,29 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
     if torch.is_tensor(aplanes):
         xpl = aplanes                   # images cut by the caller (act_planes with this call's transform and ACT_SCALE)
     elif aplanes:
-        xpl = act_planes(x, N * H * W, Cin, 1 if in_sc is not None else 0, in_sc, in_sh, fscale=ACT_SCALE)
+        ep = getattr(x, "_koaf_eplanes", None)
+        if ep is not None:              # (consumed once: the images live on with the convolution that takes them)
+            del x._koaf_eplanes
+        if (ep is not None and in_sc is not None and ep[1] is in_sc and ep[2] is in_sh
+                and ep[0].numel() == L.koaf_act_planes_elems(N * H * W, Cin)):
+            xpl = ep[0]                 # cut by the producing convolution's epilogue (emit): no pre-pass over x
+        else:
+            xpl = act_planes(x, N * H * W, Cin, 1 if in_sc is not None else 0, in_sc, in_sh, fscale=ACT_SCALE)
+    epl, em = None, None
+    if emit is not None:
+        epl = torch.empty(L.koaf_act_planes_elems(N * OH * OW, Cout), device=x.device, dtype=torch.int16)
+        em = ctypes.byref(KoafEmit(planes=epl.data_ptr(), sc=_ptr(emit[0]), sh=_ptr(emit[1])))
     check(L.koaf_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), N, H, W, Cin, Cout, KH, KW, stride, pad, _ptr(in_sc),
                             _ptr(in_sh), _ptr(part), ctypes.addressof(rows), _ptr(shift) if stats else None,
-                            _img(wimg), xpl.data_ptr() if xpl is not None else None, tail, _a16(x), _stream()), "conv2d_fwd")
+                            _img(wimg), xpl.data_ptr() if xpl is not None else None, tail, em, _a16(x), _stream()), "conv2d_fwd")
+    if epl is not None:
+        y._koaf_eplanes = (epl, emit[0], emit[1])
     if xpl is not None and not torch.is_tensor(aplanes) and (keep_planes or xpl.numel() <= KEEP_XPLANES_ELEMS):
         y._koaf_xplanes = xpl       # ride on the output: this conv's weight gradient reads them instead of cutting them again
     _prof_end(e0, "gemm", 2.0 * N * OH * OW * Cout * KH * KW * Cin,
               f"conv_fwd k{KH}s{stride} {Cin}->{Cout} px{N*OH*OW}" + (" +tail" if tail is not None else ""),
-              N * H * W * Cin * (3 if tail is not None else 1) + Cout * KH * KW * Cin + N * OH * OW * Cout, mpp=3 if wimg is not None else 6)
+              N * H * W * Cin * (3 if tail is not None else 1) + Cout * KH * KW * Cin + N * OH * OW * Cout * (2 if epl is not None else 1),
+              mpp=3 if wimg is not None else 6)
     if stats:
         part = part[:rows.value]
     if tail is not None:

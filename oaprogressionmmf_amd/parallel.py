@@ -156,6 +156,8 @@ class DataParallelRCCL(nn.Module):
         if timed:
             e1.record()
             self._exposed.append((e0, e1))
+            if len(self._exposed) > 4096:           # (never drained by the caller: keep the newest, the list must not grow with the run)
+                del self._exposed[:-1024]
         self._handles = []
 
     def exposed_ms(self, reset=True):
@@ -177,7 +179,7 @@ class DataParallelRCCL(nn.Module):
         return self.module.load_state_dict(*a, **k)
 
 
-def shard_sampler(weights, rank, world, seed, num_samples=None, batch_size=None, drop_last=True):
+def shard_sampler(weights, rank, world, seed, num_samples=None, batch_size=None, drop_last=True, equal=False):
     """This rank's share of ONE global `WeightedRandomSampler` stream (SURVEY 8e "one-time": per-rank data shards from one
     global sampler; reference: koafusion/datasets/_data_provider.py:463-483 builds
     `WeightedRandomSampler(weights, num_samples=len(weights), replacement=True)` for the single-process DataParallel run).
@@ -190,6 +192,10 @@ def shard_sampler(weights, rank, world, seed, num_samples=None, batch_size=None,
         reference's train loaders, :483) the ragged tail that cannot fill a global batch is dropped, so all ranks run the
         same number of steps;
       * batch_size None: the strided slice stream[rank::world] (truncated to equal lengths under drop_last).
+    drop_last=False is for EVALUATION only: the ragged tail is split over the leading ranks, so shard lengths differ -- under a
+    gradient exchange (DataParallelRCCL) ranks with different step counts hang in the last collective.  With `equal=True` the
+    tail is instead padded by wrapping around to the start of the stream, every rank gets the same number of indices (a few
+    samples are seen twice, as torch's DistributedSampler does); training loops that must keep every sample use that.
     Returns a list of python ints to hand to `DataLoader(sampler=...)` / `Subset`."""
     if not (0 <= rank < world):
         raise ValueError(f"rank {rank} outside world {world}")
@@ -198,6 +204,11 @@ def shard_sampler(weights, rank, world, seed, num_samples=None, batch_size=None,
     g = torch.Generator()
     g.manual_seed(int(seed))
     stream = torch.multinomial(w, n, replacement=True, generator=g).tolist()     # what WeightedRandomSampler.__iter__ draws
+    if equal and not drop_last:
+        unit = world if batch_size is None else int(batch_size) * world
+        if n % unit:
+            stream = stream + stream[:unit - n % unit]        # wrap around: equal shard lengths on every rank
+            n = len(stream)
     if batch_size is None:
         if drop_last:
             stream = stream[:n - n % world]

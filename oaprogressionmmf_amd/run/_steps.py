@@ -36,6 +36,19 @@ def train_step(model, loss_fn, optimizer, xs, ys, downscale=None):
     return logits.detach(), loss.detach()
 
 
+def train_epoch(model, loss_fn, optimizer, batches, downscale=None):
+    """the optimize branch of `ProgressionPrediction.train_epoch` (train_prog_fus.py:132-168) over an iterable of (xs, ys) device
+    batches: one train_step each, the losses read back once at the end (no per-step host sync), and ONE look at the numerics
+    status words per epoch (ops.check_numerics: clamped activations / non-finite operand scales raise a RuntimeWarning).
+    Returns the list of per-step losses (python floats)."""
+    losses = []
+    for xs, ys in batches:
+        losses.append(train_step(model, loss_fn, optimizer, xs, ys, downscale)[1])
+    out = [float(v) for v in torch.stack(losses).cpu()] if losses else []
+    ops.check_numerics()
+    return out
+
+
 def softmax_rows_(x):
     """in-place row softmax of a contiguous fp32 (rows, n) device tensor (koaf_softmax_rows)"""
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 2):

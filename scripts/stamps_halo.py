@@ -39,7 +39,7 @@ for (N_, H, W, Cin, Cout) in shapes:
     fl = 2.0 * N_ * H * W * Cout * 9 * Cin
     img = ops.build_weight_planes(w, Cout, 9, Cin)
     pl = ops.act_planes(x, N_ * H * W, Cin, 1, sc, sh, fscale=16.0)
-    for halo, name in ((2, "halo256"), (3, "halo128")):
+    for halo, name in ((2, "halo256"), (3, "halo128"), (1, "auto (2-D tiles for 64 channels)")):
         ops.set_conv3x3_halo(halo)
         for st in (True, False):
             t, b = timeit(lambda: ops.conv2d_fwd(x, w, N_, H, W, Cin, Cout, k, k, s, p, sc, sh, stats=st, wimg=img, aplanes=pl))

@@ -532,14 +532,18 @@ def test_fp16_scheme_weight_images_bit_identical(dev, N, H, W, Cin, Cout, k, s, 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,s,p", [(3, 19, 17, 64, 64, 3, 1, 1), (2, 20, 20, 128, 128, 3, 2, 1), (7, 24, 24, 64, 128, 3, 1, 1),
                                                   (2, 9, 31, 256, 64, 3, 1, 1), (1, 5, 5, 32, 64, 3, 1, 1), (2, 21, 21, 64, 64, 3, 2, 1),
-                                                  (1, 7, 120, 64, 64, 3, 1, 1), (3, 96, 96, 64, 64, 3, 1, 1), (5, 12, 12, 512, 256, 3, 1, 1)])
+                                                  (1, 7, 120, 64, 64, 3, 1, 1), (3, 96, 96, 64, 64, 3, 1, 1), (5, 12, 12, 512, 256, 3, 1, 1),
+                                                  (2, 48, 48, 128, 128, 3, 1, 1), (1, 8, 16, 64, 64, 3, 1, 1), (3, 24, 32, 128, 64, 3, 1, 1),
+                                                  (2, 16, 16, 64, 128, 3, 1, 1)])
 def test_activation_plane_images(dev, N, H, W, Cin, Cout, k, s, p):
     """3x3 conv forward with the INPUT tiles DMA'd from activation plane images (koaf_act_planes: BatchNorm + ReLU prologue
     cut once into fp16 piece planes).  Per-tap gather kernel (global_load_lds of one pixel's 8 channels per lane, padding
     from the zero chunk): the same bits -- output and BatchNorm statistics -- as the fp32 loader that converts every element
     once per filter tap.  Halo kernel (stride 1, rows <= 96 pixels: 256-pixel raster tiles, all nine taps read from one
     LDS-resident pixel range, off-image taps masked in registers): the same sums reassociated, so equal to fp32 rounding
-    and equally close to float64.  Ragged last tiles, stride 2, images smaller than a tile, rows too wide for the halo."""
+    and equally close to float64.  Ragged last tiles, stride 2, images smaller than a tile, rows too wide for the halo.
+    64- / 128-channel layers whose images are whole 8 x 16 pixel tiles run the rectangle-tile kernel (M_PT: zero-filled halo, weight
+    fragments straight into registers) under the per-layer choice (mode 1): the last four shapes and 96 x 96."""
     from oaprogressionmmf_amd import ops
     x = rnd(N, H, W, Cin).to(dev)
     w = rnd(Cout, k, k, Cin, scale=(k * k * Cin) ** -0.5).to(dev)
@@ -845,6 +849,40 @@ def test_losses_on_spatial_logits_with_class_weights_vs_reference(dev):
         assert rel_err(x.grad, torch.from_numpy(g[f"{tag}:ce:dlogits"])) < 1e-5
 
 
+def test_losses_ignore_index_and_bad_labels(dev):
+    """targets outside [0, C): -100 (F.cross_entropy's default ignore_index, which the reference's losses inherit:
+    koafusion/various/_losses.py:36,101) gives zero loss and zero gradient; the cross-entropy mean leaves the element out of its
+    denominator, the focal loss (reduction 'none', then .mean(): :101-108) still divides by every element.  Any other bad label
+    is handled the same way and counted in the numerics status words instead of reading out of bounds."""
+    from oaprogressionmmf_amd import ops
+    B, C = 37, 3
+    lg = rnd(B, C) * 2
+    tg = torch.randint(0, C, (B,), generator=G)
+    tg[[3, 11, 30]] = -100
+    cw = torch.tensor([0.5, 2.0, 1.25])
+    for w in (None, cw):
+        x = lg.clone().double().requires_grad_(True)
+        ce = F.cross_entropy(x, tg, weight=None if w is None else w.double())
+        ce.backward()
+        loss, dl = ops.focal_loss(lg.to(dev), tg.to(dev), 0.0, focal=False, class_weight=None if w is None else w.to(dev))
+        assert abs(loss.item() - ce.item()) < 2e-6 and rel_err(dl.cpu(), x.grad) < 1e-5
+        for mean in (True, False):
+            x = lg.clone().double().requires_grad_(True)
+            logpt = -F.cross_entropy(x, tg, weight=None if w is None else w.double(), reduction="none")
+            fl = -((1 - logpt.exp()) ** 2.0) * logpt
+            fl = fl.mean() if mean else fl.sum()
+            fl.backward()
+            loss, dl = ops.focal_loss(lg.to(dev), tg.to(dev), 2.0, mean=mean, class_weight=None if w is None else w.to(dev))
+            assert abs(loss.item() - fl.item()) < 2e-6 * max(1.0, abs(fl.item())) and rel_err(dl.cpu(), x.grad) < 1e-5
+            assert float(dl[[3, 11, 30]].abs().max()) == 0.0
+    ops.numerics_status(reset=True)
+    bad = tg.clone()
+    bad[5] = 7
+    loss, dl = ops.focal_loss(lg.to(dev), bad.to(dev), 2.0)
+    assert torch.isfinite(loss).item() and float(dl[5].abs().max()) == 0.0
+    assert ops.numerics_status(reset=True)["nonfinite"] == 1
+
+
 def test_interpolate_any_scale_vs_reference(dev):
     """PTInterpolate for any scale factor (the reference hands the config's `downscale` to F.interpolate: _pt.py:175-192):
     odd sizes, up- and down-scaling, several channels, the (B, CH, D0) linear rank -- fixture F8's extension; the mask branch
@@ -929,3 +967,38 @@ def test_stem_backward_without_the_pool_gradient_and_dc_tensors(dev):
     ops.stem_wgrad(dc_ref, x, dw0, N, H, W)
     ops.stem_wgrad(ap, x, dw1, N, H, W)
     assert rel_err(dw1, dw0.double()) < 2e-6
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,bf16", [(3, 24, 24, 256, 64, False), (2, 17, 19, 64, 64, False), (1, 5, 5, 128, 128, False),
+                                                 (3, 24, 24, 256, 64, True)])
+def test_conv_epilogue_emits_the_consumer_plane_images(dev, N, H, W, Cin, Cout, bf16):
+    """KoafEmit: a forward convolution whose OUTPUT BatchNorm is already known (eval mode, rebuilt stages) cuts the plane images
+    of relu(sc * y + sh) in its epilogue -- the same bits as koaf_act_planes over the stored y (fp32 and bf16 storage, full and
+    ragged last tiles, persistent 1x1 kernels), zero chunk included -- and the following 3x3 convolution picks them up instead
+    of running the pre-pass: same output bits."""
+    from oaprogressionmmf_amd import ops
+    dt = torch.bfloat16 if bf16 else torch.float32
+    x = rnd(N, H, W, Cin).to(dev).to(dt)
+    w = rnd(Cout, 1, 1, Cin, scale=Cin ** -0.5).to(dev)
+    isc, ish = (rnd(Cin) * 0.2 + 1).to(dev), (rnd(Cin) * 0.1).to(dev)
+    osc, osh = (rnd(Cout) * 0.3 + 1).to(dev), (rnd(Cout) * 0.2).to(dev)
+    img = ops.build_weight_planes(w, Cout, 1, Cin)
+    y0, _ = ops.conv2d_fwd(x, w, N, H, W, Cin, Cout, 1, 1, 1, 0, isc, ish, wimg=img)
+    y1, _ = ops.conv2d_fwd(x, w, N, H, W, Cin, Cout, 1, 1, 1, 0, isc, ish, wimg=img, emit=(osc, osh))
+    assert torch.equal(y0, y1)
+    got = y1._koaf_eplanes[0]
+    ref = ops.act_planes(y0, N * H * W, Cout, 1, osc, osh, fscale=ops.ACT_SCALE)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    # the consumer: a 3x3 convolution over y1 finds the images (and consumes them), over y0 it cuts its own
+    w3 = rnd(Cout, 3, 3, Cout, scale=(9 * Cout) ** -0.5).to(dev)
+    img3 = ops.build_weight_planes(w3, Cout, 9, Cout)
+    a, _ = ops.conv2d_fwd(y0, w3, N, H, W, Cout, Cout, 3, 3, 1, 1, osc, osh, wimg=img3)
+    b, _ = ops.conv2d_fwd(y1, w3, N, H, W, Cout, Cout, 3, 3, 1, 1, osc, osh, wimg=img3, keep_planes=True)
+    assert torch.equal(a, b) and not hasattr(y1, "_koaf_eplanes") and b._koaf_xplanes is got
+    # the bottleneck-tail form of conv1 (tf 3) emits as well
+    if not bf16:
+        idt = rnd(N, H, W, Cin).to(dev)
+        t0 = ops.conv2d_fwd(x, w, N, H, W, Cin, Cout, 1, 1, 1, 0, isc, ish, wimg=img, tail_idt=idt)
+        t1 = ops.conv2d_fwd(x, w, N, H, W, Cin, Cout, 1, 1, 1, 0, isc, ish, wimg=img, tail_idt=idt, emit=(osc, osh))
+        assert torch.equal(t0[0], t1[0]) and torch.equal(t0[2], t1[2])
+        assert torch.equal(t1[0]._koaf_eplanes[0], ops.act_planes(t0[0], N * H * W, Cout, 1, osc, osh, fscale=ops.ACT_SCALE))

@@ -143,6 +143,13 @@ def test_shard_sampler_slices_one_global_stream():
     # without drop_last nothing of the stream is lost
     all_ = [shard_sampler(w, r, world, seed=77, batch_size=B, drop_last=False) for r in range(world)]
     assert sorted(sum(all_, [])) == sorted(glob)
+    # ... but the shard lengths then differ (evaluation only); equal=True pads by wrapping around: same length on every rank
+    assert len({len(a) for a in all_}) > 1
+    eq = [shard_sampler(w, r, world, seed=77, batch_size=B, drop_last=False, equal=True) for r in range(world)]
+    assert len({len(a) for a in eq}) == 1 and len(eq[0]) == (steps + 1) * B
+    assert sum((eq[r][steps * B:] for r in range(world)), []) == (glob + glob)[steps * B * world:(steps + 1) * B * world]
+    eqs = [shard_sampler(w, r, 2, seed=77, drop_last=False, equal=True) for r in range(2)]
+    assert len(eqs[0]) == len(eqs[1]) == 32 and eqs[1][-1] == glob[0]
     # strided variant; another epoch = another seed = another stream; bad rank raises
     st = [shard_sampler(w, r, 2, seed=77) for r in range(2)]
     assert st[0] == glob[0:62:2] and st[1] == glob[1:62:2]
