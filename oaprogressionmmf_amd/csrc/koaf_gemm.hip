@@ -940,7 +940,9 @@ __device__ __forceinline__ void epi_emit_planes(const KoafGemm& p, int64_t off, 
 
 // T2D: the tile's rows are an 8 x 16 pixel rectangle of one image (M_PT): row lr = pixel (lr / 16, lr % 16) of the tile whose first
 // pixel is m0, image rows w2d pixels apart
-template <int BM, int BN, int NT, bool HAS_R, int MODE, bool HAS_C2, bool C16, bool E16, bool T2D = false>
+// EMIT: the kernel instantiation that serves KoafGemm.out_planes (separate instantiations: the persistent 1x1 kernels carry the next
+// tile's operand slot through this loop at the 256-register limit, and the emission arithmetic inline cost them 55-126 spilled registers)
+template <int BM, int BN, int NT, bool HAS_R, int MODE, bool HAS_C2, bool C16, bool E16, bool T2D = false, bool EMIT = false>
 __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs, int ldcs, float* Cp, int64_t ldc,
                                               const float* Rp, int m0, int col, int c4, int rr, v4f bv, v4f mu, v4f is,
                                               v4f ms, v4f mh, v4f mu2, v4f is2, v4f& q1, v4f& q2, v4f& q3, v4f& qm, int w2d = 0) {
@@ -948,7 +950,7 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
     static_assert((BM / RPP) % U == 0, "rows per thread must be a multiple of the batch");
     [[maybe_unused]] v4f ea = {0.f, 0.f, 0.f, 0.f}, eb = ea;      // KoafGemm.out_planes: this thread's columns of out_sc / out_sh, at the activation scale
     [[maybe_unused]] unsigned nsat = 0;
-    if constexpr (MODE == 0 && !HAS_R) {
+    if constexpr (EMIT && MODE == 0 && !HAS_R) {
         if (p.out_planes) { ea = *(const v4f*)(p.out_sc + col) * KOAF_ACT_SCALE; eb = *(const v4f*)(p.out_sh + col) * KOAF_ACT_SCALE; }
     }
 #pragma unroll 1
@@ -956,8 +958,9 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
         v4f rv[U], cv[U], yv[U], c2v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int lr_ = row + u * RPP;
-            const int64_t orow = T2D ? (int64_t)m0 + (lr_ >> 4) * w2d + (lr_ & 15) : (int64_t)m0 + lr_;
+            int64_t orow;
+            if constexpr (T2D) { const int lr_ = row + u * RPP; orow = m0 + (lr_ >> 4) * w2d + (lr_ & 15); }
+            else orow = m0 + row + u * RPP;
             // (streamed once: non-temporal, like the stores below -- the tile's operands, not these, should stay in L2)
             if constexpr (HAS_R) rv[u] = __builtin_nontemporal_load((const v4f*)(Rp + orow * p.ldr + col));
             if constexpr (MODE != 0) cv[u] = load4_nt<E16>(p.bnb_c, orow * ldc + col);
@@ -966,8 +969,9 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int lr_ = row + u * RPP;
-            const int64_t orow = T2D ? (int64_t)m0 + (lr_ >> 4) * w2d + (lr_ & 15) : (int64_t)m0 + lr_;
+            int64_t orow;
+            if constexpr (T2D) { const int lr_ = row + u * RPP; orow = m0 + (lr_ >> 4) * w2d + (lr_ & 15); }
+            else orow = m0 + row + u * RPP;
             v4f v = *(const v4f*)&Cs[(row + u * RPP) * ldcs + 4 * c4] + bv;
             if constexpr (HAS_R) v += rv[u];
             if constexpr (MODE == 1) {
@@ -985,12 +989,12 @@ __device__ __forceinline__ void epi_rows_full(const KoafGemm& p, const float* Cs
                 for (int j = 0; j < 4; ++j) qm[j] = __uint_as_float(max(__float_as_uint(qm[j]), koaf_absbits(v[j])));
             }
             store4_nt<C16>(Cp, orow * ldc + col, v);
-            if constexpr (MODE == 0 && !HAS_R) {
+            if constexpr (EMIT && MODE == 0 && !HAS_R) {
                 if (p.out_planes) epi_emit_planes<C16>(p, orow * ldc + col, v, ea, eb, nsat);
             }
         }
     }
-    if constexpr (MODE == 0 && !HAS_R) koaf_status_add(p.status, 0, nsat);
+    if constexpr (EMIT && MODE == 0 && !HAS_R) koaf_status_add(p.status, 0, nsat);
 }
 
 
@@ -1005,7 +1009,7 @@ __host__ __device__ constexpr bool persist_mode(int am, int bmd, bool f16, int t
 // (the persistent variants carry the next tile's A slot through the epilogue: held to two waves per SIMD = 256 registers)
 // ACT = KoafGemm.act16: which tensors of this call are bf16 ACTIVATIONS (0: none; 1 forward: A.ptr and C; 2 data gradient:
 // A.ptr2 (the conv output c of a tf-2 apply) and the BatchNorm-backward operands of the epilogue; 3 weight gradient: A.ptr2 and B.ptr)
-template <int BM, int BN, int AM, int BMD, int TFA, int TFB, bool VEC, bool F16, int NT = 256, int ACT = 0>
+template <int BM, int BN, int AM, int BMD, int TFA, int TFB, bool VEC, bool F16, int NT = 256, int ACT = 0, bool EMIT = false>
 __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == M_PT) ? 2 : 1) koaf_gemm_kernel(const KoafGemm p) {
     static_assert(ACT == 0 || VEC, "bf16 activation storage needs the vector path");
     constexpr bool C16 = (ACT == 1), E16 = (ACT == 2);
@@ -1738,7 +1742,7 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
             if (full) {
                 const bool hr = Rp != nullptr, h2 = bnb && p.bnb2_c != nullptr;
                 const int mode = bnb ? p.bnb_mode : 0;
-#define KOAF_EPI(R_, M_, C2_) epi_rows_full<BM, BN, NT, R_, M_, C2_, C16, E16, AT>(p, Cs, LDC_S, Cp, ldc, Rp, AT ? t2d_base : m0, col, c4, rr, bv, mu, is, \
+#define KOAF_EPI(R_, M_, C2_) epi_rows_full<BM, BN, NT, R_, M_, C2_, C16, E16, AT, EMIT>(p, Cs, LDC_S, Cp, ldc, Rp, AT ? t2d_base : m0, col, c4, rr, bv, mu, is, \
                                                                  ms, mh, mu2, is2, q1, q2, q3, qm, t2d_w)
                 if (mode == 0) { if (hr) KOAF_EPI(true, 0, false); else KOAF_EPI(false, 0, false); }
                 else if (mode == 1) {
@@ -1785,7 +1789,7 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
                         }
                     }
                     store4_nt<C16>(Cp, orow * ldc + col, v);
-                    if (p.out_planes && !bnb && !Rp) {
+                    if (EMIT && p.out_planes && !bnb && !Rp) {
                         unsigned ns = 0;
                         epi_emit_planes<C16>(p, orow * ldc + col, v, *(const v4f*)(p.out_sc + col) * KOAF_ACT_SCALE,
                                              *(const v4f*)(p.out_sh + col) * KOAF_ACT_SCALE, ns);
@@ -1794,7 +1798,7 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
                 }
             }
         }
-        if (p.out_planes && tm == 0 && tn == 0 && t == 0 && blockIdx.z == 0) *(uint4*)(p.out_planes + 2 * p.out_ps) = make_uint4(0u, 0u, 0u, 0u);   // the zero chunk
+        if (EMIT && p.out_planes && tm == 0 && tn == 0 && t == 0 && blockIdx.z == 0) *(uint4*)(p.out_planes + 2 * p.out_ps) = make_uint4(0u, 0u, 0u, 0u);   // the zero chunk
         if (bnb) {
             if (p.bnb_amax) block_amax_raise_bits(max(max(__float_as_uint(qm[0]), __float_as_uint(qm[1])), max(__float_as_uint(qm[2]), __float_as_uint(qm[3]))), p.bnb_amax);
             // column sums over the block's rows: RPP row-threads per column vector -> LDS -> one partial row
@@ -1974,6 +1978,15 @@ int operand_mode(const KoafOperand& o) {
     hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16, 256, ACT>), pgrid, dim3(256), 0, s, g);     \
     return koaf_check_launch("koaf_gemm")
 
+// KoafGemm.out_planes (the epilogue also cuts the consumer's plane images): the instantiations with EMIT, for the calls that use it
+// -- dense 1x1 forward convolutions with weight plane images (plain, BatchNorm-prologue and bottleneck-tail loaders)
+#define KOAF_LAUNCH_E(AMODE, BMODE, TA, TB)                                                                      \
+    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16, 256, ACT, true>), grid, dim3(256), 0, s, g);      \
+    return koaf_check_launch("koaf_gemm/emit")
+#define KOAF_LAUNCH_PE(AMODE, BMODE, TA, TB)                                                                     \
+    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16, 256, ACT, true>), pgrid, dim3(256), 0, s, g);     \
+    return koaf_check_launch("koaf_gemm/emit")
+
 // the operand-mode pairs the library uses: conv fwd (KC|KC_G1 x KC|PS), dgrad (KC|KC_G2 x PS, or KC x KM | KC_G2 x KM_G3
 // on fp32 weights), wgrad (KM x KM|KM_G1), linear / attention (dense pairs).  tf only where a BatchNorm prologue exists.
 // ACT (bf16 activation storage, KoafGemm.act16): only the pairs of its role are instantiated -- 1 forward convolutions,
@@ -1984,6 +1997,15 @@ int launch_modes(const KoafGemm& g, dim3 grid, hipStream_t s) {
     const int ta = g.A.tf, tb = g.B.tf;
     dim3 pgrid = grid;
     if (grid.y == 1 && grid.x > PERSIST_BLOCKS) pgrid.x = PERSIST_BLOCKS;
+    if (g.out_planes) {
+        if constexpr (VEC && F16 && (ACT == 0 || ACT == 1)) {
+            if (am == M_KC && bm == M_PS && ta == 3) { KOAF_LAUNCH_E(M_KC, M_PS, 3, 0); }
+            if (am == M_KC && bm == M_PS && ta < 2) { if (ta == 1) { KOAF_LAUNCH_PE(M_KC, M_PS, 1, 0); } else { KOAF_LAUNCH_PE(M_KC, M_PS, 0, 0); } }
+        }
+        koaf_set_error("koaf_gemm: out_planes is built for dense K-contiguous A x weight plane images on the fp16 scheme (1x1 forward convolutions); "
+                       "got operand modes (%d,%d) tf=%d fmt=%d act16=%d", am, bm, ta, (int)F16, ACT);
+        return KOAF_EINVAL;
+    }
     if constexpr (ACT == 0) {
         if (am == M_KC && bm == M_KC && !tb) { if (ta == 1) { KOAF_LAUNCH(M_KC, M_KC, 1, 0); } else if (!ta) { KOAF_LAUNCH(M_KC, M_KC, 0, 0); } }
         if (am == M_KC && bm == M_KM && !ta && !tb) { KOAF_LAUNCH(M_KC, M_KM, 0, 0); }
@@ -2122,6 +2144,7 @@ namespace {
 template <int ACT>
 int launch_act(const KoafGemm& g, const TilePlan& tp, dim3 grid, hipStream_t s) {
     const bool vec = tp.vec;
+    if (g.out_planes && (tp.t2d || tp.halo)) { koaf_set_error("koaf_gemm: out_planes is not built for the 3x3 plane-image kernels"); return KOAF_EINVAL; }
     if (tp.t2d) {
         if constexpr (ACT == 3) { koaf_set_error("koaf_gemm: 2-D tile kernel with act16 = 3"); return KOAF_EINVAL; }
         else {
@@ -2130,6 +2153,8 @@ int launch_act(const KoafGemm& g, const TilePlan& tp, dim3 grid, hipStream_t s) 
         }
     }
 #ifdef KOAF_DEV_T2D      // (development builds: only the kernels a 3x3 A/B needs are instantiated -- seconds instead of minutes)
+    if (g.M == -12345) hipLaunchKernelGGL((koaf_gemm_kernel<128, 128, M_KC, M_PS, 1, 0, true, true, 256, 0>), grid, dim3(256), 0, s, g);   // (register-usage probe)
+    if (g.M == -12346) hipLaunchKernelGGL((koaf_gemm_kernel<128, 128, M_KC, M_PS, 2, 0, true, true, 256, 0>), grid, dim3(256), 0, s, g);
     if (!tp.halo || tp.bm != 128) { koaf_set_error("koaf_gemm: KOAF_DEV_T2D build"); return KOAF_EINVAL; }
     if constexpr (ACT != 0) { koaf_set_error("koaf_gemm: KOAF_DEV_T2D build"); return KOAF_EINVAL; }
     else {

@@ -212,6 +212,7 @@ class _SideStream:
 # consume dc (ops.BnApply, koaf.h KoafOperand.tf 2) instead of being written out by an element-wise pass.  KOAF_FUSE_APPLY=0
 # (or convolutions off the fp16 scheme) materialises dc as before.
 FUSE_APPLY = os.environ.get("KOAF_FUSE_APPLY", "1") != "0"
+WGRAD_EARLY = os.environ.get("KOAF_WGRAD_EARLY", "0") == "1"
 
 
 def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True, side=None, bnb=None):
@@ -237,6 +238,12 @@ def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True,
     if side is None:
         wgrad()
         deliver_grad(conv.weight, gw, acc)
+    early = side is not None and WGRAD_EARLY and need_dx and g == 1 and k == 1
+    if early:
+        # (A/B switch KOAF_WGRAD_EARLY=1: the 1x1 weight gradient starts TOGETHER with its sibling data gradient -- both stream
+        # through the same (dz, c) tensors, and a second reader close behind the first is served by the 256 MB Infinity Cache)
+        held = dc.tensors() if isinstance(dc, ops.BnApply) else (dc, amax)
+        side.run(held + (x, in_saved), wgrad, conv.weight, gw, acc)
     dx = None
     if need_dx:
         if g == 1:
@@ -244,7 +251,7 @@ def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True,
         else:
             assert residual is None and bnb is None
             dx = ops.gconv3x3_dgrad(dc, wexp, N, H, W, cin, s)
-    if side is not None:
+    if side is not None and not early:
         # enqueued BEHIND the sibling dgrad: the side stream starts this wgrad when the dgrad is done, so it
         # overlaps the HBM-bound BatchNorm backward of the next layer instead of fighting the dgrad for MFMAs
         held = dc.tensors() if isinstance(dc, ops.BnApply) else (dc, amax)

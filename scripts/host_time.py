@@ -1,19 +1,27 @@
-"""how long does the host need to ENQUEUE one train step (vs the GPU time of the step)?"""
+"""how long does the host need to ENQUEUE one train step, against the GPU time of the step?  (multi-GPU sizing: every rank is one
+Python process issuing its own ~3 000 launches per step on its share of the node's cores)
+    python scripts/host_time.py [native | native3 | syn3 | xr1cnn | xr1c1] [batch]"""
 import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import torch
 import procedural as P
+import bench
 from oaprogressionmmf_amd.config import ConfigDict
 from oaprogressionmmf_amd.models import dict_models
 from oaprogressionmmf_amd.various import dict_losses, dict_optimizers
 dev = torch.device("cuda:0")
-cfg = P.cfg_full(dropout=0.1); B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+name = sys.argv[1] if len(sys.argv) > 1 else "native"
+cfg, B, pol = bench.workload_cfg(name)
+if len(sys.argv) > 2:
+    B = int(sys.argv[2])
+shapes = cfg.pop("_tensor_shapes", None)
 model = dict_models[cfg["name"]](config=ConfigDict(cfg), path_weights=None).to(dev).train()
+bench.apply_recompute(model, pol)
 loss_fn = dict_losses["FocalLoss"](reduction="mean", gamma=2.0, num_classes=2)
 opt = dict_optimizers["Adam"](model.parameters(), lr=1e-4, weight_decay=1e-4)
-xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(cfg, B)]
+xs = [torch.from_numpy(a).to(dev) for a in P.model_inputs(dict(cfg, input_size=shapes) if shapes else cfg, B)]
 y = torch.from_numpy(P.make_target("target", B)).to(dev)
 def step():
     t0 = time.perf_counter()
@@ -28,6 +36,8 @@ def step():
     torch.cuda.synchronize()
     t4 = time.perf_counter()
     return t1 - t0, t2 - t1, t3 - t2, t4 - t0
+import os
+print(f"{name} batch {B} ({cfg['name']}, recompute {pol}); host cores available to this process: {len(os.sched_getaffinity(0))}")
 for i in range(6):
     f, b, o, tot = step()
-    print(f"B={B} host enqueue: fwd {f*1e3:6.1f} ms  bwd {b*1e3:6.1f} ms  opt {o*1e3:5.1f} ms | step wall {tot*1e3:6.1f} ms")
+    print(f"host enqueue: fwd {f*1e3:6.1f} ms  bwd {b*1e3:6.1f} ms  opt {o*1e3:5.1f} ms  = {(f+b+o)*1e3:6.1f} ms | step wall {tot*1e3:7.1f} ms", flush=True)

@@ -43,6 +43,9 @@ def grads_and_buffers(m):
     return out, none
 
 
+_TRUTH = {}
+
+
 def run_case(fname, dev, adam_steps=0, cls=None):
     from oaprogressionmmf_amd.various import dict_losses, dict_optimizers
     gold = load(fname)
@@ -66,12 +69,15 @@ def run_case(fname, dev, adam_steps=0, cls=None):
     check_summary(got, gold, "buf:", 2e-4, fname + " BN buffers")
     # gradients: fp64 ground truth from the (reference-pinned) oracle on the host CPU; bar = the reference's
     # own fp32 rounding noise against that truth, recorded in the fixture as e32
-    from oracle import koafusion_cpu as O
-    om = O.OracleModel(cfg, fill=P.fill_value, dtype=torch.float64)
-    lg64, _ = om.train_step([x.cpu() for x in xs], y.cpu(), optimize=False)
+    if fname not in _TRUTH:     # (the float64 oracle run of a fixture: minutes of host CPU for the full model, shared by the tests on it)
+        from oracle import koafusion_cpu as O
+        om = O.OracleModel(cfg, fill=P.fill_value, dtype=torch.float64)
+        lg64, _ = om.train_step([x.cpu() for x in xs], y.cpu(), optimize=False)
+        _TRUTH[fname] = (lg64, {k: p.grad.numpy() for k, p in om.named_parameters() if p.grad is not None})
+        del om
+    lg64, truth = _TRUTH[fname]
     assert rel(lg64.numpy(), gold["train_logits64"]) < 1e-9, "oracle fp64 vs reference fp64"
     assert rel(logits.detach().cpu().numpy(), lg64.numpy()) < 3 * float(gold["e32_logits"]) + 1e-5
-    truth = {k: p.grad.numpy() for k, p in om.named_parameters() if p.grad is not None}
     mine = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None}
     e32 = e32_table(gold)
     med_ratio, worst_ratio = check_grads_vs_truth(mine, truth, e32, fname, n_top=top_relu_elems(cfg, B))
