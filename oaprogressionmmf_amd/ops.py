@@ -243,8 +243,8 @@ def conv2d_fwd(x, w, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None, in_sh=
         ep = getattr(x, "_koaf_eplanes", None)
         if ep is not None:              # (consumed once: the images live on with the convolution that takes them)
             del x._koaf_eplanes
-        if (ep is not None and in_sc is not None and ep[1] is in_sc and ep[2] is in_sh
-                and ep[0].numel() == L.koaf_act_planes_elems(N * H * W, Cin)):
+        if (ep is not None and in_sc is not None and ep[1].data_ptr() == in_sc.data_ptr() and ep[2].data_ptr() == in_sh.data_ptr()
+                and ep[0].numel() == L.koaf_act_planes_elems(N * H * W, Cin)):      # (the same coefficient memory: rows of one BatchNorm record)
             xpl = ep[0]                 # cut by the producing convolution's epilogue (emit): no pre-pass over x
         else:
             xpl = act_planes(x, N * H * W, Cin, 1 if in_sc is not None else 0, in_sc, in_sh, fscale=ACT_SCALE)
