@@ -83,7 +83,7 @@ def test_trunk_on_imagenet_like_weights(dev, arch, shape):
             # (the oracle's own update ran with momentum 0.1 from the same start: undo it to get the batch statistic)
             start = t(P.imagenet_like_fill(k, tuple(b.shape))).double()
             batch = (ref - 0.9 * start) / 0.1
-            assert rel(b.numpy(), batch.numpy()) < 2e-4, k
+            assert rel(b.numpy(), batch.numpy()) < 1e-3, k
     trunk.eval()
     with torch.no_grad():
         ye = trunk(x)
