@@ -356,6 +356,10 @@ def cpu_baseline(workload):
                           f"= {t160:.0f} s",
                 "measured_s": {f"slices_{hi}": round(ts[hi], 2), f"slices_{lo}": round(ts[lo], 2)},
                 "extrapolated_s_per_knee": round(t160, 1), "host": why_n,
+                "extrapolation_validated": "the same line checked once against ONE train step at 144 slices per MRI on a GPU-box host (16 threads, "
+                                           "120.8 s measured vs 131.7 s predicted from the 32- and 16-slice steps: the line over-predicts by 9 %, "
+                                           "i.e. this baseline is ~9 % pessimistic for the CPU; profiles/r04_cpu_baseline_validation.log, "
+                                           "scripts/validate_cpu_baseline.py)",
                 "one_thread_footnote": {"value": round(1.0 / t160_1, 6), "unit": "knees/s", "cores": 1,
                                         "why": "the reference ships OMP_NUM_THREADS=1 (train_prog_fus.py:7-9)",
                                         "measured_s": {"slices_2": round(t1[2], 2), "slices_1": round(t1[1], 2)},

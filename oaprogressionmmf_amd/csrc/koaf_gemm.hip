@@ -1975,7 +1975,7 @@ int operand_mode(const KoafOperand& o) {
     return koaf_check_launch("koaf_gemm")
 // the persistent variants (fp32 A loader + weight tiles by DMA): at most two blocks per CU, each walking its tiles
 #define KOAF_LAUNCH_P(AMODE, BMODE, TA, TB)                                                                      \
-    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16, 256, ACT>), pgrid, dim3(256), 0, s, g);     \
+    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16, 256, ACT>), (persist_mode(AMODE, BMODE, F16, TA) ? pgrid : grid), dim3(256), 0, s, g);     \
     return koaf_check_launch("koaf_gemm")
 
 // KoafGemm.out_planes (the epilogue also cuts the consumer's plane images): the instantiations with EMIT, for the calls that use it
@@ -1984,7 +1984,7 @@ int operand_mode(const KoafOperand& o) {
     hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16, 256, ACT, true>), grid, dim3(256), 0, s, g);      \
     return koaf_check_launch("koaf_gemm/emit")
 #define KOAF_LAUNCH_PE(AMODE, BMODE, TA, TB)                                                                     \
-    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16, 256, ACT, true>), pgrid, dim3(256), 0, s, g);     \
+    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16, 256, ACT, true>), (persist_mode(AMODE, BMODE, F16, TA) ? pgrid : grid), dim3(256), 0, s, g);     \
     return koaf_check_launch("koaf_gemm/emit")
 
 // the operand-mode pairs the library uses: conv fwd (KC|KC_G1 x KC|PS), dgrad (KC|KC_G2 x PS, or KC x KM | KC_G2 x KM_G3
