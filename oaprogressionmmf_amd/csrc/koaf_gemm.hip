@@ -903,15 +903,23 @@ __device__ __forceinline__ void t2d_issue_halo(const KoafOperand& A, const unsig
     const int Wd = A.W, Hd = A.H, CSa = A.CS;
     const int txn = Wd >> 4, tpi = (Hd >> 3) * txn;          // tiles per image row / per image
     const int img = tm / tpi, trem = tm - img * tpi, tyi = trem / txn, txi = trem - tyi * txn;
+    // this lane's granule of its wave's first piece; every later piece is 256 granules = 32 halo pixels further on (one halo row and
+    // 14 pixels), the second plane 1440 granules = 10 halo rows back: the pixel is carried, not re-derived by divisions
+    int Gp = w * 64 + lane, q = 0;
+    const int cs = Gp & 7;
+    int y = (Gp >> 3) / 18, x = (Gp >> 3) - 18 * y;
+    const int iy0 = tyi * 8 - 1, ix0 = txi * 16 - 1;
+    const int64_t ibase = (int64_t)img * Hd * Wd;
 #pragma unroll 1
     for (int pc = w; pc < 45; pc += 4) {
-        const int G = pc * 64 + lane, q = G >= 1440 ? 1 : 0, Gp = G - 1440 * q;
-        const int hp = Gp >> 3, cs = Gp & 7, y = hp / 18, x = hp - 18 * y;
         const int c16 = cs ^ ((x >> 1) & 7);
-        const int iy = tyi * 8 - 1 + y, ix = txi * 16 - 1 + x;
+        const int iy = iy0 + y, ix = ix0 + x;
         const bool ok = (unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd;
-        const unsigned short* src = ok ? Apl + q * A.plane_stride + ((int64_t)(img * Hd + iy) * Wd + ix) * CSa + (chunk * 64 + c16 * 8) : A.zeros;
+        const unsigned short* src = ok ? Apl + q * A.plane_stride + (ibase + iy * Wd + ix) * CSa + (chunk * 64 + c16 * 8) : A.zeros;
         lds_dma16(src, halo0 + pc * 1024);
+        Gp += 256; x += 14; y += 1;
+        if (x >= 18) { x -= 18; y += 1; }
+        if (q == 0 && Gp >= 1440) { Gp -= 1440; q = 1; y -= 10; }
     }
 }
 

@@ -68,8 +68,9 @@ def eval_epoch(model, loader, modals, downscale=None, device="cuda", profile="no
         acc["target"].extend(torch.as_tensor(ys).to("cpu").numpy().tolist())
         acc["predict"].extend(torch.argmax(lg, dim=1).numpy().tolist())
         acc["predict_proba"].extend(proba.to("cpu").tolist())
-    from .. import ops
-    ops.check_numerics()         # once per pass: clamped activations / non-finite operand scales warn instead of staying silent
+    if acc:
+        from .. import ops
+        ops.check_numerics()     # once per pass: clamped activations / non-finite operand scales warn instead of staying silent
     return dict(acc)
 
 

@@ -45,7 +45,8 @@ def train_epoch(model, loss_fn, optimizer, batches, downscale=None):
     for xs, ys in batches:
         losses.append(train_step(model, loss_fn, optimizer, xs, ys, downscale)[1])
     out = [float(v) for v in torch.stack(losses).cpu()] if losses else []
-    ops.check_numerics()
+    if losses:
+        ops.check_numerics()
     return out
 
 
