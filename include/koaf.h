@@ -222,6 +222,14 @@ int koaf_wplanes_build(const float* base, uint16_t* planes, float* amax, const K
  * 2 / 3 force the 256- / 128-row shape where it fits (tests / A-B measurements); returns the previous mode.  Process-wide;
  * not meant to be flipped while other threads launch. */
 int koaf_set_conv3x3_halo(int on);
+/* Dense K-contiguous fp32 A operands in front of weight plane images -- the 1x1 / stride-1 convolutions (plain, BatchNorm-prologue,
+ * bottleneck-tail loaders: koafusion/models/_torchvision.py:118-138) and their data gradients with the BatchNorm-backward apply --
+ * with 128-row tiles and K a multiple of 64 run the STREAMED kernel: the four waves of a block each load, transform and split their
+ * own 32 rows, two k-tiles ahead in registers, the weight tiles arrive through a three-stage LDS ring, and a persistent block
+ * prefetches across tile boundaries.  Same pieces, same MFMA order per accumulator: bit-identical to the block-wide loader.
+ * koaf_set_stream(0) sends them through the block-wide loader instead (tests / A-B measurements; environment KOAF_STREAM=0 does the
+ * same for a whole process); returns the previous setting.  Process-wide; not meant to be flipped while other threads launch. */
+int koaf_set_stream(int on);
 int64_t koaf_act_planes_elems(int64_t npix, int32_t C);
 int koaf_act_planes(const float* x, const float* x2, int64_t npix, int32_t C, int32_t tf, const float* sc, const float* sh,
                     const float* sc2, const float* amax, float fscale, uint16_t* planes, int32_t act16, void* stream);

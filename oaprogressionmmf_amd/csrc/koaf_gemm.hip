@@ -50,7 +50,9 @@ __device__ unsigned long long koaf_stamp_tab[64][8];
 #define KOAF_STAMP(i) do { kst_[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define KOAF_STAMP_ADD(slot, a, b) do { if (threadIdx.x == 0 && kst_[b] >= kst_[a]) atomicAdd(&koaf_stamp_tab[blockIdx.x & 63][slot], kst_[b] - kst_[a]); } while (0)
 #define KOAF_STAMP_ACC(slot, v) do { if (threadIdx.x == 0) atomicAdd(&koaf_stamp_tab[blockIdx.x & 63][slot], (unsigned long long)(v)); } while (0)
+#define KOAF_STAMP_NOW() __builtin_amdgcn_s_memrealtime()
 #else
+#define KOAF_STAMP_NOW() 0ull
 #define KOAF_STAMP_DECL
 #define KOAF_STAMP(i)
 #define KOAF_STAMP_ADD(slot, a, b)
@@ -152,10 +154,12 @@ enum { M_KC = 0,     // K-contiguous rows, dense
        M_PH = 9,     // the same images, 3x3 / stride 1 / pad 1: the tile's pixel rows + halo stay in LDS for all nine taps
        M_PK = 10,    // activation plane images read K-major (weight gradient: k = pixel, rows = channels), dense
        M_PKG = 11,   // the same with the conv gather on the k index and the filter tap in the column (wgrad activations)
-       M_PT = 12     // activation plane images, 3x3 / stride 1 / pad 1, 2-D pixel tiles (8 x 16) with a zero-filled halo in LDS (64 channels
+       M_PT = 12,    // activation plane images, 3x3 / stride 1 / pad 1, 2-D pixel tiles (8 x 16) with a zero-filled halo in LDS (64 channels
                      // at a time: one filter tap x 64 channels per barrier)
+       M_KS = 13     // K-contiguous dense rows (as M_KC), STREAMED: every wave loads, transforms and splits its OWN 32 rows, several
+                     // k-tiles ahead in registers (StreamA) -- the 1x1 / stride-1 convolutions and their data gradients
 };
-__host__ __device__ constexpr bool mode_is_kc(int m) { return m < 3; }
+__host__ __device__ constexpr bool mode_is_kc(int m) { return m < 3 || m == M_KS; }
 __host__ __device__ constexpr bool mode_is_pa(int m) { return m == M_PA1 || m == M_PA2; }
 // halo kernel (M_PH): widest image row kept in LDS (BM + 2 W + 2 pixels of 32 channels, two buffers) and the number of
 // weight-tile stages, chosen per column-tile width so that everything fits 160 KiB
@@ -566,6 +570,169 @@ struct TileLoader {
 #pragma unroll
             for (int q = 0; q < NPL; ++q) *(uint2*)&S[q * P + off] = make_uint2(pl[q][0], pl[q][1]);
         }
+    }
+};
+
+
+// ---- M_KS: the dense K-contiguous fp32 A operand, streamed per wave ------------------------------------------------------------
+// The block-wide loader above keeps ONE k-tile in flight (issued at the top of a k-step, consumed at its end) and meets at two
+// barriers per step: on the 1x1 convolutions of layer2-4 -- K = 128 .. 2048, 4 .. 64 steps of 24 MFMAs per wave -- every step
+// then costs a memory latency (in-kernel stamps: 1.7 us per step against 0.4 us of matrix work; the same kernel fed from
+// pre-split plane images by LDS-DMA, no conversion at all, is only 10 % faster).  Here the waves of a block are 4 x 1: wave w
+// owns rows 32 w .. 32 w + 31 of the tile and ALL its columns, so the A image rows it writes are the rows it reads -- no block
+// barrier on the A side, only the in-order LDS queue of the wave itself -- and it keeps SD k-tiles of its rows in flight in
+// registers (16 per tile and source).  The flattened (tile, k-step) sequence of a persistent block is prefetched across tile
+// boundaries: the first SD k-tiles of the next tile land under the epilogue of the current one.  Arithmetic, pieces and MFMA
+// order per accumulator are those of TileLoader + the shared k-loop: bit-identical outputs (test_stream_kernel_is_bit_identical).
+// Lane l of a wave: unit i (0..3) = row 8 i + l / 8 of the wave's band, k = 4 (l % 8) .. + 3 -- 128-B row segments per 8 lanes.
+constexpr int STREAM_TAB_K = 1024;      // longest k range of a TF 1 call on the streamed path (8 KiB of LDS beside the operand images)
+template <int TF, int SD>
+struct StreamA {
+    static constexpr bool TWO = (TF == 2 || TF == 3);
+    struct Slot {
+        v4f r[4];
+        v4f r2[TWO ? 4 : 1];
+        v4f ts, th, tk, tq;      // transform coefficients of the k-tile's 4 columns of this lane (sc, sh, sc2, sh2)
+    };
+    Slot sl[SD];
+    const float* ptr;
+    const float* ptr2;
+    const float* sc;
+    const float* sh;
+    const float* sc2;
+    const float* sh2;
+    const float* tab;     // TF 1: LDS table [2][STREAM_TAB_K] of sc * fsc, sh * fsc (the coefficients depend on k only: read when a k-tile
+                          // is consumed instead of riding in eight registers per tile in flight)
+    int64_t ld;
+    float fsc;
+    bool tail2;
+    unsigned satmax;
+    // issue cursor: the k-tile the next issue() fetches
+    v4l ibase;        // element offset of each unit's (clamped) row + 4 (l % 8)
+    int ik;
+    // consumer side
+    v4l cbase;        // TF 3: offsets of the side store (the tile being consumed)
+    unsigned rvm;     // row-valid bits of the tile being consumed
+    int kbeg, kend;
+
+    __device__ __forceinline__ v4l bases(int m0, int M) const {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        v4l b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = min(m0 + 32 * w + 8 * i + (lane >> 3), M - 1);     // (rows past M re-read the last row: zeroed in consume())
+            b[i] = (int64_t)row * ld + 4 * (lane & 7);
+        }
+        return b;
+    }
+    __device__ __forceinline__ void init(const KoafOperand& op, const float* p, int m0, int M, int kb, int ke, float scale) {
+        ptr = p;
+        ptr2 = TWO ? op.ptr2 + (p - op.ptr) : nullptr;
+        sc = op.sc; sh = op.sh; sc2 = op.sc2; sh2 = op.sh2;
+        ld = op.ld;
+        fsc = scale;
+        tail2 = (TF == 3) && op.sc2 != nullptr;
+        satmax = 0u;
+        tab = nullptr;
+        kbeg = kb; kend = ke;
+        ik = kb;
+        ibase = bases(m0, M);
+        tile(m0, M);
+    }
+    // the consumer moves on to the tile at m0
+    __device__ __forceinline__ void tile(int m0, int M) {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        rvm = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rvm |= ((m0 + 32 * w + 8 * i + (lane >> 3)) < M ? 1u : 0u) << i;
+        if constexpr (TF == 3) cbase = bases(m0, M);
+    }
+    // loads of the k-tile at the cursor into slot s; the cursor then advances by one k-tile and, at the end of the k range, to
+    // the first row next() returns for the block's following tile (the cursor runs SD k-tiles ahead of the consumer, so with as few
+    // as SD k-steps per tile it is a whole tile ahead: it keeps its own place in the block's tile sequence); next() < 0: no
+    // further tile -- the k-loop issues no more loads then
+    template <class NextFn>
+    __device__ __forceinline__ void issue(Slot& s, NextFn next, int M) {
+        const int lane = threadIdx.x & 63;
+        const int c = ik + 4 * (lane & 7);
+        if constexpr (TF > 1) {
+            s.ts = *(const v4f*)(sc + c);
+            s.th = *(const v4f*)(sh + c);
+            if constexpr (TF == 2) s.tk = *(const v4f*)(sc2 + c);
+            if constexpr (TF == 3) {
+                if (tail2) { s.tk = *(const v4f*)(sc2 + c); s.tq = *(const v4f*)(sh2 + c); }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s.r[i] = *(const v4f*)(ptr + ibase[i] + ik);
+            if constexpr (TWO) s.r2[i] = *(const v4f*)(ptr2 + ibase[i] + ik);
+        }
+        ik += BK;
+        if (ik >= kend) {
+            ik = kbeg;
+            const int nm0 = next();
+            if (nm0 >= 0) ibase = bases(nm0, M);
+        }
+    }
+    // transform (TileLoader::finish_unit's arithmetic), split and store of slot s = the k-tile at k0 of the tile being consumed,
+    // into this wave's rows of the block's A plane images S (plane_dwords(128, true) dwords per plane)
+    template <bool FULL>
+    __device__ __forceinline__ void consume_as(Slot& s, unsigned* S, int k0, float* side) {
+        constexpr float HMAX = 65504.f;
+        constexpr int P = plane_dwords(128, true);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        v4f a = s.ts, b = s.th, k = s.tk;
+        if constexpr (TF == 2) { a *= fsc; b *= fsc; k *= fsc; }
+        if constexpr (TF == 1) {
+            a = *(const v4f*)(tab + (k0 - kbeg) + 4 * (lane & 7));
+            b = *(const v4f*)(tab + STREAM_TAB_K + (k0 - kbeg) + 4 * (lane & 7));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = FULL || ((rvm >> i) & 1u);
+            v4f x = s.r[i];
+            [[maybe_unused]] v4f y = x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = x[j];
+                if constexpr (TF == 1) {
+                    v = fmaf(v, a[j], b[j]);
+                    v = __builtin_amdgcn_fmed3f(v, 0.f, HMAX);
+                } else if constexpr (TF == 2) {
+                    v = fmaf(a[j], v, fmaf(-k[j], s.r2[i][j], b[j]));
+                    v = __builtin_amdgcn_fmed3f(v, -HMAX, HMAX);
+                } else if constexpr (TF == 3) {
+                    float idv = s.r2[i][j];
+                    if (tail2) idv = fmaf(idv, k[j], s.tq[j]);
+                    v = fmaxf(fmaf(v, a[j], b[j]) + idv, 0.f);
+                    y[j] = v;
+                    v = fminf(v * fsc, HMAX);
+                } else {
+                    v = __builtin_amdgcn_fmed3f(v * fsc, -HMAX, HMAX);
+                }
+                x[j] = ok ? v : 0.f;
+            }
+            if constexpr (TF == 3) {
+                if (side != nullptr && ok) *(v4f*)(side + cbase[i] + k0) = y;
+            }
+            unsigned pl[2][2];
+            split2h(x, pl);
+            if constexpr (TF == 1 || TF == 3) {
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+                    satmax = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, satmax),
+                                                                                     __builtin_bit_cast(u16x2, pl[0][d])));
+            }
+            const int off = (32 * w + 8 * i + (lane >> 3)) * 20 + 2 * (lane & 7);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) *(uint2*)&S[q * P + off] = make_uint2(pl[q][0], pl[q][1]);
+        }
+    }
+    __device__ __forceinline__ void consume(Slot& s, unsigned* S, int k0, float* side) {
+        if (__builtin_amdgcn_ballot_w64(rvm != 15u) == 0ull) consume_as<true>(s, S, k0, side);
+        else consume_as<false>(s, S, k0, side);
     }
 };
 
@@ -1017,15 +1184,20 @@ __host__ __device__ constexpr bool persist_mode(int am, int bmd, bool f16, int t
 // (the persistent variants carry the next tile's A slot through the epilogue: held to two waves per SIMD = 256 registers)
 // ACT = KoafGemm.act16: which tensors of this call are bf16 ACTIVATIONS (0: none; 1 forward: A.ptr and C; 2 data gradient:
 // A.ptr2 (the conv output c of a tf-2 apply) and the BatchNorm-backward operands of the epilogue; 3 weight gradient: A.ptr2 and B.ptr)
-template <int BM, int BN, int AM, int BMD, int TFA, int TFB, bool VEC, bool F16, int NT = 256, int ACT = 0, bool EMIT = false>
-__global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == M_PT) ? 2 : 1) koaf_gemm_kernel(const KoafGemm p) {
+// SD (M_KS only): k-tiles of its rows a wave keeps in flight; the host picks one that divides the number of k-steps
+template <int BM, int BN, int AM, int BMD, int TFA, int TFB, bool VEC, bool F16, int NT = 256, int ACT = 0, bool EMIT = false, int SD = 0>
+__global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == M_PT || AM == M_KS) ? 2 : 1) koaf_gemm_kernel(const KoafGemm p) {
     static_assert(ACT == 0 || VEC, "bf16 activation storage needs the vector path");
     constexpr bool C16 = (ACT == 1), E16 = (ACT == 2);
     static_assert((TFA < 2 && TFB < 2) || VEC, "the two-source prologues need the vector path");
     constexpr int NPL = F16 ? 2 : 3;
     static_assert(BMD != M_PS || F16, "plane images are fp16");
-    constexpr int NW = NT / 64, WGM = NW / 2;                        // waves: WGM along M x 2 along N
-    constexpr int WM = BM / WGM, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr bool AS = (AM == M_KS);                // the streamed dense A operand: waves 4 x 1, each on its own 32 rows (StreamA)
+    static_assert(!AS || (BM == 128 && NT == 256 && BMD == M_PS && F16 && VEC && ACT == 0 && (SD == 2 || SD == 4) && TFB == 0),
+                  "the streamed A operand's one shape");
+    constexpr int WGN = AS ? 1 : 2;
+    constexpr int NW = NT / 64, WGM = NW / WGN;                      // waves: WGM along M x WGN along N
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr bool AKC = mode_is_kc(AM), BKC = mode_is_kc(BMD), BPS = (BMD == M_PS), APS = mode_is_pa(AM), AH = (AM == M_PH);
     constexpr bool AT = (AM == M_PT);                // 3x3 over plane images in 8 x 16 pixel tiles: halo in LDS, weight fragments in registers
     static_assert(!AT || (BM == 128 && BN == 64 && NT == 256 && BMD == M_PS && TFA == 0 && F16 && VEC), "the 2-D tile kernel's one shape");
@@ -1040,7 +1212,7 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
     constexpr int B_PL = (BPS || WPS) ? BN * 16 : plane_dwords(BN, BKC);
     constexpr int A_ELEMS = NPL * A_PL, B_ELEMS = NPL * B_PL;
     constexpr int NBA = (APS || (AH && HDB) || WPS) ? 2 : 1;                                  // LDS buffers per operand
-    constexpr int NBB = AH ? halo_b_stages(BN, BM) : ((BPS || WPS) ? 2 : 1);
+    constexpr int NBB = AH ? halo_b_stages(BN, BM) : (AS ? 3 : ((BPS || WPS) ? 2 : 1));
     constexpr int LDC_S = BN + 4;                                    // epilogue staging row (floats)
     constexpr int C_ELEMS = VEC ? BM * LDC_S : 0;
     constexpr int OPS = NBA * A_ELEMS + NBB * B_ELEMS;
@@ -1049,6 +1221,7 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
     constexpr int T2D_HALO_BYTES = 2 * 180 * 128;
     constexpr int SMEM = AT ? (C_ELEMS + T2D_HALO_BYTES / 4) : ((OPS > C_ELEMS) ? OPS : C_ELEMS);
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    __shared__ __attribute__((aligned(16))) float s_tab[(AS && TFA == 1) ? 2 * STREAM_TAB_K : 4];     // M_KS, tf 1: see StreamA::tab
 
     KOAF_STAMP_DECL;
     KOAF_STAMP(0);
@@ -1060,7 +1233,7 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
     // block walks the tiles vt = blockIdx.x, + gridDim.x, ... (the host launches 2 blocks per CU) and issues the NEXT tile's
     // first A loads before the epilogue of the current one, so their HBM latency runs under the staging / stores instead
     // of in front of the next k-loop.  All other variants run their single tile through the same loop.
-    constexpr bool PERSIST = persist_mode(AM, BMD, F16, TFA);
+    constexpr bool PERSIST = persist_mode(AM, BMD, F16, TFA) || (AS && TFA < 2 && SD == 2);      // (M_KS with four k-tiles in flight: one tile per block)
     const unsigned ntx = (unsigned)((p.M - p.m_base + BM - 1) / BM) * (unsigned)ntn;     // tiles of one (split, batch) slice
     auto decode = [&](unsigned v, int& tm_, int& tn_) {
         const unsigned q = ntx >> 3, rem = ntx & 7, x = v & 7, j = v >> 3;
@@ -1110,14 +1283,17 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
     const unsigned short* Bpl = (BPS || WPS) ? p.B.planes + z0 * p.B.bs0 + z1 * p.B.bs1 : nullptr;
 
     // (the unused ones of the loaders are dead code to the compiler)
-    TileLoader<(APS || AH || AT) ? 128 : BM, (APS || AH || AT || WPS) ? M_KC : AM, TFA, VEC, F16, ACT == 1,
+    TileLoader<(APS || AH || AT) ? 128 : BM, (APS || AH || AT || WPS || AS) ? M_KC : AM, AS ? 0 : TFA, VEC, F16, ACT == 1,
                ((ACT == 2 || ACT == 3) && TFA == 2) || (ACT == 1 && TFA == 3)> la;
     TileLoader<BN, (BPS || WPS) ? M_KC : BMD, TFB, VEC, F16, ACT == 3> lb;
     PlaneKLoader<WPS ? BM : 128, false> wka;
     PlaneKLoader<BN, BMD == M_PKG> wkb;
     PlaneLoader<BN> lp;
     PlaneGatherLoader<AH ? 128 : BM, AM == M_PA2 ? 2 : 1> lpa;
-    if constexpr (WPS) {
+    StreamA<AS ? TFA : 0, AS ? SD : 2> st;
+    if constexpr (AS) {
+        // (set up below, once the first tile is known)
+    } else if constexpr (WPS) {
         wka.init(p.A, m0, p.M);
         wka.seek(p.A, kbeg);
         wkb.init(p.B, n0, p.N);
@@ -1141,10 +1317,37 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
 
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / WGN, wn = w % WGN;
     const int r = lane & 31, h = lane >> 5;
-    if constexpr (PERSIST) {
+    if constexpr (PERSIST && !AS) {
         if (kbeg < kend) la.issue(la.sa, p.A, Ap, kbeg, kend, z1);      // the first tile's A loads
+    }
+    // M_KS: the tile after this one (the cursor of the A stream crosses into it SD k-steps before this tile's k-loop ends)
+    [[maybe_unused]] bool s_has_next = false;
+    [[maybe_unused]] int s_tm2 = 0, s_tn2 = 0, s_m0n = -1;
+    auto stream_next = [&]() {
+        s_has_next = PERSIST && (vt + gridDim.x) < ntx;
+        s_m0n = -1;
+        if (s_has_next) { decode(vt + gridDim.x, s_tm2, s_tn2); s_m0n = p.m_base + s_tm2 * BM; }
+    };
+    [[maybe_unused]] unsigned c_vt = blockIdx.x;      // the tile the A stream's cursor is on
+    auto cursor_next = [&]() -> int {
+        if (!PERSIST || c_vt + gridDim.x >= ntx) return -1;
+        c_vt += gridDim.x;
+        int a, b;
+        decode(c_vt, a, b);
+        return p.m_base + a * BM;
+    };
+    if constexpr (AS) {
+        st.init(p.A, Ap, m0, p.M, kbeg, kend, sca);
+        if constexpr (TFA == 1) {
+            for (int k = t; k < kend - kbeg; k += NT) { s_tab[k] = p.A.sc[kbeg + k] * sca; s_tab[STREAM_TAB_K + k] = p.A.sh[kbeg + k] * sca; }
+            st.tab = s_tab;
+            __syncthreads();
+        }
+        stream_next();
+#pragma unroll
+        for (int d = 0; d < SD; ++d) st.issue(st.sl[d], cursor_next, p.M);      // the first SD k-tiles of this block's first tile
     }
     for (;;) {      // the tiles of this block (one, unless PERSIST)
     KOAF_STAMP(0);
@@ -1575,6 +1778,71 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();       // the epilogue's staging tile covers the weight stages
+    } else if constexpr (AS) {
+        // Streamed A (StreamA) x weight plane images by LDS-DMA through a three-stage ring.  Step s of the tile, per wave:
+        //   consume A(s) -- the registers issued SD steps ago: transform, split, this wave's rows of the A image; wait for this
+        //   wave's pieces of B(s) (issued at step s - 2: counted, what was issued since stays in flight) and meet the other waves:
+        //   B(s) is complete and nobody still reads the stage of step s - 1, which B(s + 2) now overwrites; issue B(s + 2), then
+        //   A(s + SD) into the registers A(s) left; fragments + MFMAs.
+        // The A loads are ordinary loads (the compiler keeps their registers and waits for them itself); the LDS-DMA is inline
+        // assembly it does not see, so its wait for A(s) also retires the (SD - 1) NB oldest operations issued after A(s) -- in this
+        // order those are B(s - SD + 3), A(s + 1), B(s - SD + 4) ...: tiles already needed or needed next.  The manual waits
+        // count only loads that are certainly issued (NLA data loads per A tile: coefficient loads and side stores make the true
+        // count larger, which errs towards waiting longer).
+        // (Measured and dropped: the transform + split of A(s + 1) cut into quarters between the MFMAs of step s -- pinned with
+        // scheduling barriers, since hipcc otherwise puts every vector instruction behind the last MFMA -- was slower than this
+        // order on every layer, 2002 against 1977 ms per step.)
+        constexpr int NLA = (TFA == 2 || TFA == 3) ? 8 : 4;
+        constexpr int NB = 2 * (BN / 64);                   // LDS-DMA instructions per wave and weight tile (two planes)
+        const int nstep = (kend - kbeg) / BK;               // host: a multiple of SD
+        unsigned* const Aim = (unsigned*)smem;
+        float* const side = (TFA == 3 && n0 == 0) ? p.A.side : nullptr;
+        lp.template issue<NPL>(p.B, Bpl, sb0);
+        if (nstep > 1) lp.template issue<NPL>(p.B, Bpl, sb0 + (B_ELEMS * 4));
+        // "at most n vector-memory operations of this wave still in flight", rounded down to an immediate of the ladder, + barrier
+        auto wait_barrier = [&](int n) {
+            if (n >= 2 * NLA + NB) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NLA + NB) : "memory");
+            else if (n >= 2 * NLA) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NLA) : "memory");
+            else if (n >= NLA + NB) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NLA + NB) : "memory");
+            else if (n >= NLA) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NLA) : "memory");
+            else if (n >= NB) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        // does step j issue an A tile?  (its target k-tile exists: later in this tile, or in the next tile of a persistent block)
+        auto issues = [&](int j) { return j >= 0 && (j + SD < nstep || s_m0n >= 0); };
+        int bst = 0;
+        KOAF_STAMP(1);
+        [[maybe_unused]] unsigned long long kst_c = 0, kst_w = 0;      // (stamps build: time in consume() incl. the wait for A; in the B wait + barrier)
+#pragma unroll 1
+        for (int s0 = 0; s0 < nstep; s0 += SD) {
+#pragma unroll
+            for (int d = 0; d < SD; ++d) {
+                const int ss = s0 + d;
+                [[maybe_unused]] const unsigned long long ta0 = KOAF_STAMP_NOW();
+                st.consume(st.sl[d], Aim, kbeg + ss * BK, side);
+                [[maybe_unused]] const unsigned long long ta1 = KOAF_STAMP_NOW();
+                // younger than B(ss): the A tiles of steps ss - 2 and ss - 1, B(ss + 1)
+                wait_barrier((issues(ss - 2) ? NLA : 0) + (issues(ss - 1) ? NLA : 0) + ((ss + 1 < nstep) ? NB : 0));
+                kst_c += ta1 - ta0;
+                kst_w += KOAF_STAMP_NOW() - ta1;
+                if (ss + 2 < nstep) {
+                    int b2 = bst + 2;
+                    if (b2 >= 3) b2 -= 3;
+                    lp.template issue<NPL>(p.B, Bpl, sb0 + b2 * (B_ELEMS * 4));
+                }
+                if (issues(ss)) st.issue(st.sl[d], cursor_next, p.M);
+                mma(Aim, (const unsigned*)(Bs0 + bst * B_ELEMS));
+                if (++bst == 3) bst = 0;
+            }
+        }
+        // every wave is done with the operand images (the epilogue's staging tile covers them); the next tile's A stays in flight
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        KOAF_STAMP_ACC(5, kst_w);
+        KOAF_STAMP_ACC(6, kst_c);
+        if constexpr (TFA == 1 || TFA == 3) {
+            if (((st.satmax & 0xffffu) >= 0x7bffu) | ((st.satmax >> 16) >= 0x7bffu)) koaf_status_add(p.status, 0, 1u);
+            st.satmax = 0u;
+        }
     } else if constexpr (WPS) {
         // weight gradient: both K-major operands by LDS-DMA, double-buffered, one barrier per k-tile (as below)
         if (kbeg < kend) {
@@ -1670,7 +1938,9 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
     // (M_PT blocks are NOT persistent: requesting the next tile's halo under this tile's epilogue was measured -- the prologue
     // fell from 3.9 to 0.7 us per tile and the k-loops grew by as much: with two blocks per CU one block's prologue already runs
     // under the other's MFMAs)
-    if constexpr (PERSIST) {
+    if constexpr (AS) {
+        has_next = s_has_next; tm2 = s_tm2; tn2 = s_tn2;       // (its first SD k-tiles are already in flight)
+    } else if constexpr (PERSIST) {
         has_next = (vt + gridDim.x) < ntx;
         if (has_next) {
             decode(vt + gridDim.x, tm2, tn2);
@@ -1680,7 +1950,7 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
         }
     }
 
-    if constexpr (F16 && (TFA == 1 || TFA == 3) && AKC && !APS && !AH && !WPS) {
+    if constexpr (F16 && (TFA == 1 || TFA == 3) && AKC && !APS && !AH && !WPS && !AS) {
         if (((la.satmax & 0xffffu) >= 0x7bffu) | ((la.satmax >> 16) >= 0x7bffu)) koaf_status_add(p.status, 0, 1u);
         la.satmax = 0u;
     }
@@ -1699,10 +1969,13 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
     const float* Rp = (p.residual && !slab) ? p.residual + z0 * p.rbs0 + z1 * p.rbs1 : nullptr;
     const float* bias = slab ? nullptr : p.bias;
     const bool do_stats = (p.stats != nullptr) && !slab;
-    float s1[TN], s2[TN], kshift[TN];
+    // (per 32-row band i of the wave's rows: the tile's sums are then the same tree whether its four bands sit in two waves or,
+    // on the streamed kernels, in four -- band sums, lane halves, band pairs, pair of pairs)
+    float s1[TM][TN], s2[TM][TN], kshift[TN];
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
-        s1[jn] = s2[jn] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) s1[i][jn] = s2[i][jn] = 0.f;
         // statistics are summed about a per-column shift (the BatchNorm's running mean): sum (v - k), sum (v - k)^2
         // lose nothing to cancellation when |mean| >> std, which sum v^2 - (sum v)^2 / n does
         const int scol = n0 + wn * WN + 32 * jn + r;
@@ -1723,8 +1996,8 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float v = alpha * acc[i][jn][e];
-                    s1[jn] += v - kshift[jn];
-                    s2[jn] = fmaf(v - kshift[jn], v - kshift[jn], s2[jn]);     // (explicit: every instantiation rounds alike)
+                    s1[i][jn] += v - kshift[jn];
+                    s2[i][jn] = fmaf(v - kshift[jn], v - kshift[jn], s2[i][jn]);     // (explicit: every instantiation rounds alike)
                     Cs[(wm * WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC_S + wn * WN + 32 * jn + r] = v;
                 }
         __syncthreads();
@@ -1836,8 +2109,8 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * WM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
                 float v = alpha * acc[i][jn][e];
-                s1[jn] += v - kshift[jn];
-                s2[jn] = fmaf(v - kshift[jn], v - kshift[jn], s2[jn]);     // (explicit: every instantiation rounds alike)
+                s1[i][jn] += v - kshift[jn];
+                s2[i][jn] = fmaf(v - kshift[jn], v - kshift[jn], s2[i][jn]);     // (explicit: every instantiation rounds alike)
                 if (cok && row < p.M) {
                     v += bv;
                     if (Rp) v += Rp[(int64_t)row * p.ldr + col];
@@ -1852,8 +2125,13 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
         float* red = smem;  // [WGM][2][BN]
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
-            float a1 = s1[jn] + __shfl_xor(s1[jn], 32, 64);
-            float a2 = s2[jn] + __shfl_xor(s2[jn], 32, 64);
+            float a1 = s1[0][jn] + __shfl_xor(s1[0][jn], 32, 64);
+            float a2 = s2[0][jn] + __shfl_xor(s2[0][jn], 32, 64);
+#pragma unroll
+            for (int i = 1; i < TM; ++i) {
+                a1 += s1[i][jn] + __shfl_xor(s1[i][jn], 32, 64);
+                a2 += s2[i][jn] + __shfl_xor(s2[i][jn], 32, 64);
+            }
             if (h == 0) {
                 red[(wm * 2 + 0) * BN + wn * WN + 32 * jn + r] = a1;
                 red[(wm * 2 + 1) * BN + wn * WN + 32 * jn + r] = a2;
@@ -1863,8 +2141,13 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
         if (t < BN && (n0 + t) < p.N) {
             float* st = p.stats + (int64_t)(p.part_row0 + tm) * 2 * p.stats_ld + (int64_t)blockIdx.z * p.stats_bs;
             float a1 = red[0 * BN + t], a2 = red[1 * BN + t];
+            if constexpr (WGM == 4 && TM == 1) {      // (the streamed kernels' four one-band waves: pairs first, as two two-band waves add up)
+                a1 = (a1 + red[2 * BN + t]) + (red[4 * BN + t] + red[6 * BN + t]);
+                a2 = (a2 + red[3 * BN + t]) + (red[5 * BN + t] + red[7 * BN + t]);
+            } else {
 #pragma unroll
-            for (int m = 1; m < WGM; ++m) { a1 += red[(2 * m) * BN + t]; a2 += red[(2 * m + 1) * BN + t]; }
+                for (int m = 1; m < WGM; ++m) { a1 += red[(2 * m) * BN + t]; a2 += red[(2 * m + 1) * BN + t]; }
+            }
             if (p.stats_shift) {
                 // rows of the tile past M were accumulated as zeros: each put (0 - k) and k^2 into the shifted sums
                 const float k = p.stats_shift[(int64_t)blockIdx.z * p.stats_bs + n0 + t];
@@ -1892,6 +2175,10 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
     if constexpr (PERSIST) {
         lp.init(p.B, n0, p.N);
         lp.seek(p.B, kbeg);
+    }
+    if constexpr (AS) {
+        st.tile(m0, p.M);
+        stream_next();
     }
     }
 }
@@ -1936,6 +2223,16 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
 }
 
 constexpr unsigned PERSIST_BLOCKS = 512;      // 2 per CU x 256 CUs; a multiple of 8 (virtual tile ids keep their XCD)
+
+#ifdef KOAF_DEV_STREAM      // (development builds, with KOAF_DEV_T2D: the streamed-A instantiations alone -- 20 s -- for their register counts / ISA)
+template __global__ void koaf_gemm_kernel<128, 128, M_KS, M_PS, 0, 0, true, true, 256, 0, false, 2>(const KoafGemm);
+template __global__ void koaf_gemm_kernel<128, 128, M_KS, M_PS, 1, 0, true, true, 256, 0, false, 2>(const KoafGemm);
+template __global__ void koaf_gemm_kernel<128, 128, M_KS, M_PS, 2, 0, true, true, 256, 0, false, 2>(const KoafGemm);
+template __global__ void koaf_gemm_kernel<128, 128, M_KS, M_PS, 3, 0, true, true, 256, 0, false, 2>(const KoafGemm);
+template __global__ void koaf_gemm_kernel<128, 64, M_KS, M_PS, 2, 0, true, true, 256, 0, false, 2>(const KoafGemm);
+template __global__ void koaf_gemm_kernel<128, 64, M_KS, M_PS, 3, 0, true, true, 256, 0, true, 2>(const KoafGemm);
+#endif
+
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -1995,6 +2292,21 @@ int operand_mode(const KoafOperand& o) {
     hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, AMODE, BMODE, TA, TB, VEC, F16, 256, ACT, true>), (persist_mode(AMODE, BMODE, F16, TA) ? pgrid : grid), dim3(256), 0, s, g);     \
     return koaf_check_launch("koaf_gemm/emit")
 
+// the streamed dense A operand (M_KS, StreamA) in front of weight plane images: SD = 2 k-tiles in flight per wave
+#define KOAF_LAUNCH_S(TA, EM)                                                                                    \
+    hipLaunchKernelGGL((koaf_gemm_kernel<BM, BN, M_KS, M_PS, TA, 0, VEC, F16, 256, ACT, EM, 2>), ((TA) < 2 ? pgrid : grid), dim3(256), 0, s, g);      \
+    return koaf_check_launch("koaf_gemm/stream")
+// (SD = 4 -- four k-tiles in flight, one tile per block, for the one-source loaders with K >= 256 -- builds without spills (213
+// registers) and was measured on the headline step: 1977.2 ms against 1974.4 ms with SD = 2 everywhere; not instantiated.)
+
+int g_stream_mode = -1;     // the streamed A operand for the dense 1x1 kernels: -1 = read KOAF_STREAM once (default on)
+// dense K-contiguous fp32 A (1x1 / stride-1 convolutions and their data gradients) in whole k-tiles, an even number of them
+bool stream_ok(const KoafGemm& g) {
+    if (g_stream_mode < 0) { const char* e = getenv("KOAF_STREAM"); g_stream_mode = (e && e[0] == '0') ? 0 : 1; }
+    return g_stream_mode == 1 && g.A.kind == 0 && g.A.gather == 0 && g.K >= 2 * BK && (g.K % (2 * BK)) == 0 && g.splitk == 1 &&
+           g.nb0 * g.nb1 == 1 && (g.A.tf != 1 || g.K <= STREAM_TAB_K);
+}
+
 // the operand-mode pairs the library uses: conv fwd (KC|KC_G1 x KC|PS), dgrad (KC|KC_G2 x PS, or KC x KM | KC_G2 x KM_G3
 // on fp32 weights), wgrad (KM x KM|KM_G1), linear / attention (dense pairs).  tf only where a BatchNorm prologue exists.
 // ACT (bf16 activation storage, KoafGemm.act16): only the pairs of its role are instantiated -- 1 forward convolutions,
@@ -2005,6 +2317,20 @@ int launch_modes(const KoafGemm& g, dim3 grid, hipStream_t s) {
     const int ta = g.A.tf, tb = g.B.tf;
     dim3 pgrid = grid;
     if (grid.y == 1 && grid.x > PERSIST_BLOCKS) pgrid.x = PERSIST_BLOCKS;
+    if constexpr (VEC && F16 && ACT == 0 && BM == 128) {
+        if (am == M_KC && bm == M_PS && !tb && stream_ok(g)) {
+            if (g.out_planes) {
+                if (ta == 0) { KOAF_LAUNCH_S(0, true); }
+                if (ta == 1) { KOAF_LAUNCH_S(1, true); }
+                if (ta == 3) { KOAF_LAUNCH_S(3, true); }
+            } else {
+                if (ta == 0) { KOAF_LAUNCH_S(0, false); }
+                if (ta == 1) { KOAF_LAUNCH_S(1, false); }
+                if (ta == 2) { KOAF_LAUNCH_S(2, false); }
+                if (ta == 3) { KOAF_LAUNCH_S(3, false); }
+            }
+        }
+    }
     if (g.out_planes) {
         if constexpr (VEC && F16 && (ACT == 0 || ACT == 1)) {
             if (am == M_KC && bm == M_PS && ta == 3) { KOAF_LAUNCH_E(M_KC, M_PS, 3, 0); }
@@ -2698,6 +3024,13 @@ extern "C" int koaf_debug_stamps(unsigned long long* out, int reset) {
     return KOAF_OK;
 }
 #endif
+
+extern "C" int koaf_set_stream(int on) {
+    if (g_stream_mode < 0) { const char* e = getenv("KOAF_STREAM"); g_stream_mode = (e && e[0] == '0') ? 0 : 1; }
+    const int was = g_stream_mode;
+    g_stream_mode = on ? 1 : 0;
+    return was;
+}
 
 extern "C" int koaf_set_conv3x3_halo(int on) {
     const int was = g_halo_mode;

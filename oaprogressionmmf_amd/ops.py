@@ -196,6 +196,12 @@ def set_conv3x3_halo(mode):
     return lib().koaf_set_conv3x3_halo(int(mode))
 
 
+def set_stream(on):
+    """the streamed kernel for dense 1x1 / stride-1 convolutions and their data gradients (koaf.h koaf_set_stream): True (default) /
+    False = the block-wide loader; returns the previous setting"""
+    return bool(lib().koaf_set_stream(1 if on else 0))
+
+
 def use_aplanes(wimg, KH, KW, C):
     """activation plane images pay where a kernel gathers (every element is otherwise converted KH*KW times)"""
     return APLANES and wimg is not None and KH * KW > 1 and C % 32 == 0

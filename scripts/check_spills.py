@@ -6,10 +6,14 @@ the persistent 1x1 kernels 40-90 spilled registers: +40 ms per step, invisible i
 import re, subprocess, sys
 from pathlib import Path
 CS = Path(__file__).resolve().parent.parent / "oaprogressionmmf_amd" / "csrc"
-RECORDED = {   # template arguments -> spilled VGPRs at the fixed build (koaf_gemm_kernel<BM, BN, AM, BMD, TFA, TFB, VEC, F16, NT, ACT, EMIT>)
-    "128,128,0,6,1,0,1,1,256,0,0": 7, "128,128,1,6,1,0,1,1,256,0,0": 35, "128,128,1,6,0,0,1,1,256,0,0": 14,
-    "128,128,2,6,0,0,1,1,256,0,0": 15, "128,128,0,6,2,0,1,1,256,0,0": 0, "128,128,0,6,3,0,1,1,256,0,0": 0,
-    "128,64,12,6,0,0,1,1,256,0,0": 0, "256,128,9,6,0,0,1,1,512,0,0": 0,
+RECORDED = {   # template arguments -> spilled VGPRs at the fixed build (koaf_gemm_kernel<BM, BN, AM, BMD, TFA, TFB, VEC, F16, NT, ACT, EMIT, SD>)
+    "128,128,0,6,1,0,1,1,256,0,0,0": 7, "128,128,1,6,1,0,1,1,256,0,0,0": 35, "128,128,1,6,0,0,1,1,256,0,0,0": 14,
+    "128,128,2,6,0,0,1,1,256,0,0,0": 15, "128,128,0,6,2,0,1,1,256,0,0,0": 0, "128,128,0,6,3,0,1,1,256,0,0,0": 0,
+    "128,64,12,6,0,0,1,1,256,0,0,0": 0, "256,128,9,6,0,0,1,1,512,0,0,0": 0,
+    # the streamed kernels (A mode 13): the persistent one-source ones carry two k-tiles of the next tile through the epilogue
+    "128,128,13,6,0,0,1,1,256,0,0,2": 16, "128,128,13,6,1,0,1,1,256,0,0,2": 16, "128,128,13,6,0,0,1,1,256,0,1,2": 20,
+    "128,128,13,6,1,0,1,1,256,0,1,2": 20, "128,128,13,6,2,0,1,1,256,0,0,2": 0, "128,128,13,6,3,0,1,1,256,0,0,2": 0,
+    "128,64,13,6,2,0,1,1,256,0,0,2": 0, "128,64,13,6,3,0,1,1,256,0,0,2": 0,
 }
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-I../../include",
        "-mllvm", "-amdgpu-mfma-vgpr-form", "-Rpass-analysis=kernel-resource-usage", "-c", "koaf_gemm.hip", "-o", "/tmp/koaf_gemm_spills.o"]

@@ -32,12 +32,14 @@ def timeit(fn, n=REP):
 
 def show(tag, t, b, byt):
     n = max(b[7], 1)
-    us = [v / n / 100.0 for v in b[:6]]
+    us = [v / n / 100.0 for v in b[:7]]
     print(f"{tag:46s} {t:7.3f} ms {byt / t / 1e9:5.2f} TB/s | tiles/launch {b[7] // REP:6d}: per tile us: prologue {us[0]:5.2f} k-loop {us[1]:6.2f} "
-          f"stage {us[2]:5.2f} store+red {us[3]:5.2f} total {us[4]:6.2f}", flush=True)
+          f"(streamed kernel: A wait + transform {us[6]:5.2f}, B wait + barrier {us[5]:5.2f}) stage {us[2]:5.2f} store+red {us[3]:5.2f} total {us[4]:6.2f}", flush=True)
 
 
-NI = 1280
+NI = int(sys.argv[1]) if len(sys.argv) > 1 else 1280
+if len(sys.argv) > 2:
+    ops.set_stream(sys.argv[2] != '0')
 for (H, Cin, Cout) in [(96, 64, 256), (96, 256, 64), (48, 128, 512), (48, 512, 128), (24, 256, 1024), (24, 1024, 256), (12, 512, 2048)]:
     W = H
     rows = NI * H * W

@@ -1002,3 +1002,82 @@ def test_conv_epilogue_emits_the_consumer_plane_images(dev, N, H, W, Cin, Cout, 
         t1 = ops.conv2d_fwd(x, w, N, H, W, Cin, Cout, 1, 1, 1, 0, isc, ish, wimg=img, tail_idt=idt, emit=(osc, osh))
         assert torch.equal(t0[0], t1[0]) and torch.equal(t0[2], t1[2])
         assert torch.equal(t1[0]._koaf_eplanes[0], ops.act_planes(t0[0], N * H * W, Cout, 1, osc, osh, fscale=ops.ACT_SCALE))
+
+
+def _bn_record(ops, dev, x, rows, C):
+    return ops.bn_finalize(ops.colstats(x, rows, C), C, rows, (rnd(C) * 0.2 + 1).to(dev), (rnd(C) * 0.1).to(dev), torch.zeros(C, device=dev),
+                           torch.ones(C, device=dev), torch.zeros(1, dtype=torch.int64, device=dev), 0.1, 1e-5, True)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(5, 24, 24, 64, 256),       # K = 64: as many k-steps as tiles in flight, several column tiles
+                                            (600, 12, 12, 64, 128),     # ... and more tiles than resident blocks: the A stream crosses tile boundaries
+                                            (3, 17, 19, 128, 64),       # ragged last tile, 64-column tiles
+                                            (2, 16, 16, 256, 512),      # eight k-steps: four k-tiles in flight (one tile per block)
+                                            (2, 10, 10, 1024, 256)])
+def test_streamed_1x1_kernels_match_the_block_wide_loader(dev, N, H, W, Cin, Cout):
+    """koaf_set_stream: the streamed kernel of the dense 1x1 / stride-1 convolutions (every wave loads, transforms and splits its own
+    32 rows, k-tiles ahead in registers; KoafGemm A mode M_KS) against the block-wide loader on the same calls: outputs, side-stored
+    tails, emitted plane images, per-tile BatchNorm statistics, data gradients with the BatchNorm-backward apply on load and the fused
+    reduction -- BIT FOR BIT (same pieces, same MFMA order per accumulator, the statistics as the same tree of 32-row band sums).
+    _torchvision.py:118-138 (the 1x1 convolutions of a Bottleneck)."""
+    from oaprogressionmmf_amd import ops
+    rows = N * H * W
+    x = (rnd(N, H, W, Cin) * 1.5 + 0.3).to(dev)
+    w = rnd(Cout, 1, 1, Cin, scale=Cin ** -0.5).to(dev)
+    img = ops.build_weight_planes(w, Cout, 1, Cin)
+    sv = _bn_record(ops, dev, x, rows, Cin)
+    shift = (rnd(Cout) * 0.1).to(dev)
+    idt = rnd(N, H, W, Cin).to(dev)
+    ids = _bn_record(ops, dev, idt, rows, Cin)
+    em = ((torch.rand(Cout, generator=G) + 0.5).to(dev), (rnd(Cout) * 0.1).to(dev))
+
+    def forward_calls():
+        out = {}
+        out["plain"] = ops.conv2d_fwd(x, w, N, H, W, Cin, Cout, 1, 1, 1, 0, None, None, stats=True, shift=shift, wimg=img)
+        out["prologue"] = ops.conv2d_fwd(x, w, N, H, W, Cin, Cout, 1, 1, 1, 0, sv[2], sv[3], stats=True, shift=shift, wimg=img)
+        out["tail"] = ops.conv2d_fwd(x, w, N, H, W, Cin, Cout, 1, 1, 1, 0, sv[2], sv[3], stats=True, shift=shift, wimg=img, tail_idt=idt)
+        out["tail_ds"] = ops.conv2d_fwd(x, w, N, H, W, Cin, Cout, 1, 1, 1, 0, sv[2], sv[3], stats=True, shift=shift, wimg=img, tail_idt=idt,
+                                        tail_idsaved=ids)
+        y, _, yin = ops.conv2d_fwd(x, w, N, H, W, Cin, Cout, 1, 1, 1, 0, sv[2], sv[3], stats=False, wimg=img, tail_idt=idt, emit=em)
+        out["tail_emit"] = (y, None, yin, y._koaf_eplanes[0])
+        y, _ = ops.conv2d_fwd(x, w, N, H, W, Cin, Cout, 1, 1, 1, 0, sv[2], sv[3], stats=False, wimg=img, emit=em)
+        out["prologue_emit"] = (y, None, y._koaf_eplanes[0])
+        return out
+
+    # the data gradient of a Cout -> Cin convolution contracts over this call's Cin ... reuse the tensors the other way round
+    c = x                                                     # conv output whose BatchNorm is back-propagated ([rows, Cin])
+    g = (rnd(N, H, W, Cin) * 1e-3).to(dev)
+    wd = rnd(Cin, 1, 1, Cout, scale=Cout ** -0.5).to(dev)     # convolution Cout -> Cin
+    imgd = ops.build_weight_planes(wd, Cin, 1, Cout)
+    dgm, dbt = torch.empty(Cin, device=dev), torch.empty(Cin, device=dev)
+    ap = ops.bn_bwd(g.clone(), c, sv, rows, Cin, rows, dgm, dbt, 2, fused=True)
+    cx = (rnd(N, H, W, Cout) * 1.5 + 0.3).to(dev)
+    savx = _bn_record(ops, dev, cx, rows, Cout)
+    res = (rnd(N, H, W, Cout) * 1e-3).to(dev)
+
+    def gradient_calls():
+        out = {}
+        out["apply"] = (ops.conv2d_dgrad(ap, wd, N, H, W, Cout, Cin, 1, 1, 1, 0, wimg=imgd),)
+        out["apply_bnb"] = ops.conv2d_dgrad(ap, wd, N, H, W, Cout, Cin, 1, 1, 1, 0, residual=res, wimg=imgd,
+                                            bnb=dict(mode=2, c=cx, saved=savx, dz_amax=True))
+        out["apply_bnb_tail"] = ops.conv2d_dgrad(ap, wd, N, H, W, Cout, Cin, 1, 1, 1, 0, residual=res, wimg=imgd,
+                                                 bnb=dict(mode=1, c=cx, y=res, saved=savx, c2=cx, saved2=savx, dz_amax=True))
+        return out
+
+    was = ops.set_stream(False)
+    try:
+        f0, g0 = forward_calls(), gradient_calls()
+        ops.set_stream(True)
+        f1, g1 = forward_calls(), gradient_calls()
+    finally:
+        ops.set_stream(was)
+    for name in f0:
+        a, b = f0[name], f1[name]
+        assert torch.equal(a[0], b[0]), name                             # the convolution output
+        if a[1] is not None:                                              # per-tile statistics: the same tree of band sums in both kernels
+            assert torch.equal(a[1], b[1]), name
+        for ta, tb in zip(a[2:], b[2:]):                                  # the side-stored tail, the emitted plane images
+            assert torch.equal(ta, tb), name
+    for name in g0:
+        for ta, tb in zip(g0[name], g1[name]):
+            assert torch.equal(ta, tb), name
