@@ -26,7 +26,7 @@ extern "C" {
 #define KOAF_EINVAL (-1)
 #define KOAF_ELAUNCH (-2)
 
-int koaf_version(void);          /* 100 * major + 10 * minor: 170 = this header */
+int koaf_version(void);          /* 100 * major + 10 * minor: 180 = this header */
 const char* koaf_last_error(void);
 /* Numerics status words: a device uint32[4] (zeroed by the caller; NULL = off, the default) that kernels bump with atomics when
  *   [0] an activation operand left the fp16 range of the fixed activation scale and was CLAMPED (KOAF_ACT_SCALE: |x| > 4094), or

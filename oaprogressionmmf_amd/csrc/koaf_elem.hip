@@ -19,7 +19,7 @@ extern "C" const char* koaf_last_error(void) { return g_err; }
 static uint32_t* g_status = nullptr;
 uint32_t* koaf_status_ptr() { return g_status; }
 extern "C" int koaf_set_status_buffer(uint32_t* dev4) { g_status = dev4; return KOAF_OK; }
-extern "C" int koaf_version(void) { return 170; }   // 1.7: KoafEmit / KoafGemm.out_planes (epilogue cuts the consumer's plane images), loss labels outside [0, C); 1.6: KoafTail.idt_sc / idt_sh (tails behind a downsample branch), koaf_stem_fwd statistics, koaf_stem_wgrad dy_apply, koaf_bn_bwd_reduce_pool
+extern "C" int koaf_version(void) { return 180; }   // 1.8: koaf_set_stream (streamed kernel of the dense 1x1 convolutions, KoafGemm A mode M_KS); 1.7: KoafEmit / KoafGemm.out_planes (epilogue cuts the consumer's plane images), loss labels outside [0, C); 1.6: KoafTail.idt_sc / idt_sh (tails behind a downsample branch), koaf_stem_fwd statistics, koaf_stem_wgrad dy_apply, koaf_bn_bwd_reduce_pool
 
 namespace {
 
