@@ -349,18 +349,23 @@ int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int32_t N, int
 
 /* ---- Grouped 3x3 convolution (ResNeXt 32x4d; _torchvision.py:110,327-330) -------------------
  * Runs on the same MFMA GEMM as 64-channel block-diagonal slabs: packed weights [C][3][3][C/groups]
- * are expanded to wexp [C/64][64][9][64] (zeros off the group blocks), gradients compressed back. */
-int koaf_gconv_expand_w(const float* w, float* wexp, int32_t C, int32_t groups, void* stream);
+ * are expanded to wexp [C/64][64][9][64] (zeros off the group blocks), gradients compressed back.
+ * Contraction scheme (KoafGemm.fmt): with the operands' largest magnitudes known the three calls run on the fp16 scheme (two
+ * scaled fp16 pieces, three products: half the matrix instructions of the bf16 scheme, same accuracy) -- w_amax = device scalar
+ * max |w| (koaf_gconv_expand_w leaves it when given `amax`, which the caller zeroes beforehand), dy_amax = device scalar max |dy|
+ * (koaf_bn_bwd_apply leaves it); activations x use the fixed activation scale KOAF_ACT_SCALE.  NULL scalars (and every call with
+ * act16 != 0): the bf16 scheme. */
+int koaf_gconv_expand_w(const float* w, float* wexp, int32_t C, int32_t groups, float* amax, void* stream);
 int koaf_gconv_compress_dw(const float* dwexp, float* dw, int32_t C, int32_t groups, void* stream);
 int koaf_gconv3x3_fwd(const float* x, const float* wexp, float* y, int32_t N, int32_t H, int32_t W,
                       int32_t C, int32_t stride, const float* in_sc, const float* in_sh,
-                      float* stats, int32_t* stats_rows, const float* stats_shift, int32_t act16, void* stream);
+                      float* stats, int32_t* stats_rows, const float* stats_shift, const float* w_amax, int32_t act16, void* stream);
 int koaf_gconv3x3_dgrad(const float* dy, const float* wexp, float* dx, int32_t N, int32_t H,
-                        int32_t W, int32_t C, int32_t stride, void* stream);
+                        int32_t W, int32_t C, int32_t stride, const float* w_amax, const float* dy_amax, void* stream);
 int64_t koaf_gconv3x3_wgrad_ws(int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride);
 int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp, int32_t N, int32_t H,
                         int32_t W, int32_t C, int32_t stride, const float* in_sc,
-                        const float* in_sh, float* slabs, int32_t act16, void* stream);
+                        const float* in_sh, float* slabs, const float* dy_amax, int32_t act16, void* stream);
 
 /* ---- Stem: 7x7 s2 p3 conv on the 1->3 channel-repeated image (_torchvision.py:170; the
  * `repeat "b ch r c -> b (k ch) r c", k=3` of _xrNmrMcP.py:211-213 is folded: w1t = sum_c w[:,c]).

@@ -248,8 +248,9 @@ __global__ void stem_unfold_kernel(const float* __restrict__ dw1t, float* __rest
 // grouped 3x3: weights [C][9][Cg] <-> block-diagonal 64-channel slabs [C/64][64][9][64]
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) gconv_expand_kernel(const float* __restrict__ w, float* __restrict__ wexp,
-                                                           int C, int Cg) {
+                                                           int C, int Cg, float* __restrict__ amax) {
     const int64_t total = (int64_t)C * 9 * 64;
+    unsigned mb = 0u;          // largest magnitude seen by this thread, as bits (a NaN / Inf compares above every finite value)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ci = (int)(i & 63);
         int64_t r = i >> 6;
@@ -260,7 +261,9 @@ __global__ void __launch_bounds__(256) gconv_expand_kernel(const float* __restri
         float v = 0.f;
         if (ci >= g0 && ci < g0 + Cg) v = w[((int64_t)co * 9 + tap) * Cg + (ci - g0)];
         wexp[i] = v;
+        mb = max(mb, koaf_absbits(v));
     }
+    if (amax != nullptr) block_amax_raise_bits(mb, amax);
 }
 __global__ void __launch_bounds__(256) gconv_compress_kernel(const float* __restrict__ dwexp, float* __restrict__ dw,
                                                              int C, int Cg) {
@@ -564,10 +567,10 @@ extern "C" int koaf_conv2d_wgrad(const float* dy, const float* x, float* dw, int
 // ================================================================================================
 // grouped 3x3 (ResNeXt) as 64-channel block-diagonal slabs through the same GEMM
 // ================================================================================================
-extern "C" int koaf_gconv_expand_w(const float* w, float* wexp, int32_t C, int32_t groups, void* stream) {
+extern "C" int koaf_gconv_expand_w(const float* w, float* wexp, int32_t C, int32_t groups, float* amax, void* stream) {
     KOAF_REQUIRE(w && wexp && C % 64 == 0 && groups > 0 && C % groups == 0 && 64 % (C / groups) == 0,
                  "koaf_gconv_expand_w: C=%d groups=%d unsupported", C, groups);
-    hipLaunchKernelGGL(gconv_expand_kernel, dim3(1024), dim3(256), 0, STREAM, w, wexp, C, C / groups);
+    hipLaunchKernelGGL(gconv_expand_kernel, dim3(1024), dim3(256), 0, STREAM, w, wexp, C, C / groups, amax);
     return koaf_check_launch("koaf_gconv_expand_w");
 }
 extern "C" int koaf_gconv_compress_dw(const float* dwexp, float* dw, int32_t C, int32_t groups, void* stream) {
@@ -579,7 +582,7 @@ extern "C" int koaf_gconv_compress_dw(const float* dwexp, float* dw, int32_t C, 
 
 extern "C" int koaf_gconv3x3_fwd(const float* x, const float* wexp, float* y, int32_t N, int32_t H, int32_t W,
                                  int32_t C, int32_t stride, const float* in_sc, const float* in_sh, float* stats,
-                                 int32_t* stats_rows, const float* stats_shift, int32_t act16, void* stream) {
+                                 int32_t* stats_rows, const float* stats_shift, const float* w_amax, int32_t act16, void* stream) {
     KOAF_REQUIRE(x && wexp && y && N > 0 && C % 64 == 0, "koaf_gconv3x3_fwd: bad args");
     const int OH = conv_out(H, 3, stride, 1), OW = conv_out(W, 3, stride, 1);
     const int64_t M = (int64_t)N * OH * OW;
@@ -600,11 +603,12 @@ extern "C" int koaf_gconv3x3_fwd(const float* x, const float* wexp, float* y, in
     if (stats_rows) *stats_rows = (int)cdiv64(M, g.bm);
     g.A.tf_bs = 64;
     g.act16 = act16 ? 1 : 0;
+    if (w_amax && !act16) { g.fmt = 1; g.A.fscale = KOAF_ACT_SCALE; g.B.amax = w_amax; }      // (fp16 scheme: both magnitudes known)
     return koaf_gemm(&g, stream);
 }
 
 extern "C" int koaf_gconv3x3_dgrad(const float* dy, const float* wexp, float* dx, int32_t N, int32_t H, int32_t W,
-                                   int32_t C, int32_t stride, void* stream) {
+                                   int32_t C, int32_t stride, const float* w_amax, const float* dy_amax, void* stream) {
     KOAF_REQUIRE(dy && wexp && dx && N > 0 && C % 64 == 0, "koaf_gconv3x3_dgrad: bad args");
     const int OH = conv_out(H, 3, stride, 1), OW = conv_out(W, 3, stride, 1);
     const int64_t M = (int64_t)N * H * W;
@@ -622,6 +626,7 @@ extern "C" int koaf_gconv3x3_dgrad(const float* dy, const float* wexp, float* dx
     g.M = (int)M; g.N = 64; g.K = 576;
     g.C = dx; g.ldc = C; g.cbs1 = 64;
     g.bn = 64; g.bm = 128;
+    if (w_amax && dy_amax) { g.fmt = 1; g.A.amax = dy_amax; g.B.amax = w_amax; }
     return koaf_gemm(&g, stream);
 }
 
@@ -634,7 +639,7 @@ extern "C" int64_t koaf_gconv3x3_wgrad_ws(int32_t N, int32_t H, int32_t W, int32
 // dwexp [C/64][64][9][64]
 extern "C" int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp, int32_t N, int32_t H, int32_t W,
                                    int32_t C, int32_t stride, const float* in_sc, const float* in_sh, float* slabs,
-                                   int32_t act16, void* stream) {
+                                   const float* dy_amax, int32_t act16, void* stream) {
     KOAF_REQUIRE(dy && x && dwexp && slabs && N > 0 && C % 64 == 0, "koaf_gconv3x3_wgrad: bad args");
     const int OH = conv_out(H, 3, stride, 1), OW = conv_out(W, 3, stride, 1);
     const int64_t P = (int64_t)N * OH * OW;
@@ -657,6 +662,7 @@ extern "C" int koaf_gconv3x3_wgrad(const float* dy, const float* x, float* dwexp
         g.C = slabs;
         g.ldc = 576; g.cbs1 = 64 * 576;      // (unsplit case; split-K slabs are addressed by the kernel)
         g.act16 = act16 ? 3 : 0;
+        if (dy_amax && !act16) { g.fmt = 1; g.A.amax = dy_amax; g.B.fscale = KOAF_ACT_SCALE; }
         int rc = koaf_gemm(&g, stream);
         if (rc != KOAF_OK) return rc;
     }

@@ -224,7 +224,8 @@ def _conv_bwd(conv, dc, x, N, H, W, in_saved, wexp, residual=None, need_dx=True,
     k, s, p, g = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.groups
     wimg = weight_planes(conv.weight) if g == 1 else None
     if isinstance(dc, ops.BnApply) and (g != 1 or (need_dx and wimg is None)):
-        dc = dc.materialize(want_amax=(g == 1))        # grouped 3x3 / no weight plane images: the element-wise pass
+        dc = dc.materialize(want_amax=True)            # grouped 3x3 / no weight plane images: the element-wise pass (max |dc| rides along:
+        #                                                the fp16 scheme of both kinds of consumer)
     amax = getattr(dc, "_koaf_amax", None)
     sc, sh = (in_saved[2], in_saved[3]) if in_saved is not None else (None, None)
     gw, acc = grad_target(conv.weight)

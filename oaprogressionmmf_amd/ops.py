@@ -370,8 +370,13 @@ def conv2d_wgrad(dy, x, dw, N, H, W, Cin, Cout, KH, KW, stride, pad, in_sc=None,
 
 
 def gconv_expand_w(w, C, groups):
+    """block-diagonal 64-channel slabs of a grouped 3x3 weight; with the convolutions on the fp16 scheme max |w| rides on the result
+    (wexp._koaf_amax: the grouped calls then run three MFMAs per product instead of six, koaf.h)"""
     wexp = _empty((C // 64, 64, 9, 64), w)
-    check(lib().koaf_gconv_expand_w(_ptr(w), _ptr(wexp), C, groups, _stream()), "gconv_expand_w")
+    amax = torch.zeros(1, device=w.device, dtype=torch.float32) if CONV_F16 else None
+    check(lib().koaf_gconv_expand_w(_ptr(w), _ptr(wexp), C, groups, _ptr(amax), _stream()), "gconv_expand_w")
+    if amax is not None:
+        wexp._koaf_amax = amax
     return wexp
 
 
@@ -388,20 +393,25 @@ def gconv3x3_fwd(x, wexp, N, H, W, C, stride, in_sc=None, in_sh=None, stats=Fals
     if stats:
         part = _empty(((N * OH * OW + 127) // 128, 2, C), x)
     e0 = _prof_begin()
+    wam = getattr(wexp, "_koaf_amax", None)
     check(L.koaf_gconv3x3_fwd(_ptr(x), _ptr(wexp), _ptr(y), N, H, W, C, stride, _ptr(in_sc), _ptr(in_sh), _ptr(part),
-                              ctypes.addressof(rows), _ptr(shift) if stats else None, _a16(x), _stream()), "gconv3x3_fwd")
+                              ctypes.addressof(rows), _ptr(shift) if stats else None, _ptr(wam), _a16(x), _stream()), "gconv3x3_fwd")
     _prof_end(e0, "gemm", 2.0 * N * OH * OW * C * 9 * (C // 32), f"gconv_fwd s{stride} C{C} px{N*OH*OW}",   # algorithmic (32 groups)
-              N * H * W * C + N * OH * OW * C + 9 * C * (C // 32))
+              N * H * W * C + N * OH * OW * C + 9 * C * (C // 32), mpp=3 if (wam is not None and not _a16(x)) else 6)
     return y, part
 
 
 def gconv3x3_dgrad(dy, wexp, N, H, W, C, stride):
+    """dy with dy._koaf_amax (max |dy|, left by BnApply.materialize(want_amax=True)) and wexp with its max |w|: fp16 scheme"""
     dx = _empty((N, H, W, C), dy)
     e0 = _prof_begin()
-    check(lib().koaf_gconv3x3_dgrad(_ptr(dy), _ptr(wexp), _ptr(dx), N, H, W, C, stride, _stream()), "gconv3x3_dgrad")
+    wam, dam = getattr(wexp, "_koaf_amax", None), getattr(dy, "_koaf_amax", None)
+    if wam is None or dam is None:
+        wam = dam = None
+    check(lib().koaf_gconv3x3_dgrad(_ptr(dy), _ptr(wexp), _ptr(dx), N, H, W, C, stride, _ptr(wam), _ptr(dam), _stream()), "gconv3x3_dgrad")
     _prof_end(e0, "gemm", 2.0 * N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C * 9 * (C // 32),
               f"gconv_dgrad s{stride} C{C} px{N*H*W}",
-              N * H * W * C + N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C + 9 * C * (C // 32))
+              N * H * W * C + N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C + 9 * C * (C // 32), mpp=3 if wam is not None else 6)
     return dx
 
 
@@ -411,11 +421,13 @@ def gconv3x3_wgrad(dy, x, N, H, W, C, stride, in_sc=None, in_sh=None):
     slabs = _empty((ws,), dy)
     dwexp = _empty((C // 64, 64, 9, 64), dy)
     e0 = _prof_begin()
+    dam = getattr(dy, "_koaf_amax", None) if CONV_F16 else None
     check(L.koaf_gconv3x3_wgrad(_ptr(dy), _ptr(x), _ptr(dwexp), N, H, W, C, stride, _ptr(in_sc), _ptr(in_sh),
-                                _ptr(slabs), _a16(x), _stream()), "gconv3x3_wgrad")
+                                _ptr(slabs), _ptr(dam), _a16(x), _stream()), "gconv3x3_wgrad")
     _prof_end(e0, "gemm", 2.0 * N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C * 9 * (C // 32),
               f"gconv_wgrad s{stride} C{C} px{N*H*W}",
-              N * H * W * C + N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C + 9 * C * (C // 32))
+              N * H * W * C + N * conv_out(H, 3, stride, 1) * conv_out(W, 3, stride, 1) * C + 9 * C * (C // 32),
+              mpp=3 if (dam is not None and not _a16(x)) else 6)
     return dwexp
 
 

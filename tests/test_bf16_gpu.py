@@ -84,6 +84,7 @@ def test_bf16_storage_equals_fp32_mode_on_widened_inputs(dev):
     xg16 = rnd(N, H, W, Cg).to(dev).bfloat16()
     wg = rnd(Cg, 3, 3, Cg // 32, scale=0.1).to(dev)
     wexp = ops.gconv_expand_w(wg, Cg, 32)
+    del wexp._koaf_amax       # (the storage mode keeps the grouped calls on the bf16 scheme: compare on that scheme)
     scg, shg = torch.ones(Cg, device=dev), torch.zeros(Cg, device=dev)
     yg32, sg32 = ops.gconv3x3_fwd(xg16.float(), wexp, N, H, W, Cg, 1, scg, shg, stats=True)
     yg16, sg16 = ops.gconv3x3_fwd(xg16, wexp, N, H, W, Cg, 1, scg, shg, stats=True)

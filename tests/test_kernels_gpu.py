@@ -136,8 +136,11 @@ def test_conv2d_wgrad_large_splitk(dev):
     assert rel_err(dw.cpu().reshape(Cout, Cin), ref) < BWD
 
 
+@pytest.mark.parametrize("scheme", ["bf16", "f16"])
 @pytest.mark.parametrize("C,groups,stride,H", [(128, 32, 1, 22), (256, 32, 2, 22), (512, 32, 1, 11), (1024, 32, 2, 11)])
-def test_gconv3x3(dev, C, groups, stride, H):
+def test_gconv3x3(dev, C, groups, stride, H, scheme):
+    """scheme f16: max |w| rides on the expanded weight and max |dy| on the gradient, the three calls run the fp16 scheme (three
+    MFMAs per product); bf16: the scalars are withheld, six.  Same bars."""
     from oaprogressionmmf_amd import ops
     N, W = 2, H
     Cg = C // groups
@@ -152,11 +155,16 @@ def test_gconv3x3(dev, C, groups, stride, H):
     y_ref.backward(dy.double())
     xd, wp = nhwc(x).to(dev), packw(w).to(dev)
     wexp = ops.gconv_expand_w(wp, C, groups)
+    assert float(wexp._koaf_amax) == float(wp.abs().max())
+    if scheme == "bf16":
+        del wexp._koaf_amax
     y, part = ops.gconv3x3_fwd(xd, wexp, N, H, W, C, stride, sc.to(dev), sh.to(dev), stats=True)
     assert rel_err(nchw(y.cpu()), y_ref) < 2e-6
     yr = y_ref.detach().permute(1, 0, 2, 3).reshape(C, -1)
     assert rel_err(part[:, 0].double().sum(0).cpu(), yr.sum(1)) < 1e-4
     dyd = nhwc(dy).to(dev)
+    if scheme == "f16":
+        dyd._koaf_amax = dyd.abs().max().reshape(1)
     dx = ops.gconv3x3_dgrad(dyd, wexp, N, H, W, C, stride)
     assert rel_err(nchw(dx.cpu()), xin.grad) < BWD
     dwexp = ops.gconv3x3_wgrad(dyd, xd, N, H, W, C, stride, sc.to(dev), sh.to(dev))
