@@ -9,6 +9,7 @@ PROG=$GRAFT_REPO_ROOT/scripts/bench_gemm_pmc.py
 ARGS="20"
 if [ "$2" = "short" ]; then PROG=$GRAFT_REPO_ROOT/scripts/bench_gemm_pmc_short.py; ARGS="12 $OUT/plan.json"; fi
 if [ "$2" = "t2d" ]; then PROG=$GRAFT_REPO_ROOT/scripts/bench_t2d_pmc.py; ARGS="12 $OUT/plan.json"; fi            # (round 4: rectangle-tile 3x3 kernel vs the raster halo kernel)
+if [ "$2" = "stream" ]; then PROG=$GRAFT_REPO_ROOT/scripts/bench_stream_pmc.py; ARGS="10 $OUT/plan.json"; fi   # (round 4: streamed 1x1 kernels vs the block-wide loader)
 if [ "$2" = "new" ]; then PROG=$GRAFT_REPO_ROOT/scripts/bench_new_kernels_pmc.py; ARGS="10 $OUT/plan.json"; fi      # (the round-3 ring / stem / attention kernels)
 export TMPDIR=/tmp
 cd /tmp

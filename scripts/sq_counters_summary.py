@@ -93,7 +93,7 @@ doc = {"command": "bash scripts/collect_sq_counters.sh <dir> [short] (two rocpro
        "note": "averages over the launches of each kernel but its first two, on random operands; *_per_mfma are wave-instruction counts per matrix instruction; "
                "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (duration x clock); wait_* / active_* are shares of SQ_WAVE_CYCLES",
        "kernels": out}
-fname = f"{RND}_sq_counters_new_kernels.json" if BYNAME else (f"{RND}_gemm_sq_counters_short.json" if PLAN is not None else f"{RND}_gemm_sq_counters.json")
+fname = sys.argv[3] if len(sys.argv) > 3 else f"{RND}_sq_counters_new_kernels.json" if BYNAME else (f"{RND}_gemm_sq_counters_short.json" if PLAN is not None else f"{RND}_gemm_sq_counters.json")
 json.dump(doc, open(ROOT / "profiles" / fname, "w"), indent=1)
 for k in out:
     print(k)
