@@ -39,6 +39,7 @@
 //       Double-buffered: the DMA of k-tile t+1 lands while tile t is multiplied.
 #include "koaf_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // In-kernel phase stamps (diagnostic builds only: make STAMPS=1 -> libkoaf_stamps.so, scripts/stamps_*.py): thread 0 of every
 // block adds the 100 MHz real-time counter differences between its phase boundaries to a device table.
@@ -1813,27 +1814,38 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
         int bst = 0;
         KOAF_STAMP(1);
         [[maybe_unused]] unsigned long long kst_c = 0, kst_w = 0;      // (stamps build: time in consume() incl. the wait for A; in the B wait + barrier)
-#pragma unroll 1
-        for (int s0 = 0; s0 < nstep; s0 += SD) {
-#pragma unroll
-            for (int d = 0; d < SD; ++d) {
-                const int ss = s0 + d;
-                [[maybe_unused]] const unsigned long long ta0 = KOAF_STAMP_NOW();
-                st.consume(st.sl[d], Aim, kbeg + ss * BK, side);
-                [[maybe_unused]] const unsigned long long ta1 = KOAF_STAMP_NOW();
-                // younger than B(ss): the A tiles of steps ss - 2 and ss - 1, B(ss + 1)
-                wait_barrier((issues(ss - 2) ? NLA : 0) + (issues(ss - 1) ? NLA : 0) + ((ss + 1 < nstep) ? NB : 0));
-                kst_c += ta1 - ta0;
-                kst_w += KOAF_STAMP_NOW() - ta1;
-                if (ss + 2 < nstep) {
-                    int b2 = bst + 2;
-                    if (b2 >= 3) b2 -= 3;
-                    lp.template issue<NPL>(p.B, Bpl, sb0 + b2 * (B_ELEMS * 4));
-                }
-                if (issues(ss)) st.issue(st.sl[d], cursor_next, p.M);
-                mma(Aim, (const unsigned*)(Bs0 + bst * B_ELEMS));
-                if (++bst == 3) bst = 0;
+        // one step; ISSUE: it fetches an A tile (compile-time: the steps that do and the steps that do not sit in two loops, because a
+        // load issued on one path only makes hipcc count its waits for the path WITHOUT it -- every wait for A then retires nearly
+        // everything in flight)
+        auto sstep = [&](auto D, auto ISSUE, int ss) {
+            constexpr int d = decltype(D)::value;
+            [[maybe_unused]] const unsigned long long ta0 = KOAF_STAMP_NOW();
+            st.consume(st.sl[d], Aim, kbeg + ss * BK, side);
+            [[maybe_unused]] const unsigned long long ta1 = KOAF_STAMP_NOW();
+            // younger than B(ss): the A tiles of steps ss - 2 and ss - 1, B(ss + 1)
+            wait_barrier((issues(ss - 2) ? NLA : 0) + (issues(ss - 1) ? NLA : 0) + ((ss + 1 < nstep) ? NB : 0));
+            kst_c += ta1 - ta0;
+            kst_w += KOAF_STAMP_NOW() - ta1;
+            if (ss + 2 < nstep) {
+                int b2 = bst + 2;
+                if (b2 >= 3) b2 -= 3;
+                lp.template issue<NPL>(p.B, Bpl, sb0 + b2 * (B_ELEMS * 4));
             }
+            if constexpr (decltype(ISSUE)::value) st.issue(st.sl[d], cursor_next, p.M);
+            mma(Aim, (const unsigned*)(Bs0 + bst * B_ELEMS));
+            if (++bst == 3) bst = 0;
+        };
+        static_assert(SD == 0 || SD == 2, "two steps per group");
+        const int nmain = (s_m0n >= 0) ? nstep : nstep - SD;        // the steps that issue (all of them when a next tile follows)
+        int s0 = 0;
+#pragma unroll 1
+        for (; s0 < nmain; s0 += SD) {
+            sstep(std::integral_constant<int, 0>{}, std::true_type{}, s0);
+            sstep(std::integral_constant<int, 1>{}, std::true_type{}, s0 + 1);
+        }
+        if (s0 < nstep) {
+            sstep(std::integral_constant<int, 0>{}, std::false_type{}, s0);
+            sstep(std::integral_constant<int, 1>{}, std::false_type{}, s0 + 1);
         }
         // every wave is done with the operand images (the epilogue's staging tile covers them); the next tile's A stays in flight
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
