@@ -9,6 +9,8 @@ not depend on the size (the oracle-compared cases run at reduced sizes in the ot
    rounding in the path, including the bf16 splits of the gradient contractions);
  * BASELINE's synthetic tensor shapes (XR 310^2, three MRI of 160 slices x 384^2): sample independence in eval at batch 2,
    and one train step with activation recompute against the same step without it."""
+import gc
+
 import numpy as np
 import pytest
 import torch
@@ -239,8 +241,10 @@ def test_headline_syn3_batch8_train_step_and_eval(dev):
         m.train()
         m.zero_grad()
         torch.cuda.synchronize()
+        gc.collect()                                     # (tensors of earlier tests that only a reference cycle still holds)
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
+        print(f"\n[syn3 batch 8] allocated before the step: {torch.cuda.memory_allocated() / 2**30:.2f} GiB")
         loss = loss_fn(input=m(*xs)["main"].squeeze(1), target=y.long().squeeze(1))
         loss.backward()
         torch.cuda.synchronize()
