@@ -543,13 +543,17 @@ int koaf_colsum(const float* x, float* out, int32_t rows, int32_t C, float* part
 
 /* ---- FocalLoss (_losses.py:89-108): loss = mean|sum( -(1-pt)^gamma * logpt ), logpt = -F.cross_entropy(x, t, weight, 'none') ----
  * logits [B,C,S] -- S = product of the spatial dims of a (b, ch, d0, d1, ...) input, 1 for (b, ch) --, target int64 [B,S],
- * class_weight [C] or NULL; writes the scalar loss and dlogits (= d loss / d logits, same layout).  */
+ * class_weight [C] or NULL; writes the scalar loss and dlogits (= d loss / d logits, same layout).
+ * ws: koaf_loss_ws(B, S) floats or NULL.  Up to 8192 elements (the models' (b, 2) logits) one block does everything; beyond that,
+ * with a workspace, the same arithmetic runs on a grid of 4096-element blocks whose partial sums are added by one block in index
+ * order (two fixed-order stages: the result does not depend on scheduling; without a workspace the one block walks everything). */
+int64_t koaf_loss_ws(int32_t B, int64_t S);
 int koaf_focal_loss(const float* logits, const int64_t* target, const float* class_weight, float* loss, float* dlogits,
-                    int32_t B, int32_t C, int64_t S, float gamma, int32_t reduction_mean, void* stream);
+                    int32_t B, int32_t C, int64_t S, float gamma, int32_t reduction_mean, float* ws, void* stream);
 /* softmax-CE (CrossEntropyLoss wrapper = nn.CrossEntropyLoss(weight=class_weight), _losses.py:13-49): weighted mean
  * sum_i w[t_i] * (-log p_i[t_i]) / sum_i w[t_i] */
 int koaf_ce_loss(const float* logits, const int64_t* target, const float* class_weight, float* loss, float* dlogits,
-                 int32_t B, int32_t C, int64_t S, void* stream);
+                 int32_t B, int32_t C, int64_t S, float* ws, void* stream);
 
 /* ---- torch.optim.Adam (coupled L2) over a flat arena (_optimizers.py:47-52) ------------------ */
 /* vmax (nullable): amsgrad -- the running maximum of the second moment, updated in place and used in the denominator */

@@ -993,6 +993,89 @@ __global__ void __launch_bounds__(256) focal_loss_kernel(const float* __restrict
     if (threadIdx.x == 0) *loss = red[0] * wgt;
 }
 
+// Segmentation-sized logits (B * S elements beyond one block's reach): the same arithmetic on a grid, reduced in two fixed-order
+// stages -- block k owns the elements [k * chunk, (k + 1) * chunk), its 256 lanes stride through them and meet in one LDS tree;
+// the per-block partials ws[k] are then summed by ONE block in index order, so the result does not depend on scheduling.
+// LOSS_PASS 0: ws[k] = the block's share of the (weighted) mean's denominator (cross-entropy only);
+// LOSS_PASS 1: gradients + ws[k] = the block's loss sum; wden = device scalar of the denominator (NULL: n, or 1 for a sum)
+template <int LOSS_PASS>
+__global__ void __launch_bounds__(256) loss_grid_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                        const float* __restrict__ cw, float* __restrict__ dlogits, float* __restrict__ ws,
+                                                        const float* __restrict__ wden, int B, int C, int64_t S, int64_t chunk, float gamma,
+                                                        int mean, int focal, uint32_t* status) {
+    __shared__ float red[256];
+    const int64_t n = (int64_t)B * S;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    float acc = 0.f;
+    unsigned nbad = 0;
+    if constexpr (LOSS_PASS == 0) {
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+            const int64_t tg = target[i];
+            if (tg >= 0 && tg < C) acc += cw ? cw[(int)tg] : 1.f;
+        }
+    } else {
+        const float wgt = mean ? 1.f / (wden ? *wden : (float)n) : 1.f;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+            const int64_t b = i / S, sp = i - b * S;
+            const float* x = logits + b * C * S + sp;
+            float* d = dlogits + b * C * S + sp;
+            const int64_t tg64 = target[i];
+            if (tg64 < 0 || tg64 >= C) {
+                nbad += (tg64 != -100) ? 1u : 0u;
+                for (int j = 0; j < C; ++j) d[j * S] = 0.f;
+                continue;
+            }
+            float m = -INFINITY;
+            for (int j = 0; j < C; ++j) m = fmaxf(m, x[j * S]);
+            float se = 0.f;
+            for (int j = 0; j < C; ++j) se += expf(x[j * S] - m);
+            const float lse = m + logf(se);
+            const int tg = (int)tg64;
+            const float w = cw ? cw[tg] : 1.f;
+            const float logpt = w * (x[tg * S] - lse);
+            const float pt = expf(logpt);
+            float li, dl;
+            if (focal) {
+                const float om = 1.f - pt;
+                const float pw = powf(om, gamma);
+                li = -pw * logpt;
+                const float pw1 = (gamma == 0.f) ? 0.f : gamma * powf(om, gamma - 1.f);
+                dl = -pw + pw1 * pt * logpt;
+            } else {
+                li = -logpt;
+                dl = -1.f;
+            }
+            acc += li;
+            for (int j = 0; j < C; ++j) {
+                const float pj = expf(x[j * S] - lse);
+                d[j * S] = dl * w * ((j == tg ? 1.f : 0.f) - pj) * wgt;
+            }
+        }
+        koaf_status_add(status, 1, nbad);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ws[blockIdx.x] = red[0];
+}
+// out = (sum_k ws[k]) * scale, k in index order (lane l takes k = l, l + 256, ...; one LDS tree); scale: 1 / *wden, 1 / nden or 1
+__global__ void __launch_bounds__(256) loss_grid_sum_kernel(const float* __restrict__ ws, int nblk, float* __restrict__ out,
+                                                            const float* __restrict__ wden, float nden) {
+    __shared__ float red[256];
+    float a = 0.f;
+    for (int k = threadIdx.x; k < nblk; k += 256) a += ws[k];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0] * (wden ? 1.f / *wden : (nden > 0.f ? 1.f / nden : 1.f));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam single-tensor update rule, coupled L2; adamw: decoupled)
 // ------------------------------------------------------------------------------------------------
@@ -1414,17 +1497,46 @@ extern "C" int64_t koaf_colsum_ws(int32_t rows, int32_t C) {
     return (int64_t)g.nblk * C;
 }
 
+// elements one block of focal_loss_kernel covers in a few passes; beyond it the grid form runs (when the caller brought a workspace)
+static const int64_t LOSS_ONE_BLOCK = 8192;
+static const int64_t LOSS_CHUNK = 4096;        // elements per block of the grid form
+extern "C" int64_t koaf_loss_ws(int32_t B, int64_t S) {
+    const int64_t n = (int64_t)B * S;
+    return n > LOSS_ONE_BLOCK ? 2 * ((n + LOSS_CHUNK - 1) / LOSS_CHUNK) + 4 : 0;
+}
+static int loss_grid(const float* logits, const int64_t* target, const float* cw, float* loss, float* dlogits, int B, int C, int64_t S,
+                     float gamma, int mean, int focal, float* ws, hipStream_t st) {
+    const int64_t n = (int64_t)B * S;
+    const int nblk = (int)((n + LOSS_CHUNK - 1) / LOSS_CHUNK);
+    float* wl = ws;                 // [nblk] loss partials
+    float* wd = ws + nblk;          // [nblk] denominator partials, then the denominator itself at wd[nblk]
+    const float* wden = nullptr;
+    if (!focal) {                   // cross-entropy: the weighted mean divides by the weights of the elements that count
+        hipLaunchKernelGGL((loss_grid_kernel<0>), dim3(nblk), dim3(256), 0, st, logits, target, cw, dlogits, wd, (const float*)nullptr, B, C, S,
+                           LOSS_CHUNK, gamma, mean, focal, koaf_status_ptr());
+        hipLaunchKernelGGL(loss_grid_sum_kernel, dim3(1), dim3(256), 0, st, wd, nblk, wd + nblk, (const float*)nullptr, 0.f);
+        wden = wd + nblk;
+    }
+    hipLaunchKernelGGL((loss_grid_kernel<1>), dim3(nblk), dim3(256), 0, st, logits, target, cw, dlogits, wl, wden, B, C, S, LOSS_CHUNK, gamma,
+                       mean, focal, koaf_status_ptr());
+    hipLaunchKernelGGL(loss_grid_sum_kernel, dim3(1), dim3(256), 0, st, wl, nblk, loss, wden, (mean && !wden) ? (float)n : 0.f);
+    return koaf_check_launch("koaf_loss (grid form)");
+}
 extern "C" int koaf_focal_loss(const float* logits, const int64_t* target, const float* class_weight, float* loss,
                                float* dlogits, int32_t B, int32_t C, int64_t S, float gamma, int32_t reduction_mean,
-                               void* stream) {
+                               float* ws, void* stream) {
     KOAF_REQUIRE(logits && target && loss && dlogits && B > 0 && C > 0 && S > 0, "koaf_focal_loss: bad args");
+    if (ws && (int64_t)B * S > LOSS_ONE_BLOCK)
+        return loss_grid(logits, target, class_weight, loss, dlogits, B, C, S, gamma, reduction_mean, 1, ws, STREAM);
     hipLaunchKernelGGL(focal_loss_kernel, dim3(1), dim3(256), 0, STREAM, logits, target, class_weight, loss, dlogits, B, C, S,
                        gamma, reduction_mean, 1, koaf_status_ptr());
     return koaf_check_launch("koaf_focal_loss");
 }
 extern "C" int koaf_ce_loss(const float* logits, const int64_t* target, const float* class_weight, float* loss,
-                            float* dlogits, int32_t B, int32_t C, int64_t S, void* stream) {
+                            float* dlogits, int32_t B, int32_t C, int64_t S, float* ws, void* stream) {
     KOAF_REQUIRE(logits && target && loss && dlogits && B > 0 && C > 0 && S > 0, "koaf_ce_loss: bad args");
+    if (ws && (int64_t)B * S > LOSS_ONE_BLOCK)
+        return loss_grid(logits, target, class_weight, loss, dlogits, B, C, S, 0.f, 1, 0, ws, STREAM);
     hipLaunchKernelGGL(focal_loss_kernel, dim3(1), dim3(256), 0, STREAM, logits, target, class_weight, loss, dlogits, B, C, S,
                        0.f, 1, 0, koaf_status_ptr());
     return koaf_check_launch("koaf_ce_loss");

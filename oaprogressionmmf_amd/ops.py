@@ -772,11 +772,13 @@ def focal_loss(logits, target, gamma, mean=True, focal=True, class_weight=None):
         raise KoafError(f"loss: target shape {tuple(target.shape)} does not match logits {tuple(logits.shape)}")
     loss = _empty((), logits)
     dl = torch.empty_like(logits)
+    nws = lib().koaf_loss_ws(B, S)          # (segmentation-sized inputs: the grid form's partial sums)
+    ws = _empty((nws,), logits) if nws > 0 else None
     if focal:
         check(lib().koaf_focal_loss(_ptr(logits), _ptr(target), _ptr(class_weight), _ptr(loss), _ptr(dl), B, C, S, gamma,
-                                    1 if mean else 0, _stream()), "focal_loss")
+                                    1 if mean else 0, _ptr(ws), _stream()), "focal_loss")
     else:
-        check(lib().koaf_ce_loss(_ptr(logits), _ptr(target), _ptr(class_weight), _ptr(loss), _ptr(dl), B, C, S, _stream()), "ce_loss")
+        check(lib().koaf_ce_loss(_ptr(logits), _ptr(target), _ptr(class_weight), _ptr(loss), _ptr(dl), B, C, S, _ptr(ws), _stream()), "ce_loss")
     return loss, dl
 
 

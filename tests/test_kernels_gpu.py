@@ -1089,3 +1089,35 @@ def test_streamed_1x1_kernels_match_the_block_wide_loader(dev, N, H, W, Cin, Cou
     for name in g0:
         for ta, tb in zip(g0[name], g1[name]):
             assert torch.equal(ta, tb), name
+
+
+def test_losses_on_segmentation_sized_logits_run_on_a_grid(dev):
+    """(b, ch, d0, d1) logits beyond one block's reach (koaf_loss_ws > 0): the focal loss / cross-entropy arithmetic on a grid of
+    4096-element blocks with a two-stage fixed-order reduction -- against torch in float64 (class weights, ignored labels), and twice
+    for determinism.  _losses.py:36,56-57,91-108."""
+    from oaprogressionmmf_amd import ops
+    from oaprogressionmmf_amd._lib import lib
+    B, C, H, W = 2, 3, 70, 71
+    assert lib().koaf_loss_ws(B, H * W) > 0 and lib().koaf_loss_ws(37, 1) == 0
+    lg = rnd(B, C, H, W) * 2
+    tg = torch.randint(0, C, (B, H, W), generator=G)
+    tg[0, 3, 5] = tg[1, 60, 70] = -100
+    cw = torch.tensor([0.5, 2.0, 1.25])
+    for w in (None, cw):
+        wd = None if w is None else w.double()
+        x = lg.clone().double().requires_grad_(True)
+        ce = F.cross_entropy(x, tg, weight=wd)
+        ce.backward()
+        loss, dl = ops.focal_loss(lg.to(dev), tg.to(dev), 0.0, focal=False, class_weight=None if w is None else w.to(dev))
+        assert abs(loss.item() - ce.item()) < 2e-6 and rel_err(dl.cpu(), x.grad) < 1e-5
+        for mean in (True, False):
+            x = lg.clone().double().requires_grad_(True)
+            logpt = -F.cross_entropy(x, tg, weight=wd, reduction="none")
+            fl = -((1 - logpt.exp()) ** 2.0) * logpt
+            fl = fl.mean() if mean else fl.sum()
+            fl.backward()
+            loss, dl = ops.focal_loss(lg.to(dev), tg.to(dev), 2.0, mean=mean, class_weight=None if w is None else w.to(dev))
+            assert abs(loss.item() - fl.item()) < 2e-6 * max(1.0, abs(fl.item())) and rel_err(dl.cpu(), x.grad) < 1e-5
+            assert float(dl[0, :, 3, 5].abs().max()) == 0.0 and float(dl[1, :, 60, 70].abs().max()) == 0.0
+            loss2, dl2 = ops.focal_loss(lg.to(dev), tg.to(dev), 2.0, mean=mean, class_weight=None if w is None else w.to(dev))
+            assert loss2.item() == loss.item() and torch.equal(dl2, dl)
