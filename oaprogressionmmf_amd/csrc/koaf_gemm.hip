@@ -607,6 +607,7 @@ struct StreamA {
     int64_t ld;
     float fsc;
     bool tail2;
+    bool once;        // the A operand is read by ONE column tile (N <= BN): non-temporal loads (KOAF_STREAM_NT=0: off)
     unsigned satmax;
     // issue cursor: the k-tile the next issue() fetches
     v4l ibase;        // element offset of each unit's (clamped) row + 4 (l % 8)
@@ -633,6 +634,7 @@ struct StreamA {
         ld = op.ld;
         fsc = scale;
         tail2 = (TF == 3) && op.sc2 != nullptr;
+        once = false;
         satmax = 0u;
         tab = nullptr;
         kbeg = kb; kend = ke;
@@ -664,10 +666,19 @@ struct StreamA {
                 if (tail2) { s.tk = *(const v4f*)(sc2 + c); s.tq = *(const v4f*)(sh2 + c); }
             }
         }
+        if (once) {
+            // (one column tile: every A byte is read exactly once by the whole grid -- streamed past the caches' replacement order)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            s.r[i] = *(const v4f*)(ptr + ibase[i] + ik);
-            if constexpr (TWO) s.r2[i] = *(const v4f*)(ptr2 + ibase[i] + ik);
+            for (int i = 0; i < 4; ++i) {
+                s.r[i] = __builtin_nontemporal_load((const v4f*)(ptr + ibase[i] + ik));
+                if constexpr (TWO) s.r2[i] = __builtin_nontemporal_load((const v4f*)(ptr2 + ibase[i] + ik));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s.r[i] = *(const v4f*)(ptr + ibase[i] + ik);
+                if constexpr (TWO) s.r2[i] = *(const v4f*)(ptr2 + ibase[i] + ik);
+            }
         }
         ik += BK;
         if (ik >= kend) {
@@ -1341,6 +1352,7 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
     };
     if constexpr (AS) {
         st.init(p.A, Ap, m0, p.M, kbeg, kend, sca);
+        st.once = (ntn == 1) && p.prec != 55;
         if constexpr (TFA == 1) {
             for (int k = t; k < kend - kbeg; k += NT) { s_tab[k] = p.A.sc[kbeg + k] * sca; s_tab[STREAM_TAB_K + k] = p.A.sh[kbeg + k] * sca; }
             st.tab = s_tab;
@@ -2603,6 +2615,7 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     KOAF_REQUIRE(!g.cmap || vec, "koaf_gemm: row map needs the vector epilogue");
     KOAF_REQUIRE(!g.bnb_mode || vec, "koaf_gemm: fused BN-backward needs the vector epilogue");
     hipStream_t s = (hipStream_t)stream;
+    { static int nt = -1; if (nt < 0) { const char* e = getenv("KOAF_STREAM_NT"); nt = (e && e[0] == '0') ? 0 : 1; } if (!nt) g.prec = 55; }
     g.bm = tp.bm;
     g.bn = tp.bn;
     const int64_t tiles = cdiv64(g.M - g.m_base, tp.bm) * cdiv64(g.N, tp.bn);
