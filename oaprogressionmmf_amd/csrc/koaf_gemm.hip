@@ -1352,7 +1352,7 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
     };
     if constexpr (AS) {
         st.init(p.A, Ap, m0, p.M, kbeg, kend, sca);
-        st.once = (ntn == 1) && p.prec != 55;
+        st.once = (ntn == 1) && p.prec != 55;      // (prec is informational to the kernels; the launch code writes 55 there for KOAF_STREAM_NT=0)
         if constexpr (TFA == 1) {
             for (int k = t; k < kend - kbeg; k += NT) { s_tab[k] = p.A.sc[kbeg + k] * sca; s_tab[STREAM_TAB_K + k] = p.A.sh[kbeg + k] * sca; }
             st.tab = s_tab;
@@ -2615,6 +2615,8 @@ extern "C" int koaf_gemm(const KoafGemm* gp, void* stream) {
     KOAF_REQUIRE(!g.cmap || vec, "koaf_gemm: row map needs the vector epilogue");
     KOAF_REQUIRE(!g.bnb_mode || vec, "koaf_gemm: fused BN-backward needs the vector epilogue");
     hipStream_t s = (hipStream_t)stream;
+    // A/B switch KOAF_STREAM_NT=0: the streamed kernel's non-temporal A loads off.  It travels in `prec` (informational: no kernel
+    // reads it otherwise) of this launch's private copy of the descriptor.
     { static int nt = -1; if (nt < 0) { const char* e = getenv("KOAF_STREAM_NT"); nt = (e && e[0] == '0') ? 0 : 1; } if (!nt) g.prec = 55; }
     g.bm = tp.bm;
     g.bn = tp.bn;
