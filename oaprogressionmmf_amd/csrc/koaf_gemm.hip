@@ -1494,11 +1494,11 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
         const int hq = nh / NST, hr = nh - hq * NST;        // pieces at tap t < NST: hq + (t < hr)   (<= 2: np2 <= 14 NW)
         const int nstep = 9 * nchunk;
         struct Frags { v4i a[2][TM][2]; v4i b[2][TN][2]; };
-        auto load_frags = [&](Frags& f, int tap, int hbuf, int stage) {
+        // (shift: the tap's pixel offset in the halo, (kh - 1) W + (kw - 1), negated for the data gradient's flipped filter -- carried
+        // by the loop, not derived from the tap)
+        auto load_frags = [&](Frags& f, int shift, int hbuf, int stage) {
             const lds_u Ah = (lds_u)smem + hbuf * A_ELEMS;
             const lds_u Bu = (lds_u)smem + NBA * A_ELEMS + stage * B_ELEMS;
-            const int kh = tap / 3, kw = tap - 3 * kh;
-            const int shift = flip ? (1 - kh) * Wd + (1 - kw) : (kh - 1) * Wd + (kw - 1);
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
 #pragma unroll
@@ -1517,28 +1517,6 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
                 }
             }
         };
-        auto compute = [&](Frags& f, int tap) {
-            constexpr int PAH[3] = {1, 0, 0}, PBH[3] = {0, 1, 0};
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                v4i ap[TM][2];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int okm = -(int)((vb[i] >> tap) & 1u);       // all ones / zero: the tap's validity as an AND mask
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) ap[i][q] = and_mask(f.a[g][i][q], okm);
-                }
-#pragma unroll
-                for (int jn = 0; jn < TN; ++jn)
-#pragma unroll
-                    for (int term = 0; term < 3; ++term)
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ap[i][PAH[term]]),
-                                                                                __builtin_bit_cast(h16x8, f.b[g][jn][PBH[term]]),
-                                                                                acc[i][jn], 0, 0, 0);
-            }
-        };
         for (int idx = w; idx < np2; idx += NW) issue_halo(idx, 0, sm0);
 #pragma unroll
         for (int d = 0; d < 3; ++d) issue_b(d, 0, sb0 + d * (B_ELEMS * 4));       // (nstep >= 9)
@@ -1546,38 +1524,109 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         KOAF_STAMP(1);
         Frags F0, F1;
-        load_frags(F0, 0, 0, 0);
+        const int shift0 = flip ? Wd + 1 : -Wd - 1, dshift = flip ? -1 : 1, rshift = flip ? 2 - Wd : Wd - 2;     // tap 0; to the next tap in a row / to the next row
+        load_frags(F0, shift0, 0, 0);
+        int nshift = shift0, nkw = 0;       // of tap + 1 (advanced below)
         int tap = 0, chunk = 0, sb = 0;     // this step; sb = stage of its weight tile
         int itap = 3, ich = 0;              // (tap, chunk) of tile s + 3
         int hk = 0, hprev = 0;              // halo pieces of the next chunk issued so far / loads per wave at the previous step
-        auto body = [&](Frags& cur, Frags& nxt, bool has_next) {
-            // tile s + 1 (issued at step s - 2, the last loads of that step) has landed; what step s - 1 issued stays in flight
-            if (hprev == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW) : "memory");
-            else if (hprev == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW + 1) : "memory");
+        [[maybe_unused]] unsigned long long kst_hw = 0, kst_hv = 0;
+        // this wave's halo pieces inside the loop: slot hk of a chunk is piece 4 hk + w / 2 of plane w % 2 (idx = 8 hk + w above), so the
+        // plane, the lane's pixel offset and its 64-bit base are per-tile constants and a piece costs a clamp and one multiply-add
+        // (slots past the last piece repeat it)
+        const int ws = __builtin_amdgcn_readfirstlane(w);
+        const int h_npp = np2 >> 1, h_p0 = ws >> 1;
+        const int h_px = (int)hbase + (lane >> 2), h_last = (int)plast;
+        const unsigned short* const h_src = Apl + (ws & 1) * p.A.plane_stride + swz;
+        const unsigned h_dst = (ws & 1) * (A_PL * 4);
+        auto issue_halo_w = [&](int k, int chunk, unsigned buf) {
+            const int piece = min(4 * k + h_p0, h_npp - 1);
+            const int gp = min(max(h_px + 16 * piece, 0), h_last);
+            lds_dma16(h_src + ((int64_t)gp * CSa + chunk * 32), buf + h_dst + piece * 1024);
+        };
+        auto vm_wait = [&](int h) {
+            if (h == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW) : "memory");
+            else if (h == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW + 1) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BPW + 2) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // (and every wave holds the fragments of step s)
+        };
+        auto lgkm0_barrier = [&]() {
+            // (the wait is the BUILTIN: hipcc's wait-count pass does not read inline assembly and would take the fragment registers
+            // of step s for still in flight at their MFMAs)
+            __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
+            asm volatile("s_barrier" ::: "memory");
+        };
+        // One step = four (two: 64 columns) groups of six MFMAs (k-group g, column tile jn), each followed by a piece of everything else (the
+        // fragment reads of step s + 1, the two halo pieces, the weight tile), pinned by scheduling barriers: a wave issues in
+        // order, and the address arithmetic in one block in front of 24 back-to-back MFMAs ran with the matrix pipe idle in both
+        // waves of the SIMD (the step barrier keeps them in lockstep).
+        auto mask_g = [&](Frags& f, int g) {       // (in place: the set is dead after its step)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int okm = -(int)((vb[i] >> tap) & 1u);       // all ones / zero: the tap's validity as an AND mask
+#pragma unroll
+                for (int q = 0; q < 2; ++q) f.a[g][i][q] = and_mask(f.a[g][i][q], okm);
+            }
+        };
+        auto mma_q = [&](Frags& f, int g, int jn) {
+            constexpr int PAH[3] = {1, 0, 0}, PBH[3] = {0, 1, 0};
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, f.a[g][i][PAH[term]]),
+                                                                        __builtin_bit_cast(h16x8, f.b[g][jn][PBH[term]]),
+                                                                        acc[i][jn], 0, 0, 0);
+        };
+        constexpr int NQ = 2 * TN;          // MFMA groups of a step: (g, jn)
+        static_assert(NQ == 4 || NQ == 2, "the four pieces follow the MFMA groups in ones or twos");
+        auto body = [&](Frags& cur, Frags& nxt) {
+            [[maybe_unused]] const unsigned long long tw0 = KOAF_STAMP_NOW();
+            // tile s + 1 (issued at step s - 2, the last loads of that step) has landed; what step s - 1 issued stays in flight
+            vm_wait(hprev);
+            lgkm0_barrier();
+            [[maybe_unused]] const unsigned long long tw1 = KOAF_STAMP_NOW();
             const bool more_chunks = chunk + 1 < nchunk;
             const int hc = (more_chunks && tap < NST) ? hq + (tap < hr ? 1 : 0) : 0;
             const unsigned Anext = sm0 + ((chunk + 1) & 1) * (A_ELEMS * 4);
-            if (hc > 0) { const int idx = hk * NW + w; issue_halo(idx < np2 ? idx : np2 - 1, chunk + 1, Anext); ++hk; }
-            if (hc > 1) { const int idx = hk * NW + w; issue_halo(idx < np2 ? idx : np2 - 1, chunk + 1, Anext); ++hk; }
             hprev = hc;
-            // tile s + 3 into the stage tile s leaves (past the end: re-fetch the last tile there -- nobody reads it, the counts stay uniform)
-            issue_b(ich < nchunk ? itap : 8, ich < nchunk ? ich : nchunk - 1, sb0 + sb * (B_ELEMS * 4));
-            if (++itap == 9) { itap = 0; ++ich; }
             int ntap = tap + 1, nch2 = chunk;
-            if (ntap == 9) { ntap = 0; ++nch2; hk = 0; }
-            if (++sb == 3) sb = 0;
-            if (has_next) load_frags(nxt, ntap, nch2 & 1, sb);
-            compute(cur, tap);
+            if (++nkw == 3) { nkw = 0; nshift += rshift; } else nshift += dshift;
+            if (ntap == 9) { ntap = 0; ++nch2; nshift = shift0; }
+            int sbn = sb + 1;
+            if (sbn == 3) sbn = 0;
+            auto piece = [&](int f) {
+                __builtin_amdgcn_sched_barrier(0);
+                // (past the last step the reads fetch a stage / halo nobody uses: unconditional, so that the two register sets stay two)
+                if (f == 0) load_frags(nxt, nshift, nch2 & 1, sbn);
+                if (f == 1 && hc > 0) { issue_halo_w(hk, chunk + 1, Anext); ++hk; }
+                if (f == 2 && hc > 1) { issue_halo_w(hk, chunk + 1, Anext); ++hk; }
+                // tile s + 3 into the stage tile s leaves (past the end: re-fetch the last tile there -- nobody reads it, the counts stay uniform)
+                if (f == 3) issue_b(ich < nchunk ? itap : 8, ich < nchunk ? ich : nchunk - 1, sb0 + sb * (B_ELEMS * 4));
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#pragma unroll
+            for (int m = 0; m < NQ; ++m) {
+                if (m % TN == 0) mask_g(cur, m / TN);
+                mma_q(cur, m / TN, m % TN);
+#pragma unroll
+                for (int f = m * (4 / NQ); f < (m + 1) * (4 / NQ); ++f) piece(f);
+            }
+            if (++itap == 9) { itap = 0; ++ich; }
+            if (ntap == 0) hk = 0;
+            sb = sbn;
+            [[maybe_unused]] const unsigned long long tw2 = KOAF_STAMP_NOW();
+            kst_hv += tw1 - tw0;
+            kst_hw += tw2 - tw1;
             tap = ntap; chunk = nch2;
         };
 #pragma unroll 1
         for (int s2 = 0; s2 + 1 < nstep; s2 += 2) {
-            body(F0, F1, true);
-            body(F1, F0, s2 + 2 < nstep);
+            body(F0, F1);
+            body(F1, F0);
         }
-        if (nstep & 1) body(F0, F1, false);
+        if (nstep & 1) body(F0, F1);
+        KOAF_STAMP_ACC(5, kst_hv);
+        KOAF_STAMP_ACC(6, kst_hw);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the surplus fetches behind the last step)
         __syncthreads();       // the epilogue reuses the operand buffers
         } else {
@@ -2513,6 +2562,14 @@ int launch_act(const KoafGemm& g, const TilePlan& tp, dim3 grid, hipStream_t s) 
 #ifdef KOAF_DEV_T2D      // (development builds: only the kernels a 3x3 A/B needs are instantiated -- seconds instead of minutes)
     if (g.M == -12345) hipLaunchKernelGGL((koaf_gemm_kernel<128, 128, M_KC, M_PS, 1, 0, true, true, 256, 0>), grid, dim3(256), 0, s, g);   // (register-usage probe)
     if (g.M == -12346) hipLaunchKernelGGL((koaf_gemm_kernel<128, 128, M_KC, M_PS, 2, 0, true, true, 256, 0>), grid, dim3(256), 0, s, g);
+#ifdef KOAF_DEV_H256
+    if constexpr (ACT == 0) {
+        if (tp.halo && tp.bm == 256 && tp.bn == 128) {
+            hipLaunchKernelGGL((koaf_gemm_kernel<256, 128, M_PH, M_PS, 0, 0, true, true, 512, 0>), grid, dim3(512), 0, s, g);
+            return koaf_check_launch("koaf_gemm/halo");
+        }
+    }
+#endif
     if (!tp.halo || tp.bm != 128) { koaf_set_error("koaf_gemm: KOAF_DEV_T2D build"); return KOAF_EINVAL; }
     if constexpr (ACT != 0) { koaf_set_error("koaf_gemm: KOAF_DEV_T2D build"); return KOAF_EINVAL; }
     else {

@@ -44,7 +44,7 @@ for (N_, H, W, Cin, Cout) in shapes:
         for st in (True, False):
             t, b = timeit(lambda: ops.conv2d_fwd(x, w, N_, H, W, Cin, Cout, k, k, s, p, sc, sh, stats=st, wimg=img, aplanes=pl))
             n = max(b[7], 1)
-            us = [v / n / 100.0 for v in b[:6]]
+            us = [v / n / 100.0 for v in b[:7]]
             print(f"{Cin}->{Cout} @{H} {name} stats={int(st)}: {t:7.3f} ms {fl/t/1e9:6.1f} TF/s | tiles/launch {b[7] // 5}: per tile us: "
-                  f"prologue {us[0]:.2f} k-loop {us[1]:.2f} (chunk waits {us[5]:.2f}) stage {us[2]:.2f} store+stats {us[3]:.2f} total {us[4]:.2f}",
+                  f"prologue {us[0]:.2f} k-loop {us[1]:.2f} (counted waits {us[5]:.2f}, barriers {us[6]:.2f}) stage {us[2]:.2f} store+stats {us[3]:.2f} total {us[4]:.2f}",
                   flush=True)
