@@ -11,8 +11,8 @@ RECORDED = {   # template arguments -> spilled VGPRs at the fixed build (koaf_ge
     "128,128,2,6,0,0,1,1,256,0,0,0": 15, "128,128,0,6,2,0,1,1,256,0,0,0": 0, "128,128,0,6,3,0,1,1,256,0,0,0": 0,
     "128,64,12,6,0,0,1,1,256,0,0,0": 0, "256,128,9,6,0,0,1,1,512,0,0,0": 0,
     # the streamed kernels (A mode 13): the persistent one-source ones carry two k-tiles of the next tile through the epilogue
-    "128,128,13,6,0,0,1,1,256,0,0,2": 16, "128,128,13,6,1,0,1,1,256,0,0,2": 16, "128,128,13,6,0,0,1,1,256,0,1,2": 20,
-    "128,128,13,6,1,0,1,1,256,0,1,2": 20, "128,128,13,6,2,0,1,1,256,0,0,2": 0, "128,128,13,6,3,0,1,1,256,0,0,2": 0,
+    "128,128,13,6,0,0,1,1,256,0,0,2": 16, "128,128,13,6,1,0,1,1,256,0,0,2": 17, "128,128,13,6,0,0,1,1,256,0,1,2": 21,
+    "128,128,13,6,1,0,1,1,256,0,1,2": 22, "128,128,13,6,2,0,1,1,256,0,0,2": 0, "128,128,13,6,3,0,1,1,256,0,0,2": 0,
     "128,64,13,6,2,0,1,1,256,0,0,2": 0, "128,64,13,6,3,0,1,1,256,0,0,2": 0,
 }
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-I../../include",
