@@ -1,7 +1,7 @@
 """(GPU box) the 256-row halo kernel (3x3 / stride 1 / pad 1 over plane images, C >= 128) alone on the three layer shapes of the synthetic
 trunk that use it, 320 slices; with the stamps build (make -C oaprogressionmmf_amd/csrc stamps;
 KOAF_LIB=oaprogressionmmf_amd/csrc/libkoaf_stamps.so) also the per-tile phase times of wave 0
-    python scripts/bench_halo256.py"""
+    python scripts/bench_halo256.py [slices=320] [iterations=10]"""
 import ctypes, os, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -12,7 +12,10 @@ dev = torch.device("cuda:0")
 L = lib()
 buf = (ctypes.c_ulonglong * 8)()
 has = hasattr(L, "koaf_debug_stamps") and "stamps" in os.environ.get("KOAF_LIB", "")
-def timeit(fn, n=10):
+NIT = int(sys.argv[2]) if len(sys.argv) > 2 else 10          # (hundreds: a second of sustained load per shape, as inside the step)
+
+
+def timeit(fn, n=NIT):
     fn(); torch.cuda.synchronize()
     if has: L.koaf_debug_stamps(buf, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,7 +25,8 @@ def timeit(fn, n=10):
     if has: L.koaf_debug_stamps(buf, 0)
     return e0.elapsed_time(e1) / n
 ops.set_conv3x3_halo(2)
-for (N_, H, W, C) in [(320, 48, 48, 128), (320, 24, 24, 256), (320, 12, 12, 512)]:
+NS = int(sys.argv[1]) if len(sys.argv) > 1 else 320        # (1280 = one call of the headline step: the plane images no longer fit the 256 MB cache)
+for (N_, H, W, C) in [(NS, 48, 48, 128), (NS, 24, 24, 256), (NS, 12, 12, 512)]:
     x = torch.randn(N_, H, W, C, device=dev); w = torch.randn(C, 3, 3, C, device=dev) * 0.05
     sc = torch.ones(C, device=dev); sh = torch.zeros(C, device=dev)
     img = ops.build_weight_planes(w, C, 9, C)
