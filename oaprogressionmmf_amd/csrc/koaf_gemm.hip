@@ -1226,6 +1226,10 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
     constexpr int NBA = (APS || (AH && HDB) || WPS) ? 2 : 1;                                  // LDS buffers per operand
     constexpr int NBB = AH ? halo_b_stages(BN, BM) : (AS ? 3 : ((BPS || WPS) ? 2 : 1));
     constexpr int LDC_S = BN + 4;                                    // epilogue staging row (floats)
+    // the 256-row halo kernel multiplies in 16 x 16 x 32 MFMAs (the same FLOPs, LDS bytes and issue cycles as 32 x 32 x 16; the chip
+    // clocks them higher under sustained load: scripts/mfma_shapes.hip, 1.12-1.14 x): its accumulators are NRB x NCB tiles of v4f
+    constexpr bool M16 = (AM == M_PH) && (NT == 512);
+    constexpr int NRB = M16 ? WM / 16 : 1, NCB = M16 ? WN / 16 : 1;
     constexpr int C_ELEMS = VEC ? BM * LDC_S : 0;
     constexpr int OPS = NBA * A_ELEMS + NBB * B_ELEMS;
     // M_PT: the epilogue's staging tile (which the two weight-tile stages of the k-loop share) and the halo image (180 pixels x 64
@@ -1371,6 +1375,11 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    [[maybe_unused]] v4f acc16[NRB][NCB];
+#pragma unroll
+    for (int i = 0; i < NRB; ++i)
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) acc16[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     float* const Bs0 = smem + NBA * A_ELEMS;
     const unsigned sm0 = KOAF_LDS_ADDR(smem), sb0 = sm0 + NBA * A_ELEMS * 4;     // LDS byte addresses of the A / B buffers
@@ -1437,11 +1446,12 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
         const int nchunk = Ca / 32;
         const int swz = 8 * ((lane & 3) ^ ((lane >> 4) & 3));
         // validity bits of the nine taps (bit kh*3+kw) and halo pixel of the centre tap for this lane's row of each M tile
-        unsigned vb[TM];
-        int i0[TM];
+        constexpr int NVB = HDB ? WM / 16 : TM;             // row blocks of a wave: 16 rows (256-row shape: 16 x 16 x 32 MFMAs) or 32
+        unsigned vb[NVB];
+        int i0[NVB];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int lrow = wm * WM + 32 * i + r, row = m0 + lrow;
+        for (int i = 0; i < NVB; ++i) {
+            const int lrow = HDB ? wm * WM + 16 * i + (lane & 15) : wm * WM + 32 * i + r, row = m0 + lrow;
             i0[i] = lrow + Wd + 1;
             vb[i] = 0;
             if (row < p.M) {
@@ -1493,28 +1503,27 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
         const int nh = (np2 + NW - 1) / NW;                 // halo pieces per wave and chunk
         const int hq = nh / NST, hr = nh - hq * NST;        // pieces at tap t < NST: hq + (t < hr)   (<= 2: np2 <= 14 NW)
         const int nstep = 9 * nchunk;
-        struct Frags { v4i a[2][TM][2]; v4i b[2][TN][2]; };
+        // fragments of one step (32 channels of one tap) for 16 x 16 x 32 MFMAs: lane (r = l % 16, c = l / 16) holds k = 8 c .. 8 c + 7 of
+        // row r of its block -- 16-B chunk c of the pixel / weight row, one read per block and plane
+        struct Frags { v4i a[NRB][2]; v4i b[NCB][2]; };
+        const int q4 = lane >> 4;
         // (shift: the tap's pixel offset in the halo, (kh - 1) W + (kw - 1), negated for the data gradient's flipped filter -- carried
         // by the loop, not derived from the tap)
         auto load_frags = [&](Frags& f, int shift, int hbuf, int stage) {
             const lds_u Ah = (lds_u)smem + hbuf * A_ELEMS;
             const lds_u Bu = (lds_u)smem + NBA * A_ELEMS + stage * B_ELEMS;
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int i = 0; i < NRB; ++i) {
+                const int hp = i0[i] + shift;
+                const int off = hp * 16 + 4 * (q4 ^ ((hp >> 2) & 3));
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int hp = i0[i] + shift;
-                    const int off = hp * 16 + 4 * ((2 * g + h) ^ ((hp >> 2) & 3));
+                for (int q = 0; q < 2; ++q) f.a[i][q] = *(lds_v4i)&Ah[q * A_PL + off];
+            }
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) f.a[g][i][q] = *(lds_v4i)&Ah[q * A_PL + off];
-                }
+            for (int j = 0; j < NCB; ++j) {
+                const int brow = wn * WN + 16 * j + (lane & 15);
 #pragma unroll
-                for (int jn = 0; jn < TN; ++jn) {
-                    const int brow = wn * WN + 32 * jn + (lane & 31);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        f.b[g][jn][q] = *(lds_v4i)&Bu[q * B_PL + brow * 16 + 4 * ((2 * g + h) ^ ((brow >> 2) & 3))];   // = frag_load_ps
-                }
+                for (int q = 0; q < 2; ++q) f.b[j][q] = *(lds_v4i)&Bu[q * B_PL + brow * 16 + 4 * (q4 ^ ((brow >> 2) & 3))];
             }
         };
         for (int idx = w; idx < np2; idx += NW) issue_halo(idx, 0, sm0);
@@ -1555,29 +1564,28 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
             __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0)
             asm volatile("s_barrier" ::: "memory");
         };
-        // One step = four (two: 64 columns) groups of six MFMAs (k-group g, column tile jn), each followed by a piece of everything else (the
+        // One step = four (two: 64 columns) groups of twelve MFMAs (one 16-column block), each followed by a piece of everything else (the
         // fragment reads of step s + 1, the two halo pieces, the weight tile), pinned by scheduling barriers: a wave issues in
         // order, and the address arithmetic in one block in front of 24 back-to-back MFMAs ran with the matrix pipe idle in both
         // waves of the SIMD (the step barrier keeps them in lockstep).
-        auto mask_g = [&](Frags& f, int g) {       // (in place: the set is dead after its step)
+        auto mask_all = [&](Frags& f) {       // (in place: the set is dead after its step)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < NRB; ++i) {
                 const int okm = -(int)((vb[i] >> tap) & 1u);       // all ones / zero: the tap's validity as an AND mask
 #pragma unroll
-                for (int q = 0; q < 2; ++q) f.a[g][i][q] = and_mask(f.a[g][i][q], okm);
+                for (int q = 0; q < 2; ++q) f.a[i][q] = and_mask(f.a[i][q], okm);
             }
         };
-        auto mma_q = [&](Frags& f, int g, int jn) {
+        auto mma_col = [&](Frags& f, int j) {      // column block j: 3 NRB MFMAs
             constexpr int PAH[3] = {1, 0, 0}, PBH[3] = {0, 1, 0};
 #pragma unroll
             for (int term = 0; term < 3; ++term)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, f.a[g][i][PAH[term]]),
-                                                                        __builtin_bit_cast(h16x8, f.b[g][jn][PBH[term]]),
-                                                                        acc[i][jn], 0, 0, 0);
+                for (int i = 0; i < NRB; ++i)
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, f.a[i][PAH[term]]),
+                                                                          __builtin_bit_cast(h16x8, f.b[j][PBH[term]]), acc16[i][j], 0, 0, 0);
         };
-        constexpr int NQ = 2 * TN;          // MFMA groups of a step: (g, jn)
+        constexpr int NQ = NCB;             // MFMA groups of a step
         static_assert(NQ == 4 || NQ == 2, "the four pieces follow the MFMA groups in ones or twos");
         auto body = [&](Frags& cur, Frags& nxt) {
             [[maybe_unused]] const unsigned long long tw0 = KOAF_STAMP_NOW();
@@ -1606,8 +1614,8 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
             };
 #pragma unroll
             for (int m = 0; m < NQ; ++m) {
-                if (m % TN == 0) mask_g(cur, m / TN);
-                mma_q(cur, m / TN, m % TN);
+                if (m == 0) mask_all(cur);
+                mma_col(cur, m);
 #pragma unroll
                 for (int f = m * (4 / NQ); f < (m + 1) * (4 / NQ); ++f) piece(f);
             }
@@ -2045,6 +2053,15 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
     // (per 32-row band i of the wave's rows: the tile's sums are then the same tree whether its four bands sit in two waves or,
     // on the streamed kernels, in four -- band sums, lane halves, band pairs, pair of pairs)
     float s1[TM][TN], s2[TM][TN], kshift[TN];
+    [[maybe_unused]] float t1[NCB], t2[NCB], kshift16[NCB];      // (M16: per 16-column block)
+    if constexpr (M16) {
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) {
+            t1[j] = t2[j] = 0.f;
+            const int scol = n0 + wn * WN + 16 * j + (lane & 15);
+            kshift16[j] = (do_stats && p.stats_shift && scol < p.N) ? p.stats_shift[(int64_t)blockIdx.z * p.stats_bs + scol] : 0.f;
+        }
+    }
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
 #pragma unroll
@@ -2062,6 +2079,20 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
         // convolutions; staging in two 64-row halves to fit a third block per CU needs <= 168 VGPRs, which spills ~130
         // dwords per lane here and halves the speed.)
         float* Cs = smem;   // all waves passed the k-loop's last barrier: operand tiles are dead
+        if constexpr (M16) {
+            // 16 x 16 tiles: lane (c = l % 16, q = l / 16) holds column c, rows 4 q + e of its tile
+#pragma unroll
+            for (int i = 0; i < NRB; ++i)
+#pragma unroll
+                for (int j = 0; j < NCB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = alpha * acc16[i][j][e];
+                        t1[j] += v - kshift16[j];
+                        t2[j] = fmaf(v - kshift16[j], v - kshift16[j], t2[j]);
+                        Cs[(wm * WM + 16 * i + 4 * (lane >> 4) + e) * LDC_S + wn * WN + 16 * j + (lane & 15)] = v;
+                    }
+        } else
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -2196,6 +2227,19 @@ __global__ void __launch_bounds__(NT, (persist_mode(AM, BMD, F16, TFA) || AM == 
     if (do_stats) {
         // column sums over this block's BM rows: lanes (r,0)+(r,1), then the WGM M-waves via LDS
         float* red = smem;  // [WGM][2][BN]
+        if constexpr (M16) {
+            // the four lane quarters hold rows 4 q .. 4 q + 3 of every tile of the column
+#pragma unroll
+            for (int j = 0; j < NCB; ++j) {
+                float a1 = t1[j] + __shfl_xor(t1[j], 16, 64), a2 = t2[j] + __shfl_xor(t2[j], 16, 64);
+                a1 += __shfl_xor(a1, 32, 64);
+                a2 += __shfl_xor(a2, 32, 64);
+                if (lane < 16) {
+                    red[(wm * 2 + 0) * BN + wn * WN + 16 * j + lane] = a1;
+                    red[(wm * 2 + 1) * BN + wn * WN + 16 * j + lane] = a2;
+                }
+            }
+        } else
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
             float a1 = s1[0][jn] + __shfl_xor(s1[0][jn], 32, 64);
