@@ -390,3 +390,27 @@ def test_model_config_groups_load():
             assert len(ns) == len(cfg["input_size"])
     m = dict_models["XR1C1Cnn"](config=load_model_config("xr1c1_cnn"), path_weights=None)
     assert m.vs["agg_in_len"] == 4096
+
+
+def test_clock_per_kernel_reduction(tmp_path):
+    """scripts/clock_per_kernel.py: clock = GRBM_GUI_ACTIVE / 8 XCDs / duration, matrix-pipe share = busy cycles / 1024 SIMDs / cycles,
+    per kernel template, first two launches of a group skipped"""
+    import json
+    import subprocess
+    import sys
+    rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
+    name = '"void (anonymous namespace)::koaf_gemm_kernel<256, 128, 9, 6, 0, 0, true, true, 512, 0, false, 0>(KoafGemm)"'
+    for d in range(1, 8):
+        dur_ns = 2_000_000 if d > 2 else 9_000_000                    # (the two skipped launches would spoil the average)
+        cyc = 1.9e9 * dur_ns * 1e-9                                  # 1.9 GHz
+        for xcd in range(8):
+            rows.append(f"{d},{name},GRBM_GUI_ACTIVE,{cyc},{1000},{1000 + dur_ns}")
+        rows.append(f"{d},{name},SQ_VALU_MFMA_BUSY_CYCLES,{0.5 * cyc * 1024},{1000},{1000 + dur_ns}")
+    src = tmp_path / "c.csv"
+    src.write_text("\n".join(rows) + "\n")
+    out = tmp_path / "o.json"
+    root = Path(__file__).resolve().parent.parent
+    subprocess.run([sys.executable, str(root / "scripts" / "clock_per_kernel.py"), str(src), str(out), "1"], check=True, capture_output=True)
+    k = json.loads(out.read_text())["kernels"]
+    assert len(k) == 1 and k[0]["launches"] == 5 and k[0]["kernel"].startswith("koaf_gemm_kernel<256, 128, 9,")
+    assert abs(k[0]["clock_ghz"] - 1.9) < 1e-3 and abs(k[0]["mfma_busy_frac_at_clock"] - 0.5) < 1e-3 and abs(k[0]["avg_us"] - 2000.0) < 1e-6
