@@ -24,7 +24,7 @@ def timeit(fn, n=NIT):
     e1.record(); torch.cuda.synchronize()
     if has: L.koaf_debug_stamps(buf, 0)
     return e0.elapsed_time(e1) / n
-ops.set_conv3x3_halo(2)
+ops.set_conv3x3_halo(int(os.environ.get("KOAF_BENCH_HALO", "2")))       # (2: the 256-row shape; 3: 128 rows, two blocks per CU)
 NS = int(sys.argv[1]) if len(sys.argv) > 1 else 320        # (1280 = one call of the headline step: the plane images no longer fit the 256 MB cache)
 for (N_, H, W, C) in [(NS, 48, 48, 128), (NS, 24, 24, 256), (NS, 12, 12, 512)]:
     x = torch.randn(N_, H, W, C, device=dev); w = torch.randn(C, 3, 3, C, device=dev) * 0.05
